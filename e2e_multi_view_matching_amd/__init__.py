@@ -1,0 +1,16 @@
+"""e2e_multi_view_matching_amd - MI355X-native matcher -> Sinkhorn -> weighted-8-point path.
+
+Python surface (mirrors the reference's callables):
+  MultiViewMatcher / SuperGlue, estimate_relative_pose_w8pt, run_weighted_8_point, get_kpts,
+  normalize, compute_rotation_error, compute_translation_error_as_angle, pose_auc.
+Everything computes in libe2emv.so (hand-written HIP for gfx950) through ctypes.
+"""
+from .matcher import MultiViewMatcher, SuperGlue  # noqa: F401
+from .metrics import compute_pose_error, pose_auc  # noqa: F401
+from .ops import attention, extract_matches, gemm_nt, log_optimal_transport  # noqa: F401
+from .pose import (compute_rotation_error, compute_translation_error_as_angle, estimate_relative_pose_w8pt,  # noqa: F401
+                   get_kpts, normalize, pose_errors, run_weighted_8_point)
+
+__all__ = ["MultiViewMatcher", "SuperGlue", "estimate_relative_pose_w8pt", "run_weighted_8_point", "get_kpts",
+           "normalize", "compute_rotation_error", "compute_translation_error_as_angle", "pose_errors", "pose_auc",
+           "compute_pose_error", "log_optimal_transport", "extract_matches", "gemm_nt", "attention"]

@@ -1,0 +1,168 @@
+"""ctypes binding of libe2emv.so (include/e2emv.h).  No torch ops on the hot path: torch is
+only the owner of device memory and streams; every compute call goes through the C ABI.
+
+There is NO fallback: if the library or a gfx950 device is missing, ``context()`` raises.
+"""
+import ctypes
+import os
+import threading
+
+import torch  # noqa: F401  (imported first so libamdhip64.so.7 resolves to the runtime torch loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libe2emv.so")
+
+MAX_TUPLE, MAX_LAYERS, MAX_KENC, PROF_SLOTS = 8, 64, 8, 16
+FLAG_FULL_OUTPUT, FLAG_MULTI_FRAME = 1, 2
+DESC_F32, DESC_F16 = 0, 1
+OK, EINVAL, ENOMEM, EHIP, ESHAPE, ESTATE = 0, -1, -2, -3, -4, -5
+
+c_void_p, c_int, c_float, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_char_p
+c_int64, c_size_t = ctypes.c_int64, ctypes.c_size_t
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [("desc_dim", ctypes.c_int32), ("num_heads", ctypes.c_int32), ("n_kenc", ctypes.c_int32),
+                ("kenc", ctypes.c_int32 * MAX_KENC), ("n_layers", ctypes.c_int32),
+                ("layer_types", ctypes.c_int32 * MAX_LAYERS), ("conf_mlp", ctypes.c_int32)]
+
+
+class ForwardDesc(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int32), ("tuple_size", ctypes.c_int32), ("n_kpts", ctypes.c_int32),
+                ("sinkhorn_iters", ctypes.c_int32), ("match_threshold", ctypes.c_float),
+                ("desc_dtype", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("img_w", ctypes.c_float * MAX_TUPLE), ("img_h", ctypes.c_float * MAX_TUPLE)]
+
+
+# every symbol include/e2emv.h declares: name -> (restype, argtypes)
+_PP = ctypes.POINTER(c_void_p)
+SIGNATURES = {
+    "e2emv_version": (c_int, []),
+    "e2emv_create": (c_int, [ctypes.POINTER(c_void_p), c_int]),
+    "e2emv_destroy": (None, [c_void_p]),
+    "e2emv_last_error": (c_char_p, [c_void_p]),
+    "e2emv_malloc": (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_size_t]),
+    "e2emv_free": (c_int, [c_void_p, c_void_p]),
+    "e2emv_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "e2emv_d2h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "e2emv_sync": (c_int, [c_void_p, c_void_p]),
+    "e2emv_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, ctypes.POINTER(c_int64), c_int]),
+    "e2emv_commit_weights": (c_int, [c_void_p, ctypes.POINTER(ModelDesc)]),
+    "e2emv_matcher_forward": (c_int, [c_void_p, ctypes.POINTER(ForwardDesc), _PP, _PP, _PP, _PP, _PP, _PP, _PP, _PP, _PP,
+                                      c_void_p]),
+    "e2emv_sinkhorn": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_void_p]),
+    "e2emv_extract_matches": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
+    "e2emv_gather_matched": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
+    "e2emv_w8pt": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                           c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                           c_void_p]),
+    "e2emv_pose_errors": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e2emv_gemm_nt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                              c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                              c_int64, c_float, c_int, c_void_p]),
+    "e2emv_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "e2emv_profile": (c_int, [c_void_p, c_int]),
+    "e2emv_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int64), c_int, c_int]),
+    "e2emv_profile_name": (c_char_p, [c_int]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_contexts = {}
+
+
+class E2EMVError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libe2emv error {code}: {msg}")
+        self.code = code
+
+
+def load_library():
+    """dlopen libe2emv.so and attach the prototypes.  Raises if the .so is absent/stale."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing - build it with `python -m e2e_multi_view_matching_amd.build` "
+                              "(there is no CPU/PyTorch fallback for the hot path)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if lib.e2emv_version() != 1:
+            raise ImportError("libe2emv.so ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+class Context:
+    """One library context per (process, device)."""
+
+    def __init__(self, device):
+        self.lib = load_library()
+        self.device = int(device)
+        h = c_void_p()
+        rc = self.lib.e2emv_create(ctypes.byref(h), self.device)
+        if rc != OK:
+            raise E2EMVError(rc, f"cannot create a context on device {device}: no usable MI355X (gfx950) - "
+                                 "the HIP path has no CPU fallback")
+        self.h = h
+
+    def check(self, rc):
+        if rc != OK:
+            raise E2EMVError(rc, self.lib.e2emv_last_error(self.h).decode())
+
+    def call(self, name, *args):
+        self.check(getattr(self.lib, name)(self.h, *args))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.e2emv_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def context(device=None):
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if isinstance(device, torch.device):
+        device = device.index if device.index is not None else torch.cuda.current_device()
+    with _lock:
+        ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        with _lock:
+            _contexts[device] = ctx
+    return ctx
+
+
+def stream_ptr(device):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def ptr_array(tensors):
+    arr = (c_void_p * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return ctypes.cast(arr, _PP), arr
+
+
+def profile_read(ctx, reset=True):
+    ms = (c_float * PROF_SLOTS)()
+    n = (c_int64 * PROF_SLOTS)()
+    ctx.call("e2emv_profile_read", ms, n, PROF_SLOTS, 1 if reset else 0)
+    out = {}
+    for i in range(PROF_SLOTS):
+        name = ctx.lib.e2emv_profile_name(i).decode()
+        if name:
+            out[name] = {"ms": float(ms[i]), "launches": int(n[i])}
+    return out

@@ -1,0 +1,202 @@
+// Fused multi-head attention softmax(q k^T / sqrt(d)) v for the attentional GNN, fp32 on the
+// gfx950 matrix cores, flash-style (the H x N x N_src probability tensor the reference
+// materialises per layer - upstream superglue.py `attention()`, einsum 'bdhn,bdhm->bhnm' -
+// never exists).  Self layers attend inside an image, cross layers to every other image of
+// the tuple (N_src = (T-1) N; T = 2 is upstream SuperGlue's swap).
+//
+// Layout: qkv [n_img][n_rows][3D], channels head-major (c = h*64 + dd; the upstream order
+// c = dd*H + h is undone on the weights at load time, ctx.hip), image g = b*T + t.
+//
+// Per workgroup: one (image, head, 128-query tile); 4 waves x 32 queries.  Everything is
+// computed TRANSPOSED so that each lane owns ONE query (q = lane & 31) for its whole life:
+//   S^T[key][q] = mfma(A = K tile rows, B = Q)          -> a lane holds 16 keys of its query
+//   O^T[d][q]  += mfma(A = V^T,           B = P^T)      -> the B operand of step t is exactly
+// register t of the exponentiated S^T accumulator (MFMA 32x32 C layout: row = (r&3)+8(r>>2)
+// +4(lane>>5)), so P never moves between lanes or through LDS, the running max/sum are
+// per-lane scalars (+ one lane^32 exchange), and rescaling O^T is lane-local.
+// K tiles sit in LDS padded to 68 floats (conflict-free ds_read_b128, one read feeds four
+// MFMAs through the same K-slot permutation as gemm.hip); V tiles unpadded (ds_read_b32 of
+// 32 consecutive floats).  128 MFMAs (8192 cycles) per wave per 64-key tile against ~1.3k
+// VALU cycles of softmax: the kernel is MFMA-issue bound by construction.
+#include "common.h"
+
+namespace e2emv {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int ATT_Q = 128;   // queries per workgroup
+constexpr int ATT_KV = 64;   // keys per LDS tile
+constexpr int HD = 64;       // head dim
+constexpr int KLD = 68;      // padded K row (floats)
+
+struct AttnParams {
+    const float* qkv;
+    float* out;
+    int B, T, n_rows, n_valid, D, H, cross;
+    int nq, groups, gper;
+};
+
+__global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float Ks[ATT_KV * KLD];
+    __shared__ __attribute__((aligned(16))) float Vs[ATT_KV * HD];
+
+    // XCD-aware mapping: all query tiles of one (image, head) share an XCD (K/V stay in its L2)
+    const int lin = blockIdx.x;
+    const int xcd = lin & 7, idx = lin >> 3;
+    const int g = xcd * p.gper + idx / p.nq;
+    if (g >= p.groups) return;
+    const int qt = idx % p.nq;
+    const int img = g / p.H, head = g % p.H;
+    const int b = img / p.T, t = img % p.T;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int64_t row_stride = 3 * (int64_t)p.D;
+    const int64_t img_stride = (int64_t)p.n_rows * row_stride;
+
+    // ---- Q fragment: lane (q, lh) holds Q[q][8s + 4lh .. +3], pre-scaled by log2(e)/sqrt(d)
+    const int q_row = qt * ATT_Q + wave * 32 + l31;
+    const float qscale = 0.125f * 1.4426950408889634f;
+    f32x4 Qr[8];
+    {
+        const float* qp = p.qkv + img * img_stride + (int64_t)q_row * row_stride + head * HD + lh * 4;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(qp + s * 8);
+            Qr[s] = v * qscale;
+        }
+    }
+
+    f32x16 O0, O1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int n_src = p.cross ? p.T - 1 : 1;
+    const int tiles_per_img = (p.n_valid + ATT_KV - 1) / ATT_KV;
+    const int n_tiles = n_src * tiles_per_img;
+
+    // staging map: 4 float4 of K and of V per thread
+    const int st_row = tid >> 4;         // 0..15 (+16*i)
+    const int st_c4 = (tid & 15) * 4;
+    f32x4 rk[4], rv[4];
+    auto src_img = [&](int si) {
+        if (!p.cross) return img;
+        int tt = si < t ? si : si + 1;
+        return b * p.T + tt;
+    };
+    auto gload = [&](int tile) {
+        const int si = tile / tiles_per_img, kt = tile % tiles_per_img;
+        const float* base = p.qkv + src_img(si) * img_stride + (int64_t)(kt * ATT_KV) * row_stride + head * HD + st_c4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* rp = base + (int64_t)(st_row + 16 * i) * row_stride;
+            rk[i] = *reinterpret_cast<const f32x4*>(rp + p.D);
+            rv[i] = *reinterpret_cast<const f32x4*>(rp + 2 * p.D);
+        }
+    };
+
+    gload(0);
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        __syncthreads();  // everyone is done reading the previous tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&Ks[(st_row + 16 * i) * KLD + st_c4]) = rk[i];
+            *reinterpret_cast<f32x4*>(&Vs[(st_row + 16 * i) * HD + st_c4]) = rv[i];
+        }
+        __syncthreads();
+        if (tile + 1 < n_tiles) gload(tile + 1);
+
+        const int kt = tile % tiles_per_img;
+        const int valid_in_tile = p.n_valid - kt * ATT_KV;  // >= 1
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (sub * 32 >= valid_in_tile) break;  // wave-uniform
+            f32x16 S;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[r] = 0.f;
+            const float* kp = &Ks[(sub * 32 + l31) * KLD + lh * 4];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                f32x4 kf = *reinterpret_cast<const f32x4*>(kp + s * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], Qr[s][e], S, 0, 0, 0);
+            }
+            if (valid_in_tile < sub * 32 + 32) {  // ragged tail: mask keys >= n_valid
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= valid_in_tile) S[r] = -INFINITY;
+                }
+            }
+            float mx = S[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                S[r] = __builtin_amdgcn_exp2f(S[r] - m_new);
+                ps += S[r];
+            }
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { O0[r] *= alpha; O1[r] *= alpha; }
+            // O^T[d][q] += V^T[d][key] P^T[key][q]
+            const float* vp = &Vs[(sub * 32 + 4 * lh) * HD + l31];
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) {
+                const int krow = (tt & 3) + 8 * (tt >> 2);
+                const float v0 = vp[krow * HD];
+                const float v1 = vp[krow * HD + 32];
+                O0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, S[tt], O0, 0, 0, 0);
+                O1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, S[tt], O1, 0, 0, 0);
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    float* op = p.out + ((int64_t)img * p.n_rows + q_row) * p.D + head * HD + 4 * lh;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        f32x4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = O0[gq * 4 + e] * inv; c[e] = O1[gq * 4 + e] * inv; }
+        *reinterpret_cast<f32x4*>(op + 8 * gq) = a;
+        *reinterpret_cast<f32x4*>(op + 32 + 8 * gq) = c;
+    }
+}
+
+int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* qkv,
+                     int cross, float* out, hipStream_t s) {
+    if (D != H * HD) return set_err(ctx, E2EMV_ESHAPE, "attention: head dim must be 64 (D=%d H=%d)", D, H);
+    if (n_rows % ATT_Q || n_valid <= 0 || n_valid > n_rows)
+        return set_err(ctx, E2EMV_ESHAPE, "attention: n_rows=%d must be a multiple of %d and >= n_valid=%d", n_rows, ATT_Q, n_valid);
+    if (cross && T < 2) return set_err(ctx, E2EMV_ESHAPE, "attention: cross layer needs T >= 2");
+    AttnParams p;
+    p.qkv = qkv; p.out = out; p.B = B; p.T = T; p.n_rows = n_rows; p.n_valid = n_valid; p.D = D; p.H = H;
+    p.cross = cross;
+    p.nq = (n_valid + ATT_Q - 1) / ATT_Q;
+    p.groups = B * T * H;
+    p.gper = (p.groups + 7) / 8;
+    dim3 grid(8 * p.gper * p.nq);
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, s, p);
+    E2EMV_CHECK_LAUNCH(ctx, "attention_kernel");
+    return E2EMV_OK;
+}
+
+}  // namespace e2emv
+
+extern "C" int e2emv_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv,
+                               int cross, float* d_out, void* stream) {
+    if (!ctx || !d_qkv || !d_out) return E2EMV_EINVAL;
+    e2emv::prof_begin(ctx, e2emv::PS_ATTN, (hipStream_t)stream);
+    int rc = e2emv::launch_attention(ctx, B, T, n_rows, n_valid, D, H, d_qkv, cross, d_out, (hipStream_t)stream);
+    e2emv::prof_end(ctx, (hipStream_t)stream);
+    return rc;
+}

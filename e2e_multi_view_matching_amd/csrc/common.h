@@ -1,0 +1,167 @@
+// Internal declarations shared by the HIP translation units of libe2emv.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/e2emv.h"
+
+namespace e2emv {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// profile slots (kernel families)
+enum ProfSlot {
+    PS_INGEST = 0,
+    PS_GEMM,
+    PS_ATTN,
+    PS_SCORE,
+    PS_SINKHORN,
+    PS_MATCH,
+    PS_CONF,
+    PS_W8PT,
+    PS_MISC,
+    PS_COUNT
+};
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+struct LayerWeights {
+    // all device pointers into the weight arena; GEMM weights are [out][in] row-major
+    float* w_qkv = nullptr;   // [3D][D]   rows head-major: q | k | v
+    float* b_qkv = nullptr;   // [3D]
+    float* w_merge = nullptr; // [D][D]    input columns head-major
+    float* b_merge = nullptr;
+    float* w_mlp0 = nullptr;  // [2D][2D]  BN folded
+    float* b_mlp0 = nullptr;
+    float* w_mlp1 = nullptr;  // [D][2D]
+    float* b_mlp1 = nullptr;
+    int type = 0;             // 0 self, 1 cross
+};
+
+struct ProfEvent {
+    hipEvent_t a, b;
+    int slot;
+};
+
+}  // namespace e2emv
+
+struct e2emv_ctx {
+    int device = 0;
+    int num_cus = 256;
+    std::string err;
+    // raw host weights as handed over by e2emv_set_weight
+    std::map<std::string, e2emv::HostTensor> raw;
+    // committed model
+    bool committed = false;
+    e2emv_model_desc model{};
+    float* d_warena = nullptr;
+    size_t warena_floats = 0;
+    // keypoint encoder: layer 0 (3->c0) used by the ingest kernel, the rest through the GEMM
+    float* kenc_w0 = nullptr;  // [c0][3] folded
+    float* kenc_b0 = nullptr;  // [c0]
+    std::vector<float*> kenc_w, kenc_b;  // layers 1..n (folded), [out][in]
+    std::vector<int> kenc_dims;          // [3, c0, c1, ..., D]
+    std::vector<e2emv::LayerWeights> layers;
+    float* w_final = nullptr;
+    float* b_final = nullptr;
+    float bin_score = 1.f;
+    float* w_conf0 = nullptr;  // [D][2D] folded
+    float* b_conf0 = nullptr;
+    float* w_conf1 = nullptr;  // [D]
+    float b_conf1 = 0.f;
+    // workspace arena
+    char* d_ws = nullptr;
+    size_t ws_bytes = 0;
+    // profiling
+    bool prof = false;
+    std::vector<e2emv::ProfEvent> prof_events;
+    std::vector<hipEvent_t> event_pool;
+    float prof_ms[E2EMV_PROF_SLOTS] = {0};
+    int64_t prof_n[E2EMV_PROF_SLOTS] = {0};
+};
+
+namespace e2emv {
+
+int set_err(e2emv_ctx* ctx, int code, const char* fmt, ...);
+
+#define E2EMV_HIP(ctx, expr)                                                                      \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return e2emv::set_err(ctx, E2EMV_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                  __FILE__, __LINE__);                                            \
+    } while (0)
+
+#define E2EMV_CHECK_LAUNCH(ctx, what)                                                             \
+    do {                                                                                          \
+        hipError_t _e = hipGetLastError();                                                        \
+        if (_e != hipSuccess)                                                                     \
+            return e2emv::set_err(ctx, E2EMV_EHIP, "launch of %s failed: %s", what, hipGetErrorString(_e)); \
+    } while (0)
+
+// workspace: returns a device pointer to at least `bytes` (256-B aligned); grows the arena
+// (synchronising) when needed.  The arena is carved by a bump offset per top-level call.
+int ws_reserve(e2emv_ctx* ctx, size_t bytes);
+
+struct WsBump {
+    e2emv_ctx* ctx;
+    size_t off = 0;
+    explicit WsBump(e2emv_ctx* c) : ctx(c) {}
+    template <typename T>
+    T* take(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        T* p = reinterpret_cast<T*>(ctx->d_ws + off);
+        off += bytes;
+        return p;
+    }
+};
+
+// RAII-less profiling bracket
+void prof_begin(e2emv_ctx* ctx, int slot, hipStream_t s);
+void prof_end(e2emv_ctx* ctx, hipStream_t s);
+
+// ---- kernel launchers (defined in the respective .hip files) ----
+struct GemmArgs {
+    int batch = 1, M = 0, N = 0, K = 0, K1 = 0;
+    const float* A = nullptr;
+    int64_t lda = 0, sA = 0;
+    const float* A2 = nullptr;
+    int64_t lda2 = 0, sA2 = 0;
+    const float* W = nullptr;
+    int64_t ldw = 0, sW = 0;
+    const float* bias = nullptr;
+    const float* R = nullptr;
+    int64_t ldr = 0, sR = 0;
+    float* C = nullptr;
+    int64_t ldc = 0, sC = 0;
+    float scale = 1.f;
+    bool relu = false;
+};
+int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s);
+
+int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* qkv,
+                     int cross, float* out, hipStream_t s);
+
+// Sinkhorn on an internal score buffer S [B][M][ldS] (ldS % 4 == 0); writes logZ dense
+// [B][M+1][N+1] (optional) and, when wanted, the match outputs.
+struct SinkhornOut {
+    float* logZ = nullptr;
+    int64_t* m0 = nullptr;
+    int64_t* m1 = nullptr;
+    float* ms0 = nullptr;
+    float* ms1 = nullptr;
+};
+size_t sinkhorn_ws_bytes(int B, int M, int N);
+int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t ldS, float alpha, int iters,
+                    float match_thr, const SinkhornOut& out, char* ws, hipStream_t s);
+
+}  // namespace e2emv

@@ -1,0 +1,387 @@
+// Context lifecycle, memory helpers, weight ingestion (BN folding + head-major re-ordering),
+// workspace arena and the HIP-event profiling hooks of libe2emv.so.
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+namespace e2emv {
+
+int set_err(e2emv_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+int ws_reserve(e2emv_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return E2EMV_OK;
+    E2EMV_HIP(ctx, hipDeviceSynchronize());
+    if (ctx->d_ws) E2EMV_HIP(ctx, hipFree(ctx->d_ws));
+    ctx->d_ws = nullptr;
+    ctx->ws_bytes = 0;
+    size_t want = bytes + bytes / 8 + (size_t(1) << 20);
+    void* p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        return set_err(ctx, E2EMV_ENOMEM, "workspace allocation of %zu bytes failed", want);
+    }
+    // padded rows of activation buffers must start finite (see forward.hip)
+    E2EMV_HIP(ctx, hipMemset(p, 0, want));
+    ctx->d_ws = static_cast<char*>(p);
+    ctx->ws_bytes = want;
+    return E2EMV_OK;
+}
+
+static hipEvent_t take_event(e2emv_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(e2emv_ctx* ctx, int slot, hipStream_t s) {
+    if (!ctx->prof) return;
+    ProfEvent pe;
+    pe.a = take_event(ctx);
+    pe.b = take_event(ctx);
+    pe.slot = slot;
+    (void)hipEventRecord(pe.a, s);
+    ctx->prof_events.push_back(pe);
+}
+
+void prof_end(e2emv_ctx* ctx, hipStream_t s) {
+    if (!ctx->prof || ctx->prof_events.empty()) return;
+    (void)hipEventRecord(ctx->prof_events.back().b, s);
+}
+
+}  // namespace e2emv
+
+using namespace e2emv;
+
+static const char* kProfNames[PS_COUNT] = {"ingest", "gemm", "attention", "score_gemm", "sinkhorn",
+                                           "match", "conf", "w8pt", "misc"};
+
+extern "C" {
+
+int e2emv_version(void) { return E2EMV_ABI_VERSION; }
+
+int e2emv_create(e2emv_ctx** out, int device) {
+    if (!out) return E2EMV_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return E2EMV_EHIP;
+    }
+    if (device < 0 || device >= n) return E2EMV_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return E2EMV_EHIP;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return E2EMV_EHIP;
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) return E2EMV_EHIP;  // kernels are gfx950-only
+    e2emv_ctx* ctx = new (std::nothrow) e2emv_ctx();
+    if (!ctx) return E2EMV_ENOMEM;
+    ctx->device = device;
+    ctx->num_cus = p.multiProcessorCount;
+    *out = ctx;
+    return E2EMV_OK;
+}
+
+void e2emv_destroy(e2emv_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_warena) (void)hipFree(ctx->d_warena);
+    for (auto& pe : ctx->prof_events) {
+        (void)hipEventDestroy(pe.a);
+        (void)hipEventDestroy(pe.b);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+const char* e2emv_last_error(const e2emv_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int e2emv_malloc(e2emv_ctx* ctx, void** d_ptr, size_t bytes) {
+    if (!ctx || !d_ptr) return E2EMV_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        return set_err(ctx, E2EMV_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    }
+    return E2EMV_OK;
+}
+
+int e2emv_free(e2emv_ctx* ctx, void* d_ptr) {
+    if (!ctx) return E2EMV_EINVAL;
+    if (d_ptr) E2EMV_HIP(ctx, hipFree(d_ptr));
+    return E2EMV_OK;
+}
+
+int e2emv_h2d(e2emv_ctx* ctx, void* d_dst, const void* src, size_t bytes, void* stream) {
+    if (!ctx || (!d_dst && bytes) || (!src && bytes)) return E2EMV_EINVAL;
+    E2EMV_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return E2EMV_OK;
+}
+
+int e2emv_d2h(e2emv_ctx* ctx, void* dst, const void* d_src, size_t bytes, void* stream) {
+    if (!ctx || (!dst && bytes) || (!d_src && bytes)) return E2EMV_EINVAL;
+    E2EMV_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return E2EMV_OK;
+}
+
+int e2emv_sync(e2emv_ctx* ctx, void* stream) {
+    if (!ctx) return E2EMV_EINVAL;
+    E2EMV_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return E2EMV_OK;
+}
+
+int e2emv_set_weight(e2emv_ctx* ctx, const char* key, const float* data, const int64_t* shape, int ndim) {
+    if (!ctx || !key || !data || ndim < 0 || ndim > 4 || (ndim && !shape)) return E2EMV_EINVAL;
+    std::string k(key);
+    if (k.rfind("module.", 0) == 0) k = k.substr(7);
+    HostTensor t;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0) return set_err(ctx, E2EMV_ESHAPE, "negative dim in '%s'", key);
+        t.shape.push_back(shape[i]);
+        n *= shape[i];
+    }
+    t.data.assign(data, data + n);
+    ctx->raw[k] = std::move(t);
+    ctx->committed = false;
+    return E2EMV_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Packer {
+    std::vector<float> host;
+    size_t add(const std::vector<float>& v) {
+        size_t off = (host.size() + 63) & ~size_t(63);  // 256-B aligned segments
+        host.resize(off);
+        host.insert(host.end(), v.begin(), v.end());
+        return off;
+    }
+};
+
+const HostTensor* find(e2emv_ctx* ctx, const std::string& k) {
+    auto it = ctx->raw.find(k);
+    return it == ctx->raw.end() ? nullptr : &it->second;
+}
+
+// conv weight [out][in](,1) -> checked copy
+int get_conv(e2emv_ctx* ctx, const std::string& prefix, int out, int in, std::vector<float>& w,
+             std::vector<float>& b) {
+    const HostTensor* tw = find(ctx, prefix + ".weight");
+    const HostTensor* tb = find(ctx, prefix + ".bias");
+    if (!tw || !tb) return set_err(ctx, E2EMV_ESTATE, "missing weight '%s.{weight,bias}'", prefix.c_str());
+    if ((int64_t)tw->data.size() != (int64_t)out * in || (int64_t)tb->data.size() != out)
+        return set_err(ctx, E2EMV_ESHAPE, "'%s': expected [%d,%d], got %zu elements", prefix.c_str(), out, in,
+                       tw->data.size());
+    w = tw->data;
+    b = tb->data;
+    return E2EMV_OK;
+}
+
+// fold eval-mode BatchNorm1d `bn` (if present) into conv (w [out][in], b [out])
+int fold_bn(e2emv_ctx* ctx, const std::string& bn, int out, int in, std::vector<float>& w, std::vector<float>& b) {
+    const HostTensor* mean = find(ctx, bn + ".running_mean");
+    if (!mean) return E2EMV_OK;  // fork without BN: nothing to fold
+    const HostTensor* var = find(ctx, bn + ".running_var");
+    const HostTensor* g = find(ctx, bn + ".weight");
+    const HostTensor* be = find(ctx, bn + ".bias");
+    if (!var || !g || !be || (int)mean->data.size() != out || (int)var->data.size() != out ||
+        (int)g->data.size() != out || (int)be->data.size() != out)
+        return set_err(ctx, E2EMV_ESHAPE, "BatchNorm '%s' incomplete or wrong size", bn.c_str());
+    for (int o = 0; o < out; ++o) {
+        // same association as the unfolded op order: (x - mean) / sqrt(var + eps) * g + beta
+        double s = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+        for (int i = 0; i < in; ++i) w[(size_t)o * in + i] = (float)((double)w[(size_t)o * in + i] * s);
+        b[o] = (float)(((double)b[o] - (double)mean->data[o]) * s + (double)be->data[o]);
+    }
+    return E2EMV_OK;
+}
+
+}  // namespace
+
+extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
+    if (!ctx || !m) return E2EMV_EINVAL;
+    const int D = m->desc_dim, H = m->num_heads;
+    if (D <= 0 || H <= 0 || D % H != 0 || D / H != 64 || D % 64 != 0)
+        return set_err(ctx, E2EMV_ESHAPE, "descriptor_dim %d / num_heads %d: head dim must be 64", D, H);
+    if (m->n_kenc < 1 || m->n_kenc > E2EMV_MAX_KENC || m->n_layers < 0 || m->n_layers > E2EMV_MAX_LAYERS)
+        return set_err(ctx, E2EMV_ESHAPE, "bad layer counts");
+    (void)hipSetDevice(ctx->device);
+    const int d = D / H;
+    Packer pk;
+    int rc;
+    std::vector<float> w, b;
+    // ---- keypoint encoder ----
+    std::vector<int> dims = {3};
+    for (int i = 0; i < m->n_kenc; ++i) dims.push_back(m->kenc[i]);
+    dims.push_back(D);
+    for (size_t i = 1; i + 1 < dims.size(); ++i)
+        if (dims[i] % 32 != 0) return set_err(ctx, E2EMV_ESHAPE, "keypoint_encoder width %d not a multiple of 32", dims[i]);
+    std::vector<size_t> kw_off, kb_off;
+    const int nk = (int)dims.size() - 1;
+    for (int i = 0; i < nk; ++i) {
+        std::string p = "kenc.encoder." + std::to_string(3 * i);
+        if ((rc = get_conv(ctx, p, dims[i + 1], dims[i], w, b))) return rc;
+        if (i < nk - 1 && (rc = fold_bn(ctx, "kenc.encoder." + std::to_string(3 * i + 1), dims[i + 1], dims[i], w, b)))
+            return rc;
+        kw_off.push_back(pk.add(w));
+        kb_off.push_back(pk.add(b));
+    }
+    // ---- GNN layers ----
+    struct LOff {
+        size_t wqkv, bqkv, wm, bm, w0, b0, w1, b1;
+    };
+    std::vector<LOff> loff(m->n_layers);
+    for (int l = 0; l < m->n_layers; ++l) {
+        std::string base = "gnn.layers." + std::to_string(l);
+        std::vector<float> wqkv((size_t)3 * D * D), bqkv((size_t)3 * D);
+        for (int p = 0; p < 3; ++p) {
+            if ((rc = get_conv(ctx, base + ".attn.proj." + std::to_string(p), D, D, w, b))) return rc;
+            for (int h = 0; h < H; ++h)
+                for (int dd = 0; dd < d; ++dd) {
+                    int src = dd * H + h, dst = p * D + h * d + dd;  // upstream channel -> head-major
+                    memcpy(&wqkv[(size_t)dst * D], &w[(size_t)src * D], sizeof(float) * D);
+                    bqkv[dst] = b[src];
+                }
+        }
+        loff[l].wqkv = pk.add(wqkv);
+        loff[l].bqkv = pk.add(bqkv);
+        if ((rc = get_conv(ctx, base + ".attn.merge", D, D, w, b))) return rc;
+        std::vector<float> wm((size_t)D * D);
+        for (int o = 0; o < D; ++o)
+            for (int h = 0; h < H; ++h)
+                for (int dd = 0; dd < d; ++dd) wm[(size_t)o * D + h * d + dd] = w[(size_t)o * D + dd * H + h];
+        loff[l].wm = pk.add(wm);
+        loff[l].bm = pk.add(b);
+        if ((rc = get_conv(ctx, base + ".mlp.0", 2 * D, 2 * D, w, b))) return rc;
+        if ((rc = fold_bn(ctx, base + ".mlp.1", 2 * D, 2 * D, w, b))) return rc;
+        loff[l].w0 = pk.add(w);
+        loff[l].b0 = pk.add(b);
+        if ((rc = get_conv(ctx, base + ".mlp.3", D, 2 * D, w, b))) return rc;
+        loff[l].w1 = pk.add(w);
+        loff[l].b1 = pk.add(b);
+    }
+    if ((rc = get_conv(ctx, "final_proj", D, D, w, b))) return rc;
+    size_t wf = pk.add(w), bf = pk.add(b);
+    const HostTensor* bs = find(ctx, "bin_score");
+    if (!bs || bs->data.size() != 1) return set_err(ctx, E2EMV_ESTATE, "missing scalar 'bin_score'");
+    size_t wc0 = 0, bc0 = 0, wc1 = 0;
+    float bc1 = 0.f;
+    if (m->conf_mlp) {
+        if ((rc = get_conv(ctx, "conf_mlp.0", D, 2 * D, w, b))) return rc;
+        if ((rc = fold_bn(ctx, "conf_mlp.1", D, 2 * D, w, b))) return rc;
+        wc0 = pk.add(w);
+        bc0 = pk.add(b);
+        if ((rc = get_conv(ctx, "conf_mlp.3", 1, D, w, b))) return rc;
+        wc1 = pk.add(w);
+        bc1 = b[0];
+    }
+    // ---- upload ----
+    if (pk.host.size() > ctx->warena_floats) {
+        E2EMV_HIP(ctx, hipDeviceSynchronize());
+        if (ctx->d_warena) E2EMV_HIP(ctx, hipFree(ctx->d_warena));
+        ctx->d_warena = nullptr;
+        ctx->warena_floats = 0;
+        void* p = nullptr;
+        if (hipMalloc(&p, pk.host.size() * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            return set_err(ctx, E2EMV_ENOMEM, "weight arena allocation failed");
+        }
+        ctx->d_warena = (float*)p;
+        ctx->warena_floats = pk.host.size();
+    }
+    E2EMV_HIP(ctx, hipDeviceSynchronize());  // no forward may be in flight while weights change
+    E2EMV_HIP(ctx, hipMemcpy(ctx->d_warena, pk.host.data(), pk.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    float* base = ctx->d_warena;
+    ctx->kenc_dims = dims;
+    ctx->kenc_w0 = base + kw_off[0];
+    ctx->kenc_b0 = base + kb_off[0];
+    ctx->kenc_w.clear();
+    ctx->kenc_b.clear();
+    for (int i = 1; i < nk; ++i) {
+        ctx->kenc_w.push_back(base + kw_off[i]);
+        ctx->kenc_b.push_back(base + kb_off[i]);
+    }
+    ctx->layers.assign(m->n_layers, LayerWeights());
+    for (int l = 0; l < m->n_layers; ++l) {
+        LayerWeights& L = ctx->layers[l];
+        L.w_qkv = base + loff[l].wqkv;
+        L.b_qkv = base + loff[l].bqkv;
+        L.w_merge = base + loff[l].wm;
+        L.b_merge = base + loff[l].bm;
+        L.w_mlp0 = base + loff[l].w0;
+        L.b_mlp0 = base + loff[l].b0;
+        L.w_mlp1 = base + loff[l].w1;
+        L.b_mlp1 = base + loff[l].b1;
+        L.type = m->layer_types[l] ? 1 : 0;
+    }
+    ctx->w_final = base + wf;
+    ctx->b_final = base + bf;
+    ctx->bin_score = bs->data[0];
+    if (m->conf_mlp) {
+        ctx->w_conf0 = base + wc0;
+        ctx->b_conf0 = base + bc0;
+        ctx->w_conf1 = base + wc1;
+        ctx->b_conf1 = bc1;
+    } else {
+        ctx->w_conf0 = ctx->b_conf0 = ctx->w_conf1 = nullptr;
+    }
+    ctx->model = *m;
+    ctx->committed = true;
+    return E2EMV_OK;
+}
+
+extern "C" {
+
+int e2emv_profile(e2emv_ctx* ctx, int enable) {
+    if (!ctx) return E2EMV_EINVAL;
+    ctx->prof = enable != 0;
+    return E2EMV_OK;
+}
+
+int e2emv_profile_read(e2emv_ctx* ctx, float* ms, int64_t* launches, int n_slots, int reset) {
+    if (!ctx) return E2EMV_EINVAL;
+    E2EMV_HIP(ctx, hipDeviceSynchronize());
+    for (auto& pe : ctx->prof_events) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, pe.a, pe.b) == hipSuccess && pe.slot >= 0 && pe.slot < E2EMV_PROF_SLOTS) {
+            ctx->prof_ms[pe.slot] += t;
+            ctx->prof_n[pe.slot] += 1;
+        } else {
+            (void)hipGetLastError();
+        }
+        ctx->event_pool.push_back(pe.a);
+        ctx->event_pool.push_back(pe.b);
+    }
+    ctx->prof_events.clear();
+    for (int i = 0; i < n_slots && i < E2EMV_PROF_SLOTS; ++i) {
+        if (ms) ms[i] = ctx->prof_ms[i];
+        if (launches) launches[i] = ctx->prof_n[i];
+    }
+    if (reset)
+        for (int i = 0; i < E2EMV_PROF_SLOTS; ++i) {
+            ctx->prof_ms[i] = 0.f;
+            ctx->prof_n[i] = 0;
+        }
+    return E2EMV_OK;
+}
+
+const char* e2emv_profile_name(int slot) { return (slot >= 0 && slot < PS_COUNT) ? kProfNames[slot] : ""; }
+
+}  // extern "C"

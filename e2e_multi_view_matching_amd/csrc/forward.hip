@@ -1,0 +1,345 @@
+// e2emv_matcher_forward: the MultiViewMatcher.forward replacement (reference call sites
+// helpers.py:246, eval_pairs.py:212, eval_multi_view.py:160; algorithm = upstream SuperGlue
+// superglue.py SuperGlue.forward, see oracle/matcher.py for the restated spec).
+//
+//   ingest (descriptor transpose [B,D,N] -> [img][row][D], keypoint normalisation + first
+//   keypoint-encoder layer)  ->  kenc MLP (MFMA GEMMs, last one adds the descriptors)
+//   -> L x { q|k|v GEMM, fused attention, merge GEMM, MLP0 GEMM (+BN folded, ReLU) over the
+//   un-materialised concat [x | message], MLP1 GEMM + residual }  -> final_proj GEMM
+//   -> per pair: score GEMM (1/sqrt(D) fused) -> one-sweep Sinkhorn -> match block -> conf head.
+//
+// HBM layout: image g = b*T + t owns n_rows = round_up(N,128) rows of D contiguous channels
+// in every activation buffer, so every GEMM sees one [B*T*n_rows] x D matrix, keys/queries of
+// one image are contiguous, and a tuple's images are adjacent (cross-attention sources).
+// Rows >= N are zeroed at ingest and stay finite; attention masks them as keys.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace e2emv {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct IngestParams {
+    const float* kpts[E2EMV_MAX_TUPLE];
+    const float* ksc[E2EMV_MAX_TUPLE];
+    const void* desc[E2EMV_MAX_TUPLE];
+    float img_w[E2EMV_MAX_TUPLE], img_h[E2EMV_MAX_TUPLE];
+    int B, T, N, n_rows, D, c0, f16;
+    const float* w0;
+    const float* b0;
+    float* x0;
+    float* h0;
+};
+
+// [B][D][N] (N contiguous) -> [img][n_rows][D] (D contiguous); rows >= N := 0
+__global__ __launch_bounds__(256) void ingest_transpose(IngestParams p) {
+    __shared__ float tile[64][65];
+    const int n0 = blockIdx.x * 64, d0 = blockIdx.y * 64, img = blockIdx.z;
+    const int b = img / p.T, t = img % p.T;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = n0 + tx;
+    for (int dd = ty; dd < 64; dd += 4) {
+        float v = 0.f;
+        if (n < p.N) {
+            const int64_t o = ((int64_t)b * p.D + d0 + dd) * p.N + n;
+            v = p.f16 ? __half2float(reinterpret_cast<const __half*>(p.desc[t])[o])
+                      : reinterpret_cast<const float*>(p.desc[t])[o];
+        }
+        tile[dd][tx] = v;
+    }
+    __syncthreads();
+    for (int nn = ty; nn < 64; nn += 4)
+        p.x0[((int64_t)img * p.n_rows + n0 + nn) * p.D + d0 + tx] = tile[tx][nn];
+}
+
+// keypoint normalisation + kenc layer 0 (3 -> c0, BN folded, ReLU); rows >= N := 0
+__global__ __launch_bounds__(256) void ingest_kenc0(IngestParams p) {
+    const int row = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
+    if (row >= p.n_rows) return;
+    const int b = img / p.T, t = img % p.T;
+    float* out = p.h0 + ((int64_t)img * p.n_rows + row) * p.c0;
+    if (row >= p.N) {
+        for (int c = 0; c < p.c0; c += 4) *reinterpret_cast<f32x4*>(out + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const float W = p.img_w[t], H = p.img_h[t];
+    const float sc = fmaxf(W, H) * 0.7f;
+    const float kx = (p.kpts[t][((int64_t)b * p.N + row) * 2] - W / 2) / sc;
+    const float ky = (p.kpts[t][((int64_t)b * p.N + row) * 2 + 1] - H / 2) / sc;
+    const float ks = p.ksc[t][(int64_t)b * p.N + row];
+    for (int c = 0; c < p.c0; c += 4) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* w = p.w0 + (c + e) * 3;
+            o[e] = fmaxf(w[0] * kx + w[1] * ky + w[2] * ks + p.b0[c + e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(out + c) = o;
+    }
+}
+
+// conf head, step 1: feat2[b][n][:] = mdesc_j[b][max(match,0)][:]
+__global__ __launch_bounds__(256) void conf_gather_kernel(int N, int n_rows, int D, const float* mdesc_j, int64_t tuple_stride,
+                                                          const int64_t* matches, float* out) {
+    const int b = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    int64_t j = row < N ? matches[(int64_t)b * N + row] : 0;
+    if (j < 0) j = 0;
+    const float* src = mdesc_j + b * tuple_stride + j * D;
+    float* dst = out + ((int64_t)b * n_rows + row) * D;
+    for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(src + c);
+}
+
+// conf head, last step: sigmoid(<hidden, w> + b) for matched keypoints, 0 otherwise;
+// without conf_mlp the confidence is the match score (reference quirk E13)
+__global__ __launch_bounds__(256) void conf_final_kernel(int N, int n_rows, int D, const float* hidden, const float* w, float bias,
+                                                         const int64_t* matches, const float* mscores, int use_mlp, float* conf) {
+    const int b = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const bool valid = matches[(int64_t)b * N + row] >= 0;
+    float r = 0.f;
+    if (use_mlp) {
+        const float* h = hidden + ((int64_t)b * n_rows + row) * D;
+        float acc = 0.f;
+        for (int c = lane * 4; c < D; c += 256) {
+            f32x4 hv = *reinterpret_cast<const f32x4*>(h + c), wv = *reinterpret_cast<const f32x4*>(w + c);
+            acc += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        r = 1.f / (1.f + __expf(-(acc + bias)));
+    } else {
+        r = mscores[(int64_t)b * N + row];
+    }
+    if (lane == 0) conf[(int64_t)b * N + row] = valid ? r : 0.f;
+}
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace e2emv
+
+using namespace e2emv;
+
+static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const float* const* d_kpts,
+                         const float* const* d_kscores, const void* const* d_desc, float* const* d_logZ,
+                         int64_t* const* d_m0, int64_t* const* d_m1, float* const* d_ms0, float* const* d_ms1,
+                         float* const* d_conf, hipStream_t s) {
+    const int B = fd->batch, T = fd->tuple_size, N = fd->n_kpts;
+    const int D = ctx->model.desc_dim, H = ctx->model.num_heads;
+    const int n_rows = round_up(N, 128);
+    const int n_img = B * T;
+    const int64_t Mtot = (int64_t)n_img * n_rows;
+    const int P = T * (T - 1) / 2;
+    const int ldS = round_up(N, 4);
+    const bool full = (fd->flags & E2EMV_FLAG_FULL_OUTPUT) != 0;
+
+    // ---- workspace ----
+    auto al = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
+    const size_t sz_x = al((size_t)Mtot * D * 4), sz_qkv = al((size_t)Mtot * 3 * D * 4), sz_hid = al((size_t)Mtot * 2 * D * 4);
+    const size_t sz_S = al((size_t)B * N * ldS * 4);
+    const size_t sz_sk = sinkhorn_ws_bytes(B, N, N);
+    const size_t sz_match = full ? 2 * al((size_t)B * N * 8) + 2 * al((size_t)B * N * 4) : 0;
+    const size_t need = sz_x * 3 + sz_qkv + sz_hid + sz_S + sz_sk + sz_match + 4096;
+    int rc = ws_reserve(ctx, need);
+    if (rc) return rc;
+    char* w = ctx->d_ws;
+    float* x = (float*)w; w += sz_x;
+    float* att = (float*)w; w += sz_x;     // attention output, later mdesc
+    float* msg = (float*)w; w += sz_x;     // merge output, later conf gather / hidden
+    float* qkv = (float*)w; w += sz_qkv;
+    float* hid = (float*)w; w += sz_hid;
+    float* S = (float*)w; w += sz_S;
+    char* skws = w; w += sz_sk;
+    int64_t* tmp_m0 = nullptr; int64_t* tmp_m1 = nullptr; float* tmp_ms0 = nullptr; float* tmp_ms1 = nullptr;
+    if (full) {
+        tmp_m0 = (int64_t*)w; w += al((size_t)B * N * 8);
+        tmp_m1 = (int64_t*)w; w += al((size_t)B * N * 8);
+        tmp_ms0 = (float*)w; w += al((size_t)B * N * 4);
+        tmp_ms1 = (float*)w; w += al((size_t)B * N * 4);
+    }
+
+    // ---- ingest ----
+    const std::vector<int>& kd = ctx->kenc_dims;  // [3, c0, ..., D]
+    const int c0 = kd[1];
+    {
+        int64_t tot = 0;
+        for (size_t i = 1; i + 1 < kd.size(); ++i) tot += kd[i];
+        if (tot > 2 * D) return set_err(ctx, E2EMV_ESHAPE, "keypoint_encoder too wide for the workspace plan");
+    }
+    IngestParams ip{};
+    for (int t = 0; t < T; ++t) {
+        ip.kpts[t] = d_kpts[t]; ip.ksc[t] = d_kscores[t]; ip.desc[t] = d_desc[t];
+        ip.img_w[t] = fd->img_w[t]; ip.img_h[t] = fd->img_h[t];
+    }
+    ip.B = B; ip.T = T; ip.N = N; ip.n_rows = n_rows; ip.D = D; ip.c0 = c0; ip.f16 = fd->desc_dtype == E2EMV_DESC_F16;
+    ip.w0 = ctx->kenc_w0; ip.b0 = ctx->kenc_b0; ip.x0 = x; ip.h0 = hid;
+    prof_begin(ctx, PS_INGEST, s);
+    hipLaunchKernelGGL(ingest_transpose, dim3(n_rows / 64, D / 64, n_img), dim3(256), 0, s, ip);
+    hipLaunchKernelGGL(ingest_kenc0, dim3((n_rows + 255) / 256, n_img), dim3(256), 0, s, ip);
+    prof_end(ctx, s);
+    E2EMV_CHECK_LAUNCH(ctx, "ingest kernels");
+
+    // ---- keypoint encoder layers 1..n through the GEMM; the last adds the descriptors ----
+    {
+        float* cur = hid;  // [Mtot][c0]
+        float* nxt = hid + Mtot * c0;
+        const int nl = (int)ctx->kenc_w.size();
+        for (int i = 0; i < nl; ++i) {
+            const int cin = kd[i + 1], cout = kd[i + 2];
+            const bool last = i == nl - 1;
+            GemmArgs g;
+            g.M = (int)Mtot; g.N = cout; g.K = cin; g.K1 = cin;
+            g.A = cur; g.lda = cin;
+            g.W = ctx->kenc_w[i]; g.ldw = cin; g.bias = ctx->kenc_b[i];
+            g.relu = !last;
+            if (last) { g.R = x; g.ldr = D; g.C = x; g.ldc = D; }
+            else { g.C = nxt; g.ldc = cout; }
+            prof_begin(ctx, PS_GEMM, s);
+            rc = launch_gemm_nt(ctx, g, s);
+            prof_end(ctx, s);
+            if (rc) return rc;
+            cur = nxt;
+            nxt = nxt + Mtot * cout;
+        }
+    }
+
+    // ---- attentional GNN ----
+    for (size_t l = 0; l < ctx->layers.size(); ++l) {
+        const LayerWeights& L = ctx->layers[l];
+        GemmArgs g;
+        // q|k|v = x Wqkv^T + b
+        g = GemmArgs();
+        g.M = (int)Mtot; g.N = 3 * D; g.K = D; g.K1 = D; g.A = x; g.lda = D; g.W = L.w_qkv; g.ldw = D; g.bias = L.b_qkv;
+        g.C = qkv; g.ldc = 3 * D;
+        prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
+        if (rc) return rc;
+        prof_begin(ctx, PS_ATTN, s);
+        rc = launch_attention(ctx, B, T, n_rows, N, D, H, qkv, L.type, att, s);
+        prof_end(ctx, s);
+        if (rc) return rc;
+        // message = merge(attention)
+        g = GemmArgs();
+        g.M = (int)Mtot; g.N = D; g.K = D; g.K1 = D; g.A = att; g.lda = D; g.W = L.w_merge; g.ldw = D; g.bias = L.b_merge;
+        g.C = msg; g.ldc = D;
+        prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
+        if (rc) return rc;
+        // hidden = relu(BN(W0 [x | message] + b0))   (concat never materialised: two K segments)
+        g = GemmArgs();
+        g.M = (int)Mtot; g.N = 2 * D; g.K = 2 * D; g.K1 = D; g.A = x; g.lda = D; g.A2 = msg; g.lda2 = D;
+        g.W = L.w_mlp0; g.ldw = 2 * D; g.bias = L.b_mlp0; g.relu = true; g.C = hid; g.ldc = 2 * D;
+        prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
+        if (rc) return rc;
+        // x += W1 hidden + b1
+        g = GemmArgs();
+        g.M = (int)Mtot; g.N = D; g.K = 2 * D; g.K1 = 2 * D; g.A = hid; g.lda = 2 * D; g.W = L.w_mlp1; g.ldw = 2 * D;
+        g.bias = L.b_mlp1; g.R = x; g.ldr = D; g.C = x; g.ldc = D;
+        prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
+        if (rc) return rc;
+    }
+
+    // ---- final projection ----
+    float* mdesc = att;
+    {
+        GemmArgs g;
+        g.M = (int)Mtot; g.N = D; g.K = D; g.K1 = D; g.A = x; g.lda = D; g.W = ctx->w_final; g.ldw = D; g.bias = ctx->b_final;
+        g.C = mdesc; g.ldc = D;
+        prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
+        if (rc) return rc;
+    }
+
+    // ---- per pair: scores -> Sinkhorn -> matches -> confidence ----
+    const int64_t tuple_stride = (int64_t)T * n_rows * D;
+    int pidx = 0;
+    for (int j = 0; j < T; ++j)
+        for (int i = 0; i < j; ++i, ++pidx) {
+            GemmArgs g;
+            g.batch = B; g.M = N; g.N = N; g.K = D; g.K1 = D;
+            g.A = mdesc + (int64_t)i * n_rows * D; g.lda = D; g.sA = tuple_stride;
+            g.W = mdesc + (int64_t)j * n_rows * D; g.ldw = D; g.sW = tuple_stride;
+            g.C = S; g.ldc = ldS; g.sC = (int64_t)N * ldS;
+            g.scale = 1.0f / sqrtf((float)D);
+            prof_begin(ctx, PS_SCORE, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
+            if (rc) return rc;
+            const bool want_conf = full && d_conf && d_conf[pidx];
+            SinkhornOut so;
+            so.logZ = d_logZ ? d_logZ[pidx] : nullptr;
+            if (full) {
+                so.m0 = (d_m0 && d_m0[pidx]) ? d_m0[pidx] : (want_conf ? tmp_m0 : nullptr);
+                so.m1 = d_m1 ? d_m1[pidx] : nullptr;
+                so.ms0 = (d_ms0 && d_ms0[pidx]) ? d_ms0[pidx] : (want_conf ? tmp_ms0 : nullptr);
+                so.ms1 = d_ms1 ? d_ms1[pidx] : nullptr;
+            }
+            prof_begin(ctx, PS_SINKHORN, s);
+            rc = launch_sinkhorn(ctx, B, N, N, S, ldS, ctx->bin_score, fd->sinkhorn_iters, fd->match_threshold, so, skws, s);
+            prof_end(ctx, s);
+            if (rc) return rc;
+            if (want_conf) {
+                const bool use_mlp = ctx->model.conf_mlp != 0;
+                float* gathered = msg;          // [B][n_rows][D]
+                float* chid = hid;              // [B][n_rows][D]
+                if (use_mlp) {
+                    prof_begin(ctx, PS_CONF, s);
+                    hipLaunchKernelGGL(conf_gather_kernel, dim3((n_rows + 3) / 4, B), dim3(256), 0, s, N, n_rows, D,
+                                       mdesc + (int64_t)j * n_rows * D, tuple_stride, so.m0, gathered);
+                    prof_end(ctx, s);
+                    GemmArgs c;
+                    c.batch = B; c.M = n_rows; c.N = D; c.K = 2 * D; c.K1 = D;
+                    c.A = mdesc + (int64_t)i * n_rows * D; c.lda = D; c.sA = tuple_stride;
+                    c.A2 = gathered; c.lda2 = D; c.sA2 = (int64_t)n_rows * D;
+                    c.W = ctx->w_conf0; c.ldw = 2 * D; c.bias = ctx->b_conf0; c.relu = true;
+                    c.C = chid; c.ldc = D; c.sC = (int64_t)n_rows * D;
+                    prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, c, s); prof_end(ctx, s);
+                    if (rc) return rc;
+                }
+                prof_begin(ctx, PS_CONF, s);
+                hipLaunchKernelGGL(conf_final_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, N, n_rows, D, chid, ctx->w_conf1,
+                                   ctx->b_conf1, so.m0, so.ms0, use_mlp ? 1 : 0, d_conf[pidx]);
+                prof_end(ctx, s);
+                E2EMV_CHECK_LAUNCH(ctx, "conf kernels");
+            }
+        }
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_matcher_forward(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const float* const* d_kpts,
+                                     const float* const* d_kscores, const void* const* d_desc, float* const* d_logZ,
+                                     int64_t* const* d_matches0, int64_t* const* d_matches1, float* const* d_mscores0,
+                                     float* const* d_mscores1, float* const* d_conf, void* stream) {
+    if (!ctx || !fd || !d_kpts || !d_kscores || !d_desc) return E2EMV_EINVAL;
+    if (!ctx->committed) return set_err(ctx, E2EMV_ESTATE, "matcher_forward: weights not committed");
+    const int B = fd->batch, T = fd->tuple_size, N = fd->n_kpts;
+    if (B <= 0 || T < 2 || T > E2EMV_MAX_TUPLE) return set_err(ctx, E2EMV_ESHAPE, "matcher_forward: batch=%d tuple_size=%d", B, T);
+    if (N <= 0 || N > 2048) return set_err(ctx, E2EMV_ESHAPE, "matcher_forward: n_kpts=%d not in [1, 2048]", N);
+    if (fd->desc_dtype != E2EMV_DESC_F32 && fd->desc_dtype != E2EMV_DESC_F16) return set_err(ctx, E2EMV_EINVAL, "bad desc_dtype");
+    if (fd->sinkhorn_iters < 0) return set_err(ctx, E2EMV_EINVAL, "negative sinkhorn_iters");
+    for (int t = 0; t < T; ++t)
+        if (!d_kpts[t] || !d_kscores[t] || !d_desc[t]) return set_err(ctx, E2EMV_EINVAL, "matcher_forward: null input for image %d", t);
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (T == 2 || (fd->flags & E2EMV_FLAG_MULTI_FRAME))
+        return forward_joint(ctx, fd, d_kpts, d_kscores, d_desc, d_logZ, d_matches0, d_matches1, d_mscores0, d_mscores1, d_conf, s);
+    // pairwise mode on a tuple: every pair goes through the 2-view network on its own
+    int pidx = 0;
+    for (int j = 0; j < T; ++j)
+        for (int i = 0; i < j; ++i, ++pidx) {
+            e2emv_forward_desc f2 = *fd;
+            f2.tuple_size = 2;
+            f2.img_w[0] = fd->img_w[i]; f2.img_h[0] = fd->img_h[i];
+            f2.img_w[1] = fd->img_w[j]; f2.img_h[1] = fd->img_h[j];
+            const float* kp[2] = {d_kpts[i], d_kpts[j]};
+            const float* ks[2] = {d_kscores[i], d_kscores[j]};
+            const void* de[2] = {d_desc[i], d_desc[j]};
+            float* lz[1] = {d_logZ ? d_logZ[pidx] : nullptr};
+            int64_t* m0[1] = {d_matches0 ? d_matches0[pidx] : nullptr};
+            int64_t* m1[1] = {d_matches1 ? d_matches1[pidx] : nullptr};
+            float* s0[1] = {d_mscores0 ? d_mscores0[pidx] : nullptr};
+            float* s1[1] = {d_mscores1 ? d_mscores1[pidx] : nullptr};
+            float* cf[1] = {d_conf ? d_conf[pidx] : nullptr};
+            int rc = forward_joint(ctx, &f2, kp, ks, de, lz, m0, m1, s0, s1, cf, s);
+            if (rc) return rc;
+        }
+    return E2EMV_OK;
+}

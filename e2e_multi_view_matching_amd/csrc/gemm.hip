@@ -1,0 +1,213 @@
+// fp32 "NT" GEMM on the gfx950 matrix cores:  C[m][n] = act(scale * sum_k A[m][k] W[n][k] + bias[n]) (+ R[m][n])
+//
+// Every dense descriptor contraction of the matcher that is not attention goes through
+// this kernel: the 1x1-Conv projections (q|k|v, merge), the propagation MLP, the keypoint
+// encoder, final_proj, the conf head and the per-pair score matrix mdesc_i^T mdesc_j / sqrt(D)
+// (upstream SuperGlue superglue.py: MLP / MultiHeadedAttention.proj / final_proj / einsum
+// 'bdn,bdm->bnm'; the reference's matcher source is an absent submodule).
+// Both operands are K-contiguous (activations [rows][channels], Conv1d weights [out][in]).
+//
+// Design (MI355X / CDNA4):
+//  * v_mfma_f32_32x32x2_f32 - exact fp32 (bitwise an fmaf chain), 157 TFLOP/s peak; parity
+//    with the fp32 reference forbids bf16/fp16 here and gfx950 has no tf32/xf32.
+//  * 128x128x32 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles (64 acc VGPRs).
+//  * LDS rows padded to 36 floats: the ds_read_b128 operand fetch (lane = row, 16 B of K) is
+//    bank-conflict free (16 rows x 16 B cover the 64 banks: 36*i mod 64 distinct for 16 i).
+//  * K-slot permutation: one ds_read_b128 feeds FOUR MFMAs - lanes 0-31 hold k = 8c+e,
+//    lanes 32-63 hold k = 8c+4+e for MFMA e; A and B use the same map, the sum over k is
+//    unchanged.  4 x b128 reads per 16 MFMAs -> LDS is idle, the kernel is MFMA-issue bound.
+//  * register-staged double buffering (global_load_dwordx4 -> ds_write_b128), one barrier
+//    per K tile; 73.7 KB LDS -> 2 blocks/CU = 2 waves/SIMD to cover the barrier.
+//  * XCD-aware tile order: the N-tiles that share an A panel run on the same XCD (same L2).
+#include "common.h"
+
+namespace e2emv {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int BM = 128, BN = 128, BK = 32, LDK = 36;
+
+struct GemmParams {
+    const float* A;
+    const float* A2;
+    const float* W;
+    const float* bias;
+    const float* R;
+    float* C;
+    int64_t lda, lda2, ldw, ldr, ldc;
+    int64_t sA, sA2, sW, sR, sC;
+    int M, N, K, K1;
+    int tiles_m, tiles_n;
+    float scale;
+    int relu;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                   // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;    // [2][BN][LDK]
+
+    // XCD-aware bijective remap of the linear block id -> tile id
+    const int total = p.tiles_m * p.tiles_n;
+    const int per_xcd = (total + 7) / 8;
+    const int lin = blockIdx.x;
+    const int tile = (lin % 8) * per_xcd + lin / 8;
+    if (tile >= total) return;
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int z = blockIdx.z;
+    const float* A = p.A + z * p.sA;
+    const float* A2 = p.A2 ? p.A2 + z * p.sA2 : nullptr;
+    const float* W = p.W + z * p.sW;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // global->LDS staging map: 4 float4 per thread per operand
+    const int ld_row = tid >> 3;        // 0..31 (+32*i)
+    const int ld_c4 = (tid & 7) * 4;    // float offset inside the K tile
+    const float* a_ptr[4];
+    const float* a2_ptr[4];
+    const float* w_ptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ra = min(m0 + ld_row + 32 * i, p.M - 1);
+        int rw = min(n0 + ld_row + 32 * i, p.N - 1);
+        a_ptr[i] = A + (int64_t)ra * p.lda + ld_c4;
+        a2_ptr[i] = A2 ? A2 + (int64_t)ra * p.lda2 + ld_c4 : nullptr;
+        w_ptr[i] = W + (int64_t)rw * p.ldw + ld_c4;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+        const int k = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* src = (k < p.K1) ? a_ptr[i] + k : a2_ptr[i] + (k - p.K1);
+            ra[i] = *reinterpret_cast<const f32x4*>(src);
+            rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + k);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + ld_row + 32 * i) * LDK + ld_c4]) = ra[i];
+            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + ld_row + 32 * i) * LDK + ld_c4]) = rb[i];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* as = &As[(cur * BM + wr * 64 + l31) * LDK + lh * 4];
+        const float* bs = &Bs[(cur * BN + wc * 64 + l31) * LDK + lh * 4];
+#pragma unroll
+        for (int c = 0; c < BK / 8; ++c) {
+            f32x4 a0 = *reinterpret_cast<const f32x4*>(as + c * 8);
+            f32x4 a1 = *reinterpret_cast<const f32x4*>(as + 32 * LDK + c * 8);
+            f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + c * 8);
+            f32x4 b1 = *reinterpret_cast<const f32x4*>(bs + 32 * LDK + c * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* C = p.C + z * p.sC;
+    const float* R = p.R ? p.R + z * p.sR : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wc * 64 + j * 32 + l31;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M) {
+                    float v = acc[i][j][r] * p.scale + bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (R) v += R[(int64_t)m * p.ldr + n];
+                    C[(int64_t)m * p.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.batch <= 0) return set_err(ctx, E2EMV_ESHAPE, "gemm: empty problem");
+    const int K1 = a.A2 ? a.K1 : a.K;
+    if (a.K % BK || K1 % BK || K1 > a.K || (K1 < a.K && !a.A2))
+        return set_err(ctx, E2EMV_ESHAPE, "gemm: K=%d K1=%d must be multiples of %d", a.K, K1, BK);
+    if ((a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4)) || ((uintptr_t)a.A % 16) || ((uintptr_t)a.W % 16) ||
+        (a.A2 && ((uintptr_t)a.A2 % 16)) || (a.sA % 4) || (a.sW % 4) || (a.sA2 % 4))
+        return set_err(ctx, E2EMV_ESHAPE, "gemm: operands must be 16-byte aligned with leading dims %% 4 == 0");
+    GemmParams p;
+    p.A = a.A; p.A2 = a.A2; p.W = a.W; p.bias = a.bias; p.R = a.R; p.C = a.C;
+    p.lda = a.lda; p.lda2 = a.lda2; p.ldw = a.ldw; p.ldr = a.ldr; p.ldc = a.ldc;
+    p.sA = a.sA; p.sA2 = a.sA2; p.sW = a.sW; p.sR = a.sR; p.sC = a.sC;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.K1 = K1;
+    p.tiles_m = (a.M + BM - 1) / BM;
+    p.tiles_n = (a.N + BN - 1) / BN;
+    p.scale = a.scale;
+    p.relu = a.relu ? 1 : 0;
+    const int total = p.tiles_m * p.tiles_n;
+    const int per_xcd = (total + 7) / 8;
+    const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        E2EMV_HIP(ctx, hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(per_xcd * 8, 1, a.batch);
+    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), lds, s, p);
+    E2EMV_CHECK_LAUNCH(ctx, "gemm_nt_kernel");
+    return E2EMV_OK;
+}
+
+}  // namespace e2emv
+
+extern "C" int e2emv_gemm_nt(e2emv_ctx* ctx, int batch, int M, int Nout, int K, int K1, const float* d_A, int64_t lda,
+                             int64_t strideA, const float* d_A2, int64_t lda2, int64_t strideA2, const float* d_W,
+                             int64_t ldw, int64_t strideW, const float* d_bias, const float* d_R, int64_t ldr,
+                             int64_t strideR, float* d_C, int64_t ldc, int64_t strideC, float scale, int flags,
+                             void* stream) {
+    if (!ctx || !d_A || !d_W || !d_C) return E2EMV_EINVAL;
+    e2emv::GemmArgs a;
+    a.batch = batch; a.M = M; a.N = Nout; a.K = K; a.K1 = K1;
+    a.A = d_A; a.lda = lda; a.sA = strideA;
+    a.A2 = d_A2; a.lda2 = lda2; a.sA2 = strideA2;
+    a.W = d_W; a.ldw = ldw; a.sW = strideW;
+    a.bias = d_bias; a.R = d_R; a.ldr = ldr; a.sR = strideR;
+    a.C = d_C; a.ldc = ldc; a.sC = strideC;
+    a.scale = scale; a.relu = (flags & 1) != 0;
+    e2emv::prof_begin(ctx, e2emv::PS_GEMM, (hipStream_t)stream);
+    int rc = e2emv::launch_gemm_nt(ctx, a, (hipStream_t)stream);
+    e2emv::prof_end(ctx, (hipStream_t)stream);
+    return rc;
+}

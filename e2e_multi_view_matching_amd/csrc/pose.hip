@@ -1,0 +1,580 @@
+// Confidence-weighted eight-point relative pose on the GPU (two views), batched over pairs.
+//
+// Restates pose_optimization/two_view/estimate_relative_pose.py:
+//   normalize :9-14, get_kpts :16-31, find_fundamental :34-82, estimate_relative_pose_w8pt
+//   :84-128, and compute_pose_error.py:3-22; the kornia 0.7.0 calls the reference makes there
+//   (normalize_points, normalize_transformation, motion_from_essential[_choose_solution],
+//   triangulate_points, depth_from_point, symmetrical_epipolar_distance) are folded in.
+//
+// What the reference does with cuSOLVER/LAPACK SVDs is done here without any SVD library:
+//   * the N x 9 weighted design matrix is never materialised (the reference even builds an
+//     N x N diag, :68-69): its 9 x 9 Gram matrix is accumulated in fp64 with wavefront
+//     shuffles; the null vector = eigenvector of the smallest eigenvalue (cyclic Jacobi, fp64).
+//     fp64 Gram + Jacobi is MORE accurate than the reference's fp32 N x 9 SVD.
+//   * rank-2 projection: F - (F v3) v3^T with v3 from the 3 x 3 Jacobi of F^T F.
+//   * essential decomposition: V from Jacobi of E^T E, u_k = E v_k / |E v_k|; the reference's
+//     det-sign fixes make U = [u1 u2 u1xu2], V = [v1 v2 v1xv2], so no sign bookkeeping.
+//   * 5N four-by-four DLT triangulations per pair (86 % of the reference's time, all in
+//     batched 4 x 4 SVDs): one thread per point, 4 x 4 Jacobi of A^T A in registers (fp64).
+// Candidate ORDER is SVD-sign dependent in the reference too; only the chosen pose is
+// compared.  Cheirality winner = per-sample arg-max of the positive-depth counts (first
+// maximum), see oracle/kornia_fns.py for the B > 1 caveat of kornia 0.7.0.
+#include "common.h"
+
+namespace e2emv {
+
+// ---------------------------------------------------------------- small fp64 linear algebra
+template <int N>
+__device__ __forceinline__ void jacobi_static(double (&A)[N][N], double (&V)[N][N]) {
+    // cyclic Jacobi, everything statically indexed -> registers.  A symmetric (full storage).
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, dg = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            dg += A[i][i] * A[i][i];
+#pragma unroll
+            for (int j = i + 1; j < N; ++j) off += A[i][j] * A[i][j];
+        }
+        if (off <= 1e-60 || off <= 1e-34 * dg) break;
+#pragma unroll
+        for (int p = 0; p < N - 1; ++p)
+#pragma unroll
+            for (int q = p + 1; q < N; ++q) {
+                const double apq = A[p][q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                A[p][p] -= t * apq;
+                A[q][q] += t * apq;
+                A[p][q] = 0.0;
+                A[q][p] = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    if (k != p && k != q) {
+                        const double akp = A[k][p], akq = A[k][q];
+                        A[k][p] = A[p][k] = c * akp - s * akq;
+                        A[k][q] = A[q][k] = s * akp + c * akq;
+                    }
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+// dynamic-index variant for the 9 x 9 problem, operating on LDS arrays from ONE thread
+__device__ void jacobi_dynamic(double* A, double* V, int n) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = 0; i < n; ++i) {
+            dg += A[i * n + i] * A[i * n + i];
+            for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+        }
+        if (off <= 1e-60 || off <= 1e-34 * dg) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                A[p * n + p] -= t * apq;
+                A[q * n + q] += t * apq;
+                A[p * n + q] = 0.0;
+                A[q * n + p] = 0.0;
+                for (int k = 0; k < n; ++k) {
+                    if (k != p && k != q) {
+                        const double akp = A[k * n + p], akq = A[k * n + q];
+                        const double np_ = c * akp - s * akq, nq_ = s * akp + c * akq;
+                        A[k * n + p] = np_;
+                        A[p * n + k] = np_;
+                        A[k * n + q] = nq_;
+                        A[q * n + k] = nq_;
+                    }
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+struct W8Params {
+    int B, N, kdim, intr_batch;
+    const float* k0;
+    const float* k1;
+    const float* K0;
+    const float* K1;
+    const float* conf;
+    int choose_closest;
+    const float* Tgt;
+    int determine_inliers;
+    float* T;
+    float* k0n;
+    float* k1n;
+    float* conf_n;
+    uint8_t* inliers;
+    uint8_t* posdepth;
+    float* F;
+    int32_t* status;
+    // workspace
+    double* E;       // [B][9]
+    double* cands;   // [B][4][12]  R row-major, t
+    int* sel;        // [B] chosen candidate for choose_closest, else -1
+    int* counts;     // [B][4]
+    uint8_t* pd_c;   // [B][4][N]
+};
+
+__device__ __forceinline__ void mat3_mul(const double* a, const double* b, double* c) {  // c = a b
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+}
+
+__device__ __forceinline__ double angle_err(const double* R, const double* t, const float* Tg) {
+    // compute_rotation_error + compute_translation_error_as_angle(reduce=False)
+    double tr = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) tr += R[i * 3 + j] * (double)Tg[i * 4 + j];  // trace(R^T Rg)
+    double ca = fmin(fmax((tr - 1.0) * 0.5, -1.0), 1.0);
+    double er = fabs(acos(ca));
+    double n0 = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+    double g0 = (double)Tg[3], g1 = (double)Tg[7], g2 = (double)Tg[11];
+    double n1 = sqrt(g0 * g0 + g1 * g1 + g2 * g2);
+    double et = 0.0;
+    if (n0 * n1 > 1e-6) {
+        double cd = (t[0] * g0 + t[1] * g1 + t[2] * g2) / (n0 * n1);
+        et = fabs(acos(fmin(fmax(cd, -1.0), 1.0)));
+    }
+    return er + et;
+}
+
+// Kernel 1: one workgroup per pair -> normalised points, weights, essential matrix, candidates.
+__global__ __launch_bounds__(256) void w8pt_fundamental(W8Params p) {
+    __shared__ double sG[81];
+    __shared__ double sV[81];
+    __shared__ double sred[4 * 48];
+    __shared__ double sstat[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = p.N;
+    const float* K0 = p.K0 + (p.intr_batch == 1 ? 0 : (int64_t)b * p.kdim * p.kdim);
+    const float* K1 = p.K1 + (p.intr_batch == 1 ? 0 : (int64_t)b * p.kdim * p.kdim);
+    const float fx0 = K0[0], fy0 = K0[p.kdim + 1], cx0 = K0[2], cy0 = K0[p.kdim + 2];
+    const float fx1 = K1[0], fy1 = K1[p.kdim + 1], cx1 = K1[2], cy1 = K1[p.kdim + 2];
+    const float* k0 = p.k0 + (int64_t)b * N * 2;
+    const float* k1 = p.k1 + (int64_t)b * N * 2;
+    const float* cf = p.conf + (int64_t)b * N;
+    float* k0n = p.k0n + (int64_t)b * N * 2;
+    float* k1n = p.k1n + (int64_t)b * N * 2;
+
+    // pass 1: intrinsics normalisation (fp32 like the reference), sums for Hartley + weights
+    double acc[5] = {0, 0, 0, 0, 0};  // sum x0,y0,x1,y1,conf
+    for (int i = tid; i < N; i += 256) {
+        const float x0 = (k0[2 * i] - cx0) / fx0, y0 = (k0[2 * i + 1] - cy0) / fy0;
+        const float x1 = (k1[2 * i] - cx1) / fx1, y1 = (k1[2 * i + 1] - cy1) / fy1;
+        k0n[2 * i] = x0; k0n[2 * i + 1] = y0;
+        k1n[2 * i] = x1; k1n[2 * i + 1] = y1;
+        acc[0] += x0; acc[1] += y0; acc[2] += x1; acc[3] += y1; acc[4] += cf[i];
+    }
+    for (int j = 0; j < 5; ++j) {
+        double v = wave_sum_d(acc[j]);
+        if (lane == 0) sred[wave * 48 + j] = v;
+    }
+    __syncthreads();
+    if (tid < 5) sstat[tid] = sred[tid] + sred[48 + tid] + sred[96 + tid] + sred[144 + tid];
+    __syncthreads();
+    const double mx0 = sstat[0] / N, my0 = sstat[1] / N, mx1 = sstat[2] / N, my1 = sstat[3] / N;
+    const float wsum = (float)sstat[4] + 1e-6f;  // confidence / (sum + 1e-6)   (:87-88)
+    // pass 2: mean distance to the centroid (Hartley scale, UNWEIGHTED over all N rows - E2)
+    double d0 = 0, d1 = 0;
+    for (int i = tid; i < N; i += 256) {
+        const double ax = (double)k0n[2 * i] - mx0, ay = (double)k0n[2 * i + 1] - my0;
+        const double bx = (double)k1n[2 * i] - mx1, by = (double)k1n[2 * i + 1] - my1;
+        d0 += sqrt(ax * ax + ay * ay);
+        d1 += sqrt(bx * bx + by * by);
+    }
+    d0 = wave_sum_d(d0);
+    d1 = wave_sum_d(d1);
+    __syncthreads();
+    if (lane == 0) { sred[wave * 48] = d0; sred[wave * 48 + 1] = d1; }
+    __syncthreads();
+    if (tid < 2) sstat[8 + tid] = sred[tid] + sred[48 + tid] + sred[96 + tid] + sred[144 + tid];
+    __syncthreads();
+    const double s0 = sqrt(2.0) / (sstat[8] / N + 1e-8), s1 = sqrt(2.0) / (sstat[9] / N + 1e-8);
+
+    // pass 3: weighted Gram matrix of the design rows (45 unique entries, fp64)
+    double g[45];
+#pragma unroll
+    for (int j = 0; j < 45; ++j) g[j] = 0.0;
+    for (int i = tid; i < N; i += 256) {
+        const float wn = cf[i] / wsum;
+        p.conf_n[(int64_t)b * N + i] = wn;
+        const double w = wn;
+        const double x1 = s0 * ((double)k0n[2 * i] - mx0), y1 = s0 * ((double)k0n[2 * i + 1] - my0);
+        const double x2 = s1 * ((double)k1n[2 * i] - mx1), y2 = s1 * ((double)k1n[2 * i + 1] - my1);
+        // row order (:65): [x2x1, x2y1, x2, y2x1, y2y1, y2, x1, y1, 1], weights multiply ROWS (E1)
+        const double r[9] = {w * x2 * x1, w * x2 * y1, w * x2, w * y2 * x1, w * y2 * y1, w * y2, w * x1, w * y1, w};
+        int j = 0;
+#pragma unroll
+        for (int a = 0; a < 9; ++a)
+#pragma unroll
+            for (int c = a; c < 9; ++c) g[j++] += r[a] * r[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 45; ++j) {
+        double v = wave_sum_d(g[j]);
+        if (lane == 0) sred[wave * 48 + j] = v;
+    }
+    __syncthreads();
+    if (tid < 45) {
+        const double v = sred[tid] + sred[48 + tid] + sred[96 + tid] + sred[144 + tid];
+        int j = 0, a = 0, c = 0;
+        for (a = 0; a < 9; ++a) {
+            if (tid < j + 9 - a) { c = a + (tid - j); break; }
+            j += 9 - a;
+        }
+        sG[a * 9 + c] = v;
+        sG[c * 9 + a] = v;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+
+    // ---- single-thread tail: tiny dense algebra in fp64 ----
+    jacobi_dynamic(sG, sV, 9);
+    // The reference takes V[..., -1] of torch.svd(X) with X [N,9] (:72-73).  For N >= 9 that is
+    // the right singular vector of the smallest singular value; for N == 8 the thin SVD only has
+    // 8 columns, so it is the vector of the smallest of the 8 NON-null singular values, not the
+    // null vector.  Replicated: skip (9 - N) eigenvalues from the bottom.
+    int mi = 0;
+    {
+        const int skip = N >= 9 ? 0 : 9 - N;
+        bool used[9];
+        for (int i = 0; i < 9; ++i) used[i] = false;
+        for (int k = 0; k <= skip; ++k) {
+            mi = -1;
+            for (int i = 0; i < 9; ++i)
+                if (!used[i] && (mi < 0 || sG[i * 9 + i] < sG[mi * 9 + mi])) mi = i;
+            used[mi] = true;
+        }
+    }
+    double Fm[9];
+    for (int i = 0; i < 9; ++i) Fm[i] = sV[i * 9 + mi];  // row-major 3x3 (E6)
+    // rank 2: remove the smallest singular direction
+    {
+        double A3[3][3], V3[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) A3[i][j] = Fm[i] * Fm[j] + Fm[3 + i] * Fm[3 + j] + Fm[6 + i] * Fm[6 + j];  // F^T F
+        jacobi_static<3>(A3, V3);
+        int m3 = 0;
+        if (A3[1][1] < A3[m3][m3]) m3 = 1;
+        if (A3[2][2] < A3[m3][m3]) m3 = 2;
+        const double v[3] = {V3[0][m3], V3[1][m3], V3[2][m3]};
+        for (int i = 0; i < 3; ++i) {
+            const double fv = Fm[i * 3] * v[0] + Fm[i * 3 + 1] * v[1] + Fm[i * 3 + 2] * v[2];
+            for (int j = 0; j < 3; ++j) Fm[i * 3 + j] -= fv * v[j];
+        }
+    }
+    // de-normalise: T2^T F T1 with T = [[s,0,-s mx],[0,s,-s my],[0,0,1]]
+    double E[9];
+    {
+        const double T1[9] = {s0, 0, -s0 * mx0, 0, s0, -s0 * my0, 0, 0, 1};
+        const double T2t[9] = {s1, 0, 0, 0, s1, 0, -s1 * mx1, -s1 * my1, 1};
+        double tmp[9];
+        mat3_mul(Fm, T1, tmp);
+        mat3_mul(T2t, tmp, E);
+        if (fabs(E[8]) > 1e-8) {  // normalize_transformation
+            const double d = E[8] + 1e-8;
+            for (int i = 0; i < 9; ++i) E[i] /= d;
+        }
+    }
+    int st = 0;
+    if (!(sstat[4] > 1e-6)) st |= 1;
+    for (int i = 0; i < 9; ++i) {
+        p.E[b * 9 + i] = E[i];
+        if (p.F) p.F[b * 9 + i] = (float)E[i];
+        if (!isfinite(E[i])) st |= 2;
+    }
+    // ---- essential decomposition ----
+    double R1[9], R2[9], tv[3];
+    {
+        double A3[3][3], V3[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) A3[i][j] = E[i] * E[j] + E[3 + i] * E[3 + j] + E[6 + i] * E[6 + j];
+        jacobi_static<3>(A3, V3);
+        // order eigenvalues descending: i0 >= i1 >= i2
+        int i0 = 0, i2 = 0;
+        for (int i = 1; i < 3; ++i) {
+            if (A3[i][i] > A3[i0][i0]) i0 = i;
+            if (A3[i][i] < A3[i2][i2]) i2 = i;
+        }
+        if (i0 == i2) { i0 = 0; i2 = 2; }
+        const int i1 = 3 - i0 - i2;
+        double v1[3] = {V3[0][i0], V3[1][i0], V3[2][i0]};
+        double v2[3] = {V3[0][i1], V3[1][i1], V3[2][i1]};
+        double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+        double u1[3], u2[3];
+        for (int i = 0; i < 3; ++i) {
+            u1[i] = E[i * 3] * v1[0] + E[i * 3 + 1] * v1[1] + E[i * 3 + 2] * v1[2];
+            u2[i] = E[i * 3] * v2[0] + E[i * 3 + 1] * v2[1] + E[i * 3 + 2] * v2[2];
+        }
+        double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+        for (int i = 0; i < 3; ++i) u1[i] /= n1;
+        // Gram-Schmidt keeps U orthonormal when sigma1 ~ sigma2 makes E v2 slightly oblique
+        double dp = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+        for (int i = 0; i < 3; ++i) u2[i] -= dp * u1[i];
+        double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+        for (int i = 0; i < 3; ++i) u2[i] /= n2;
+        double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
+        // R1 = U W V^T, R2 = U W^T V^T,  W = [[0,-1,0],[1,0,0],[0,0,1]]
+        // U W   = [u2, -u1, u3] (columns);  U W^T = [-u2, u1, u3]
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                R1[i * 3 + j] = u2[i] * v1[j] - u1[i] * v2[j] + u3[i] * v3[j];
+                R2[i * 3 + j] = -u2[i] * v1[j] + u1[i] * v2[j] + u3[i] * v3[j];
+            }
+        for (int i = 0; i < 3; ++i) tv[i] = u3[i];
+    }
+    double* cd = p.cands + (int64_t)b * 48;
+    for (int c = 0; c < 4; ++c) {
+        const double* R = (c < 2) ? R1 : R2;
+        const double sg = (c & 1) ? -1.0 : 1.0;
+        for (int i = 0; i < 9; ++i) cd[c * 12 + i] = R[i];
+        for (int i = 0; i < 3; ++i) cd[c * 12 + 9 + i] = sg * tv[i];
+    }
+    int sel = -1;
+    if (p.choose_closest) {  // :95-107, strict < against 1e6 in candidate order
+        const float* Tg = p.Tgt + (int64_t)b * 16;
+        double best = 1e6;
+        sel = -2;  // none accepted -> identity, like the reference's initial eye(4)
+        for (int c = 0; c < 4; ++c) {
+            const double e = angle_err(cd + c * 12, cd + c * 12 + 9, Tg);
+            if (e < best) { best = e; sel = c; }
+        }
+    }
+    p.sel[b] = sel;
+    for (int c = 0; c < 4; ++c) p.counts[b * 4 + c] = 0;
+    if (p.status) p.status[b] = st;
+}
+
+// DLT triangulation of one correspondence with P1 = [I|0], P2 = [R|t]; returns depths.
+__device__ __forceinline__ void triangulate(double x1, double y1, double x2, double y2, const double* Rt,
+                                            double& depth0, double& depth1) {
+    // rows of A: x*P[2] - P[0], y*P[2] - P[1] for both views
+    double Ar[4][4];
+    Ar[0][0] = -1.0; Ar[0][1] = 0.0; Ar[0][2] = x1; Ar[0][3] = 0.0;
+    Ar[1][0] = 0.0; Ar[1][1] = -1.0; Ar[1][2] = y1; Ar[1][3] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        Ar[2][j] = x2 * Rt[6 + j] - Rt[j];
+        Ar[3][j] = y2 * Rt[6 + j] - Rt[3 + j];
+    }
+    Ar[2][3] = x2 * Rt[11] - Rt[9];
+    Ar[3][3] = y2 * Rt[11] - Rt[10];
+    double G[4][4], V[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i; j < 4; ++j) {
+            double v = Ar[0][i] * Ar[0][j] + Ar[1][i] * Ar[1][j] + Ar[2][i] * Ar[2][j] + Ar[3][i] * Ar[3][j];
+            G[i][j] = v;
+            G[j][i] = v;
+        }
+    jacobi_static<4>(G, V);
+    int m = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (G[i][i] < G[m][m]) m = i;
+    double X[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X[i] = (m == 0) ? V[i][0] : (m == 1) ? V[i][1] : (m == 2) ? V[i][2] : V[i][3];
+    // convert_points_from_homogeneous (eps 1e-8)
+    const double sc = fabs(X[3]) > 1e-8 ? 1.0 / (X[3] + 1e-8) : 1.0;
+    const double Xx = X[0] * sc, Xy = X[1] * sc, Xz = X[2] * sc;
+    depth0 = Xz;
+    depth1 = Rt[6] * Xx + Rt[7] * Xy + Rt[8] * Xz + Rt[11];
+}
+
+// Kernel 2: positive-depth test of every point under each of the 4 candidates.
+__global__ __launch_bounds__(256) void w8pt_triangulate(W8Params p) {
+    const int b = blockIdx.y, c = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ double sRt[12];
+    if (threadIdx.x < 12) sRt[threadIdx.x] = p.cands[(int64_t)b * 48 + c * 12 + threadIdx.x];
+    __syncthreads();
+    bool ok = false;
+    if (i < p.N) {
+        const float* a = p.k0n + ((int64_t)b * p.N + i) * 2;
+        const float* q = p.k1n + ((int64_t)b * p.N + i) * 2;
+        double d0, d1;
+        triangulate(a[0], a[1], q[0], q[1], sRt, d0, d1);
+        ok = d0 > 0.0 && d1 > 0.0;
+        p.pd_c[((int64_t)b * 4 + c) * p.N + i] = ok ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&p.counts[b * 4 + c], __popcll(m));
+}
+
+// Kernel 3: pick the pose, emit T, masks.
+__global__ __launch_bounds__(256) void w8pt_select(W8Params p) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    int sel = p.sel[b];
+    if (sel == -1) {  // cheirality vote: first maximum
+        sel = 0;
+        int best = p.counts[b * 4];
+        for (int c = 1; c < 4; ++c)
+            if (p.counts[b * 4 + c] > best) { best = p.counts[b * 4 + c]; sel = c; }
+    }
+    const double* cd = p.cands + (int64_t)b * 48 + (sel >= 0 ? sel : 0) * 12;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float* T = p.T + (int64_t)b * 16;
+        bool fin = true;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) T[r * 4 + c] = sel >= 0 ? (float)cd[r * 3 + c] : (r == c ? 1.f : 0.f);
+            T[r * 4 + 3] = sel >= 0 ? (float)cd[9 + r] : 0.f;
+            for (int c = 0; c < 4; ++c) fin = fin && isfinite(T[r * 4 + c]);
+        }
+        T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+        if (!fin && p.status) p.status[b] |= 2;
+    }
+    if (i >= p.N) return;
+    bool pos;
+    if (sel >= 0) {
+        pos = p.pd_c[((int64_t)b * 4 + sel) * p.N + i] != 0;
+    } else {  // identity pose (choose_closest accepted nothing): triangulate against [I|0]
+        const double Rt[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+        const float* a = p.k0n + ((int64_t)b * p.N + i) * 2;
+        const float* q = p.k1n + ((int64_t)b * p.N + i) * 2;
+        double d0, d1;
+        triangulate(a[0], a[1], q[0], q[1], Rt, d0, d1);
+        pos = d0 > 0.0 && d1 > 0.0;
+    }
+    p.posdepth[(int64_t)b * p.N + i] = pos ? 1 : 0;
+    if (p.determine_inliers) {
+        // symmetrical_epipolar_distance (squared) -> sqrt, threshold 3 px / mean focal (:121-125)
+        const double* E = p.E + (int64_t)b * 9;
+        const float* K0 = p.K0 + (p.intr_batch == 1 ? 0 : (int64_t)b * p.kdim * p.kdim);
+        const float* K1 = p.K1 + (p.intr_batch == 1 ? 0 : (int64_t)b * p.kdim * p.kdim);
+        const float thr = 3.f / ((K0[0] + K0[p.kdim + 1] + K1[0] + K1[p.kdim + 1]) / 4.f);
+        const double x1 = p.k0n[((int64_t)b * p.N + i) * 2], y1 = p.k0n[((int64_t)b * p.N + i) * 2 + 1];
+        const double x2 = p.k1n[((int64_t)b * p.N + i) * 2], y2 = p.k1n[((int64_t)b * p.N + i) * 2 + 1];
+        const double l0 = E[0] * x1 + E[1] * y1 + E[2], l1 = E[3] * x1 + E[4] * y1 + E[5], l2 = E[6] * x1 + E[7] * y1 + E[8];
+        const double m0 = E[0] * x2 + E[3] * y2 + E[6], m1 = E[1] * x2 + E[4] * y2 + E[7];
+        const double num = (x2 * l0 + y2 * l1 + l2);
+        const double sed = num * num * (1.0 / (l0 * l0 + l1 * l1) + 1.0 / (m0 * m0 + m1 * m1));
+        p.inliers[(int64_t)b * p.N + i] = (pos && (float)sqrt(sed) <= thr) ? 1 : 0;
+    }
+}
+
+__global__ void gather_matched_kernel(int N0, int N1, const float* k1, const int64_t* m, const float* conf, float* k1g,
+                                      float* conf_out) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N0) return;
+    int64_t j = m[(int64_t)b * N0 + i];
+    const bool valid = j >= 0;
+    if (j < 0) j += N1;  // python negative index: -1 -> last keypoint (its weight is 0)
+    j = j < 0 ? 0 : (j >= N1 ? N1 - 1 : j);
+    k1g[((int64_t)b * N0 + i) * 2] = k1[((int64_t)b * N1 + j) * 2];
+    k1g[((int64_t)b * N0 + i) * 2 + 1] = k1[((int64_t)b * N1 + j) * 2 + 1];
+    conf_out[(int64_t)b * N0 + i] = valid ? conf[(int64_t)b * N0 + i] : 0.f;
+}
+
+__global__ void pose_errors_kernel(int B, const float* T, const float* Tg, float* rot, float* tr) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* A = T + (int64_t)b * 16;
+    const float* G = Tg + (int64_t)b * 16;
+    float trc = 0.f;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) trc += A[i * 4 + j] * G[i * 4 + j];
+    const float ca = fminf(fmaxf((trc - 1.f) * 0.5f, -1.f), 1.f);
+    rot[b] = fabsf(acosf(ca));
+    const float n0 = sqrtf(A[3] * A[3] + A[7] * A[7] + A[11] * A[11]);
+    const float n1 = sqrtf(G[3] * G[3] + G[7] * G[7] + G[11] * G[11]);
+    float e = 0.f;
+    if (n0 * n1 > 1e-6f) {
+        const float cd = (A[3] * G[3] + A[7] * G[7] + A[11] * G[11]) / (n0 * n1);
+        e = fabsf(acosf(fminf(fmaxf(cd, -1.f), 1.f)));
+    }
+    tr[b] = e;
+}
+
+}  // namespace e2emv
+
+using namespace e2emv;
+
+extern "C" int e2emv_gather_matched(e2emv_ctx* ctx, int B, int N0, int N1, const float* d_kpts1, const int64_t* d_matches,
+                                    const float* d_conf, float* d_kpts1_g, float* d_conf_out, void* stream) {
+    if (!ctx || !d_kpts1 || !d_matches || !d_conf || !d_kpts1_g || !d_conf_out) return E2EMV_EINVAL;
+    if (B <= 0 || N0 <= 0 || N1 <= 0) return set_err(ctx, E2EMV_ESHAPE, "gather_matched: empty problem");
+    hipStream_t s = (hipStream_t)stream;
+    prof_begin(ctx, PS_W8PT, s);
+    hipLaunchKernelGGL(gather_matched_kernel, dim3((N0 + 255) / 256, B), dim3(256), 0, s, N0, N1, d_kpts1, d_matches, d_conf,
+                       d_kpts1_g, d_conf_out);
+    prof_end(ctx, s);
+    E2EMV_CHECK_LAUNCH(ctx, "gather_matched_kernel");
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_w8pt(e2emv_ctx* ctx, int B, int N, const float* d_kpts0, const float* d_kpts1, const float* d_intr0,
+                          const float* d_intr1, int kdim, int intr_batch, const float* d_conf, int choose_closest,
+                          const float* d_T_gt, int determine_inliers, float* d_T, float* d_kpts0n, float* d_kpts1n,
+                          float* d_conf_n, uint8_t* d_inliers, uint8_t* d_posdepth, float* d_F, int32_t* d_status,
+                          void* stream) {
+    if (!ctx || !d_kpts0 || !d_kpts1 || !d_intr0 || !d_intr1 || !d_conf || !d_T || !d_kpts0n || !d_kpts1n || !d_conf_n ||
+        !d_posdepth)
+        return E2EMV_EINVAL;
+    if (choose_closest && !d_T_gt) return set_err(ctx, E2EMV_EINVAL, "w8pt: choose_closest needs T_021");
+    if (determine_inliers && !d_inliers) return set_err(ctx, E2EMV_EINVAL, "w8pt: determine_inliers needs an output buffer");
+    if (B <= 0) return set_err(ctx, E2EMV_ESHAPE, "w8pt: empty batch");
+    if (N < 8) return set_err(ctx, E2EMV_ESHAPE, "w8pt: fewer than 8 correspondences (N=%d)", N);
+    if (kdim != 3 && kdim != 4) return set_err(ctx, E2EMV_ESHAPE, "w8pt: intrinsics must be 3x3 or 4x4");
+    hipStream_t s = (hipStream_t)stream;
+    auto al = [](size_t n) { return (n + 255) & ~size_t(255); };
+    size_t need = al((size_t)B * 9 * 8) + al((size_t)B * 48 * 8) + 2 * al((size_t)B * 4 * 4) + al((size_t)B * 4 * N);
+    int rc = ws_reserve(ctx, need);
+    if (rc) return rc;
+    W8Params p{};
+    p.B = B; p.N = N; p.kdim = kdim; p.intr_batch = intr_batch;
+    p.k0 = d_kpts0; p.k1 = d_kpts1; p.K0 = d_intr0; p.K1 = d_intr1; p.conf = d_conf;
+    p.choose_closest = choose_closest; p.Tgt = d_T_gt; p.determine_inliers = determine_inliers;
+    p.T = d_T; p.k0n = d_kpts0n; p.k1n = d_kpts1n; p.conf_n = d_conf_n; p.inliers = d_inliers; p.posdepth = d_posdepth;
+    p.F = d_F; p.status = d_status;
+    char* w = ctx->d_ws;
+    p.E = (double*)w; w += al((size_t)B * 9 * 8);
+    p.cands = (double*)w; w += al((size_t)B * 48 * 8);
+    p.sel = (int*)w; w += al((size_t)B * 4 * 4);
+    p.counts = (int*)w; w += al((size_t)B * 4 * 4);
+    p.pd_c = (uint8_t*)w;
+    prof_begin(ctx, PS_W8PT, s);
+    hipLaunchKernelGGL(w8pt_fundamental, dim3(B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(w8pt_triangulate, dim3((N + 255) / 256, B, 4), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(w8pt_select, dim3((N + 255) / 256, B), dim3(256), 0, s, p);
+    prof_end(ctx, s);
+    E2EMV_CHECK_LAUNCH(ctx, "w8pt kernels");
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_pose_errors(e2emv_ctx* ctx, int B, const float* d_T, const float* d_T_gt, float* d_rot_err,
+                                 float* d_transl_err, void* stream) {
+    if (!ctx || !d_T || !d_T_gt || !d_rot_err || !d_transl_err) return E2EMV_EINVAL;
+    if (B <= 0) return set_err(ctx, E2EMV_ESHAPE, "pose_errors: empty batch");
+    hipStream_t s = (hipStream_t)stream;
+    prof_begin(ctx, PS_W8PT, s);
+    hipLaunchKernelGGL(pose_errors_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, d_T, d_T_gt, d_rot_err, d_transl_err);
+    prof_end(ctx, s);
+    E2EMV_CHECK_LAUNCH(ctx, "pose_errors_kernel");
+    return E2EMV_OK;
+}

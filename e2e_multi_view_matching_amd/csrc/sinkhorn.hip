@@ -1,0 +1,562 @@
+// Sinkhorn log-space optimal transport with dustbins + mutual-arg-max matching.
+//
+// Restates upstream SuperGlue `log_optimal_transport` / `log_sinkhorn_iterations` and the
+// match block of `SuperGlue.forward` (superglue.py; the reference runs them inside its
+// absent MultiViewMatcher.forward - call sites helpers.py:246, eval_pairs.py:212).
+//
+// HBM plan.  The reference (torch) runs, per iteration, two `Z + v` adds and two
+// logsumexp's over the (N+1)^2 couplings: ~10 sweeps.  SURVEY.md 8(d)'s byte model charges
+// 2 sweeps / iteration.  Here ONE sweep per iteration:
+//   * the couplings matrix is never built: the dustbin row/column are the constant alpha, so
+//     only the aligned core S [M][ldS] is streamed and the dustbin terms are added
+//     analytically;
+//   * a workgroup owns 16 full rows (4 waves x 4 rows, 64 floats per lane in registers):
+//     it computes u for its rows (row LSE = wave shuffles only) and, FROM THE SAME REGISTERS,
+//     the per-column partial (max, sum-exp) of S + u over its 16 rows (cross-wave through
+//     LDS).  `sinkhorn_combine` (one workgroup per pair) folds the M/16 partials into v and
+//     the two dustbin scalars.
+// Row loads are 16 B per lane, 1 KiB contiguous per wave instruction.
+// The final sweep writes logZ = couplings + u + v + log(M+N) densely ([M+1][N+1], the API
+// layout) and fuses the row/column arg-max needed by the match block, so Z is never re-read.
+#include <cmath>
+
+#include "common.h"
+
+namespace e2emv {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int SK_ROWS = 16;  // rows per workgroup (4 waves x 4 rows)
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block-wide (256 threads) max / sum through LDS scratch (>= 8 floats)
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r += red[i];
+    return r;
+}
+
+struct SkParams {
+    const float* S;     // [B][M][ldS]
+    int64_t ldS;
+    int M, N;
+    int chunks;         // ceil(M / SK_ROWS)
+    float alpha;        // bin score
+    float norm;         // -log(M+N)
+    float* u;           // [B][M+1]
+    float* v;           // [B][ldV]  (ldV = ldS + 4, v[N] = dustbin column)
+    int64_t ldV;
+    float* pm;          // [B][chunks][ldS] partial column max
+    float* ps;          // [B][chunks][ldS] partial column sum-exp
+    float* uM;          // [B] dustbin-row potential of the running iteration
+    // final sweep
+    float* logZ;        // [B][M+1][N+1] or null
+    float* max0;        // [B][M] row max of the core (value of logZ)
+    int* idx0;          // [B][M]
+    float* pv;          // [B][chunks][ldS] partial column max value (final)
+    int* pi;            // [B][chunks][ldS] partial column arg-max row (final)
+};
+
+// One sweep of S: u for 16 rows + column partials of S + u.  KT = ceil(ldS / 256).
+template <int KT, bool FINAL>
+__global__ __launch_bounds__(256) void sinkhorn_sweep(SkParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][2][KT*256]
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = chunk * SK_ROWS + wave * 4;
+    const float* Sb = p.S + (int64_t)b * p.M * p.ldS;
+    const float* vb = p.v + (int64_t)b * p.ldV;
+
+    if (FINAL && chunk == p.chunks) {
+        // dustbin row of logZ: (alpha + u_M) + v_j + log(M+N)
+        if (p.logZ) {
+            const float uM = p.u[(int64_t)b * (p.M + 1) + p.M];
+            float* zr = p.logZ + ((int64_t)b * (p.M + 1) + p.M) * (p.N + 1);
+            for (int j = tid; j <= p.N; j += 256) zr[j] = ((p.alpha + uM) + vb[j]) - p.norm;
+        }
+        return;
+    }
+
+    float z[4][KT][4];
+    float vv[KT][4];
+    int col[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        col[k] = 4 * (lane + 64 * k);
+        f32x4 t = (col[k] < p.ldS) ? *reinterpret_cast<const f32x4*>(vb + col[k]) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[k][e] = t[e];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = min(row0 + r, p.M - 1);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            f32x4 t = (col[k] < p.ldS) ? *reinterpret_cast<const f32x4*>(Sb + (int64_t)row * p.ldS + col[k])
+                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[r][k][e] = t[e];
+        }
+    }
+    const float vN = vb[p.N];
+    float ur[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool rvalid = row0 + r < p.M;
+        if (!FINAL) {
+            // u_i = log_mu - LSE_j(S_ij + v_j  U  alpha + v_N)
+            float mx = p.alpha + vN;
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col[k] + e < p.N) mx = fmaxf(mx, z[r][k][e] + vv[k][e]);
+            mx = wave_max(mx);
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col[k] + e < p.N) sm += __expf(z[r][k][e] + vv[k][e] - mx);
+            sm = wave_sum(sm) + __expf(p.alpha + vN - mx);
+            ur[r] = p.norm - (mx + __logf(sm));
+            if (rvalid && lane == 0) p.u[(int64_t)b * (p.M + 1) + row0 + r] = ur[r];
+        } else {
+            ur[r] = p.u[(int64_t)b * (p.M + 1) + min(row0 + r, p.M - 1)];
+        }
+        if (!rvalid) ur[r] = -INFINITY;  // ragged last chunk: row does not exist
+    }
+
+    float* lm = lds + (wave * 2 + 0) * (KT * 256);
+    float* ls = lds + (wave * 2 + 1) * (KT * 256);
+    if (!FINAL) {
+        // column partials over this wave's 4 rows: (max, sum exp) of S_ij + u_i
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            f32x4 m4, s4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y0 = z[0][k][e] + ur[0], y1 = z[1][k][e] + ur[1], y2 = z[2][k][e] + ur[2], y3 = z[3][k][e] + ur[3];
+                float m = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+                float mm = (m == -INFINITY) ? 0.f : m;
+                m4[e] = m;
+                s4[e] = __expf(y0 - mm) + __expf(y1 - mm) + __expf(y2 - mm) + __expf(y3 - mm);
+            }
+            *reinterpret_cast<f32x4*>(lm + col[k]) = m4;
+            *reinterpret_cast<f32x4*>(ls + col[k]) = s4;
+        }
+        __syncthreads();
+        // fold the 4 waves; thread owns 4 consecutive columns per 1024-column group
+        for (int c = tid * 4; c < p.ldS; c += 1024) {
+            f32x4 M4 = *reinterpret_cast<const f32x4*>(lds + c);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(lds + (w * 2) * (KT * 256) + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) M4[e] = fmaxf(M4[e], t[e]);
+            }
+            f32x4 S4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                f32x4 tm = *reinterpret_cast<const f32x4*>(lds + (w * 2) * (KT * 256) + c);
+                f32x4 ts = *reinterpret_cast<const f32x4*>(lds + (w * 2 + 1) * (KT * 256) + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S4[e] += ts[e] * __expf(tm[e] - M4[e]);  // exp(-inf) = 0 for empty waves
+            }
+            const int64_t o = ((int64_t)b * p.chunks + chunk) * p.ldS + c;
+            *reinterpret_cast<f32x4*>(p.pm + o) = M4;
+            *reinterpret_cast<f32x4*>(p.ps + o) = S4;
+        }
+    } else {
+        // final: write logZ rows, row arg-max (first max wins), column partial arg-max
+        int* li = reinterpret_cast<int*>(ls);
+        float cm[KT][4];
+        int ci[KT][4];
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cm[k][e] = -INFINITY; ci[k][e] = 0; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + r;
+            const bool rvalid = row < p.M;  // wave-uniform
+            float best = -INFINITY;
+            int bj = 0x7fffffff;
+            float* zr = p.logZ ? p.logZ + ((int64_t)b * (p.M + 1) + row) * (p.N + 1) : nullptr;
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = col[k] + e;
+                    if (j < p.N) {
+                        // same association as the reference: ((couplings + u) + v) - norm
+                        const float zz = ((z[r][k][e] + ur[r]) + vv[k][e]) - p.norm;
+                        if (rvalid) {
+                            if (zr) zr[j] = zz;
+                            if (zz > best) { best = zz; bj = j; }
+                            if (zz > cm[k][e]) { cm[k][e] = zz; ci[k][e] = row; }
+                        }
+                    }
+                }
+            if (rvalid) {
+                if (zr && lane == 0) zr[p.N] = ((p.alpha + ur[r]) + vN) - p.norm;
+                // wave arg-max, lowest index on ties (torch CPU max semantics)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    float ob = __shfl_xor(best, o);
+                    int oj = __shfl_xor(bj, o);
+                    if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+                }
+                if (lane == 0) {
+                    p.max0[(int64_t)b * p.M + row] = best;
+                    p.idx0[(int64_t)b * p.M + row] = bj;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lm[col[k] + e] = cm[k][e]; li[col[k] + e] = ci[k][e]; }
+        __syncthreads();
+        for (int c = tid; c < p.ldS; c += 256) {
+            float bm = lds[c];
+            int bi = reinterpret_cast<int*>(lds + (KT * 256))[c];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {  // waves own increasing rows: strict > keeps the first
+                float m = lds[(w * 2) * (KT * 256) + c];
+                int i = reinterpret_cast<int*>(lds + (w * 2 + 1) * (KT * 256))[c];
+                if (m > bm) { bm = m; bi = i; }
+            }
+            const int64_t o = ((int64_t)b * p.chunks + chunk) * p.ldS + c;
+            p.pv[o] = bm;
+            p.pi[o] = bi;
+        }
+    }
+}
+
+// One workgroup per pair: fold column partials -> v, dustbin column v_N and next u_M.
+__global__ __launch_bounds__(256) void sinkhorn_combine(SkParams p) {
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* ub = p.u + (int64_t)b * (p.M + 1);
+    float* vb = p.v + (int64_t)b * p.ldV;
+    const float uM = p.uM[b];
+    if (tid == 0) ub[p.M] = uM;  // dustbin-row potential of THIS iteration (read by the final sweep)
+    const float lognu = p.norm;  // log_nu_j for j < N
+    float vmax = -INFINITY;
+    // v_j = log_nu - LSE_i(S_ij + u_i  U  alpha + u_M)
+    for (int c = tid * 4; c < p.ldS; c += 1024) {
+        f32x4 Mx, Sx;
+        const float yb = p.alpha + uM;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { Mx[e] = yb; Sx[e] = 1.f; }
+        const int64_t o0 = (int64_t)b * p.chunks * p.ldS + c;
+#pragma unroll 4
+        for (int ch = 0; ch < p.chunks; ++ch) {
+            f32x4 m = *reinterpret_cast<const f32x4*>(p.pm + o0 + (int64_t)ch * p.ldS);
+            f32x4 s = *reinterpret_cast<const f32x4*>(p.ps + o0 + (int64_t)ch * p.ldS);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float nm = fmaxf(Mx[e], m[e]);
+                Sx[e] = Sx[e] * __expf(Mx[e] - nm) + s[e] * __expf(m[e] - nm);
+                Mx[e] = nm;
+            }
+        }
+        f32x4 vo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            vo[e] = lognu - (Mx[e] + __logf(Sx[e]));
+            if (c + e < p.N) vmax = fmaxf(vmax, vo[e]); else vo[e] = 0.f;
+        }
+        *reinterpret_cast<f32x4*>(vb + c) = vo;
+    }
+    // v_N = log_nu_N - (alpha + LSE(u_0..u_M)),  log_nu_N = log M + norm
+    float um = (tid == 0) ? uM : -INFINITY;
+    for (int i = tid; i < p.M; i += 256) um = fmaxf(um, ub[i]);
+    um = block_max(um, red);
+    float us = (tid == 0) ? __expf(uM - um) : 0.f;
+    for (int i = tid; i < p.M; i += 256) us += __expf(ub[i] - um);
+    us = block_sum(us, red);
+    const float vN = (__logf((float)p.M) + p.norm) - (p.alpha + um + __logf(us));
+    // u_M(next) = log_mu_M - (alpha + LSE(v_0..v_N)),  log_mu_M = log N + norm
+    vmax = fmaxf(block_max(vmax, red), vN);
+    __syncthreads();  // v writes of this block visible to its own re-read below
+    float vs = (tid == 0) ? __expf(vN - vmax) : 0.f;
+    for (int j = tid; j < p.N; j += 256) vs += __expf(vb[j] - vmax);
+    vs = block_sum(vs, red);
+    if (tid == 0) {
+        vb[p.N] = vN;
+        p.uM[b] = (__logf((float)p.N) + p.norm) - (p.alpha + vmax + __logf(vs));
+    }
+}
+
+__global__ void sinkhorn_init(SkParams p, int B) {
+    const int b = blockIdx.x;
+    float* vb = p.v + (int64_t)b * p.ldV;
+    for (int j = threadIdx.x; j < p.ldV; j += blockDim.x) vb[j] = 0.f;
+    if (threadIdx.x == 0)  // u_M of iteration 1: v = 0 -> LSE over N+1 equal entries alpha
+        p.uM[b] = (__logf((float)p.N) + p.norm) - (p.alpha + __logf((float)(p.N + 1)));
+}
+
+// degenerate iters == 0: u = 0 (the reference returns couplings + 0 + 0 - norm)
+__global__ void sinkhorn_zero_u(SkParams p) {
+    const int b = blockIdx.x;
+    float* ub = p.u + (int64_t)b * (p.M + 1);
+    for (int i = threadIdx.x; i <= p.M; i += blockDim.x) ub[i] = 0.f;
+}
+
+struct MatchParams {
+    int M, N, chunks;
+    int64_t ldS;
+    const float* max0;  // [B][M]
+    const int* idx0;    // [B][M]
+    const float* pv;    // [B][chunks][ldS]
+    const int* pi;
+    const int* idx1_in;  // [B][N] when the column arg-max is already final (dense path), else null
+    float thr;
+    int64_t* m0;
+    int64_t* m1;
+    float* ms0;
+    float* ms1;
+};
+
+// Mutual check (match block of SuperGlue.forward).  One workgroup per pair, indices in LDS.
+__global__ __launch_bounds__(256) void match_finalize(MatchParams p) {
+    extern __shared__ int sidx[];  // idx0 [M] | idx1 [N] | valid0 [M]
+    int* i0 = sidx;
+    int* i1 = sidx + p.M;
+    int* v0 = sidx + p.M + p.N;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < p.M; i += 256) i0[i] = p.idx0[(int64_t)b * p.M + i];
+    for (int j = tid; j < p.N; j += 256) {
+        if (p.idx1_in) {
+            i1[j] = p.idx1_in[(int64_t)b * p.N + j];
+        } else {
+            const int64_t o = (int64_t)b * p.chunks * p.ldS + j;
+            float bm = p.pv[o];
+            int bi = p.pi[o];
+            for (int ch = 1; ch < p.chunks; ++ch) {  // chunks own increasing rows: strict > keeps the first
+                float m = p.pv[o + (int64_t)ch * p.ldS];
+                if (m > bm) { bm = m; bi = p.pi[o + (int64_t)ch * p.ldS]; }
+            }
+            i1[j] = bi;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < p.M; i += 256) {
+        const int j = i0[i];
+        const bool mutual = i1[j] == i;
+        const float sc = mutual ? __expf(p.max0[(int64_t)b * p.M + i]) : 0.f;
+        const bool valid = mutual && sc > p.thr;
+        v0[i] = valid;
+        if (p.ms0) p.ms0[(int64_t)b * p.M + i] = sc;
+        if (p.m0) p.m0[(int64_t)b * p.M + i] = valid ? (int64_t)j : (int64_t)-1;
+    }
+    __syncthreads();
+    for (int j = tid; j < p.N; j += 256) {
+        const int i = i1[j];
+        const bool mutual = i0[i] == j;
+        // mscores1 = where(mutual1, mscores0.gather(idx1), 0): mscores0[i] is exp(max0[i]) iff i is mutual
+        const bool mut_i = i1[i0[i]] == i;
+        const float sc = (mutual && mut_i) ? __expf(p.max0[(int64_t)b * p.M + i]) : 0.f;
+        if (p.ms1) p.ms1[(int64_t)b * p.N + j] = sc;
+        if (p.m1) p.m1[(int64_t)b * p.N + j] = (mutual && v0[i]) ? (int64_t)i : (int64_t)-1;
+    }
+}
+
+// ---- dense-logZ arg-max (stand-alone e2emv_extract_matches) ----
+__global__ __launch_bounds__(256) void dense_row_argmax(const float* Z, int M, int N, float* max0, int* idx0) {
+    const int b = blockIdx.y, row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* zr = Z + ((int64_t)b * (M + 1) + row) * (N + 1);
+    float best = -INFINITY;
+    int bj = 0x7fffffff;
+    for (int j = lane; j < N; j += 64) {
+        float zz = zr[j];
+        if (zz > best) { best = zz; bj = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o);
+        int oj = __shfl_xor(bj, o);
+        if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+    }
+    if (lane == 0) { max0[(int64_t)b * M + row] = best; idx0[(int64_t)b * M + row] = bj; }
+}
+__global__ __launch_bounds__(256) void dense_col_argmax(const float* Z, int M, int N, int* idx1) {
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const float* zc = Z + (int64_t)b * (M + 1) * (N + 1) + j;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int i = 0; i < M; ++i) {
+        float zz = zc[(int64_t)i * (N + 1)];
+        if (zz > best) { best = zz; bi = i; }
+    }
+    idx1[(int64_t)b * N + j] = bi;
+}
+
+__global__ void pad_copy_rows(const float* src, int64_t rows, int N, float* dst, int64_t ld) {
+    const int64_t r = blockIdx.x;
+    for (int j = threadIdx.x; j < ld; j += blockDim.x) dst[r * ld + j] = j < N ? src[r * N + j] : 0.f;
+}
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+size_t sinkhorn_ws_bytes(int B, int M, int N) {
+    const int ldS = round_up(N, 4);
+    const int chunks = (M + SK_ROWS - 1) / SK_ROWS;
+    size_t f = 0;
+    auto al = [](size_t n) { return (n * 4 + 255) & ~size_t(255); };
+    f += al((size_t)B * (M + 1));                 // u
+    f += al((size_t)B * (ldS + 4));               // v
+    f += 2 * al((size_t)B * chunks * ldS);        // pm / ps (re-used as pv / pi)
+    f += al(B);                                   // uM
+    f += 2 * al((size_t)B * M);                   // max0, idx0
+    return f;
+}
+
+template <int KT>
+static void launch_sweeps(const SkParams& p, int B, bool final, hipStream_t s) {
+    const size_t lds = sizeof(float) * 8 * KT * 256;
+    if (!final)
+        hipLaunchKernelGGL((sinkhorn_sweep<KT, false>), dim3(p.chunks, B), dim3(256), lds, s, p);
+    else
+        hipLaunchKernelGGL((sinkhorn_sweep<KT, true>), dim3(p.chunks + 1, B), dim3(256), lds, s, p);
+}
+
+int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t ldS, float alpha, int iters,
+                    float match_thr, const SinkhornOut& out, char* ws, hipStream_t s) {
+    if (B <= 0 || M <= 0 || N <= 0) return set_err(ctx, E2EMV_ESHAPE, "sinkhorn: empty problem");
+    if (ldS % 4 || ldS < N || ((uintptr_t)S % 16)) return set_err(ctx, E2EMV_ESHAPE, "sinkhorn: score rows must be 16-byte aligned");
+    if (ldS > 2048) return set_err(ctx, E2EMV_ESHAPE, "sinkhorn: N=%d > 2048 keypoints not supported", N);
+    if ((size_t)(2 * M + N) * 4 > 60000) return set_err(ctx, E2EMV_ESHAPE, "sinkhorn: M=%d too large", M);
+    SkParams p{};
+    p.S = S; p.ldS = ldS; p.M = M; p.N = N;
+    p.chunks = (M + SK_ROWS - 1) / SK_ROWS;
+    p.alpha = alpha;
+    p.norm = -logf((float)(M + N));
+    auto al = [](size_t n) { return (n * 4 + 255) & ~size_t(255); };
+    char* w = ws;
+    p.u = (float*)w; w += al((size_t)B * (M + 1));
+    p.ldV = ldS + 4;
+    p.v = (float*)w; w += al((size_t)B * p.ldV);
+    p.pm = (float*)w; w += al((size_t)B * p.chunks * ldS);
+    p.ps = (float*)w; w += al((size_t)B * p.chunks * ldS);
+    p.uM = (float*)w; w += al(B);
+    p.max0 = (float*)w; w += al((size_t)B * M);
+    p.idx0 = (int*)w; w += al((size_t)B * M);
+    p.pv = p.pm;
+    p.pi = (int*)p.ps;
+    p.logZ = out.logZ;
+    const int KT = (int)((ldS + 255) / 256);
+
+    hipLaunchKernelGGL(sinkhorn_init, dim3(B), dim3(256), 0, s, p, B);
+    if (iters <= 0) hipLaunchKernelGGL(sinkhorn_zero_u, dim3(B), dim3(256), 0, s, p);
+    for (int it = 0; it < iters; ++it) {
+        switch (KT) {
+            case 1: launch_sweeps<1>(p, B, false, s); break;
+            case 2: launch_sweeps<2>(p, B, false, s); break;
+            case 3: case 4: launch_sweeps<4>(p, B, false, s); break;
+            default: launch_sweeps<8>(p, B, false, s); break;
+        }
+        hipLaunchKernelGGL(sinkhorn_combine, dim3(B), dim3(256), 0, s, p);
+    }
+    switch (KT) {
+        case 1: launch_sweeps<1>(p, B, true, s); break;
+        case 2: launch_sweeps<2>(p, B, true, s); break;
+        case 3: case 4: launch_sweeps<4>(p, B, true, s); break;
+        default: launch_sweeps<8>(p, B, true, s); break;
+    }
+    E2EMV_CHECK_LAUNCH(ctx, "sinkhorn kernels");
+    if (out.m0 || out.m1 || out.ms0 || out.ms1) {
+        MatchParams mp{};
+        mp.M = M; mp.N = N; mp.chunks = p.chunks; mp.ldS = ldS;
+        mp.max0 = p.max0; mp.idx0 = p.idx0; mp.pv = p.pv; mp.pi = p.pi; mp.idx1_in = nullptr;
+        mp.thr = match_thr;
+        mp.m0 = out.m0; mp.m1 = out.m1; mp.ms0 = out.ms0; mp.ms1 = out.ms1;
+        hipLaunchKernelGGL(match_finalize, dim3(B), dim3(256), sizeof(int) * (2 * M + N), s, mp);
+        E2EMV_CHECK_LAUNCH(ctx, "match_finalize");
+    }
+    return E2EMV_OK;
+}
+
+}  // namespace e2emv
+
+using namespace e2emv;
+
+extern "C" int e2emv_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* d_scores, float bin_score, int iters,
+                              float* d_logZ, void* stream) {
+    if (!ctx || !d_scores || !d_logZ) return E2EMV_EINVAL;
+    if (B <= 0 || M <= 0 || N <= 0 || iters < 0) return set_err(ctx, E2EMV_ESHAPE, "sinkhorn: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const int ldS = round_up(N, 4);
+    const bool need_copy = (N % 4 != 0) || ((uintptr_t)d_scores % 16 != 0);
+    size_t need = sinkhorn_ws_bytes(B, M, N) + (need_copy ? (((size_t)B * M * ldS * 4 + 255) & ~size_t(255)) : 0);
+    int rc = ws_reserve(ctx, need);
+    if (rc) return rc;
+    char* ws = ctx->d_ws;
+    const float* S = d_scores;
+    prof_begin(ctx, PS_SINKHORN, s);
+    if (need_copy) {
+        float* Sp = (float*)ws;
+        ws += ((size_t)B * M * ldS * 4 + 255) & ~size_t(255);
+        hipLaunchKernelGGL(pad_copy_rows, dim3((unsigned)((int64_t)B * M)), dim3(256), 0, s, d_scores, (int64_t)B * M, N, Sp, (int64_t)ldS);
+        S = Sp;
+    }
+    SinkhornOut out;
+    out.logZ = d_logZ;
+    rc = launch_sinkhorn(ctx, B, M, N, S, ldS, bin_score, iters, 0.f, out, ws, s);
+    prof_end(ctx, s);
+    return rc;
+}
+
+extern "C" int e2emv_extract_matches(e2emv_ctx* ctx, int B, int M, int N, const float* d_logZ, float match_threshold,
+                                     int64_t* d_matches0, int64_t* d_matches1, float* d_mscores0, float* d_mscores1,
+                                     void* stream) {
+    if (!ctx || !d_logZ) return E2EMV_EINVAL;
+    if (B <= 0 || M <= 0 || N <= 0) return set_err(ctx, E2EMV_ESHAPE, "extract_matches: bad sizes");
+    if ((size_t)(2 * M + N) * 4 > 60000) return set_err(ctx, E2EMV_ESHAPE, "extract_matches: too many keypoints");
+    hipStream_t s = (hipStream_t)stream;
+    auto al = [](size_t n) { return (n * 4 + 255) & ~size_t(255); };
+    int rc = ws_reserve(ctx, 2 * al((size_t)B * M) + al((size_t)B * N));
+    if (rc) return rc;
+    char* w = ctx->d_ws;
+    float* max0 = (float*)w; w += al((size_t)B * M);
+    int* idx0 = (int*)w; w += al((size_t)B * M);
+    int* idx1 = (int*)w;
+    prof_begin(ctx, PS_MATCH, s);
+    hipLaunchKernelGGL(dense_row_argmax, dim3((M + 3) / 4, B), dim3(256), 0, s, d_logZ, M, N, max0, idx0);
+    hipLaunchKernelGGL(dense_col_argmax, dim3((N + 255) / 256, B), dim3(256), 0, s, d_logZ, M, N, idx1);
+    MatchParams mp{};
+    mp.M = M; mp.N = N; mp.chunks = 0; mp.ldS = 0;
+    mp.max0 = max0; mp.idx0 = idx0; mp.idx1_in = idx1; mp.thr = match_threshold;
+    mp.m0 = d_matches0; mp.m1 = d_matches1; mp.ms0 = d_mscores0; mp.ms1 = d_mscores1;
+    hipLaunchKernelGGL(match_finalize, dim3(B), dim3(256), sizeof(int) * (2 * M + N), s, mp);
+    prof_end(ctx, s);
+    E2EMV_CHECK_LAUNCH(ctx, "extract_matches kernels");
+    return E2EMV_OK;
+}

@@ -1,0 +1,226 @@
+"""``MultiViewMatcher`` - drop-in for ``models.models.multi_view_matcher.MultiViewMatcher``.
+
+The reference imports it from an absent submodule (``train.py:18``, ``eval_pairs.py:14``,
+``eval_multi_view.py:14``); the contract re-created here is the one its call sites use:
+
+* ``MultiViewMatcher(config: dict)``, ``.config`` a mutable dict (``helpers.py:245`` sets
+  ``config["full_output"]`` after construction), keys ``multi_frame_matching``,
+  ``GNN_layers``, ``conf_mlp``, ``tuple_size`` (``train.py:343-348``) plus the upstream
+  SuperGlue ones (``descriptor_dim``, ``keypoint_encoder``, ``sinkhorn_iterations``,
+  ``match_threshold``).
+* an ``nn.Module`` whose parameters carry the upstream names (``kenc.encoder.*``,
+  ``gnn.layers.{i}.attn.{proj.{0,1,2},merge}``, ``gnn.layers.{i}.mlp.*``, ``final_proj``,
+  ``bin_score``, ``conf_mlp.*``) so ``load_ckpt``'s ``load_state_dict(strict=False)``
+  (``helpers.py:47-52``), ``get_parameters(..., "conf_mlp")`` (``helpers.py:63-71``) and
+  DataParallel/DDP wrapping (``train.py:349-357``) work unchanged.
+* ``forward(data) -> dict`` with ``scores_{i}_{j}`` [B,N+1,N+1], ``matches{i}_{i}_{j}``
+  [B,N] int64, ``conf_scores_{i}_{j}`` [B,N,1] (App. A.4 of SURVEY.md).
+
+The sub-modules below are parameter CONTAINERS only - their torch ``forward`` is never
+called.  ``forward`` hands the weights to libe2emv.so (BN folding / head re-ordering happen
+there) and runs the hand-written HIP path; without the library or an MI355X it raises.
+Inference only: outputs carry no autograd graph (backward is out of scope).
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+
+DEFAULT_CONFIG = {
+    "descriptor_dim": 256,
+    "keypoint_encoder": [32, 64, 128, 256],
+    "GNN_layers": ["self", "cross"] * 9,
+    "num_heads": 4,
+    "sinkhorn_iterations": 100,
+    "match_threshold": 0.2,
+    "multi_frame_matching": False,
+    "tuple_size": 2,
+    "conf_mlp": False,
+    "full_output": False,
+}
+
+
+def _mlp(channels, do_bn=True):
+    """Upstream ``MLP``: Sequential(Conv1d, BN, ReLU, ..., Conv1d) - container only."""
+    layers = []
+    n = len(channels)
+    for i in range(1, n):
+        layers.append(nn.Conv1d(channels[i - 1], channels[i], kernel_size=1, bias=True))
+        if i < n - 1:
+            if do_bn:
+                layers.append(nn.BatchNorm1d(channels[i]))
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+class _KeypointEncoder(nn.Module):
+    def __init__(self, feature_dim, layers):
+        super().__init__()
+        self.encoder = _mlp([3] + list(layers) + [feature_dim])
+        nn.init.constant_(self.encoder[-1].bias, 0.0)
+
+
+class _Attention(nn.Module):
+    def __init__(self, d_model):
+        super().__init__()
+        self.merge = nn.Conv1d(d_model, d_model, kernel_size=1)
+        self.proj = nn.ModuleList([nn.Conv1d(d_model, d_model, kernel_size=1) for _ in range(3)])
+
+
+class _Propagation(nn.Module):
+    def __init__(self, feature_dim):
+        super().__init__()
+        self.attn = _Attention(feature_dim)
+        self.mlp = _mlp([feature_dim * 2, feature_dim * 2, feature_dim])
+        nn.init.constant_(self.mlp[-1].bias, 0.0)
+
+
+class _GNN(nn.Module):
+    def __init__(self, feature_dim, n_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([_Propagation(feature_dim) for _ in range(n_layers)])
+
+
+class MultiViewMatcher(nn.Module):
+    default_config = DEFAULT_CONFIG
+
+    def __init__(self, config=None):
+        super().__init__()
+        self.config = {**self.default_config, **(config or {})}
+        D = self.config["descriptor_dim"]
+        self.kenc = _KeypointEncoder(D, self.config["keypoint_encoder"])
+        self.gnn = _GNN(D, len(self.config["GNN_layers"]))
+        self.final_proj = nn.Conv1d(D, D, kernel_size=1, bias=True)
+        self.bin_score = nn.Parameter(torch.tensor(1.0))
+        if self.config["conf_mlp"]:
+            self.conf_mlp = _mlp([2 * D, D, 1])
+        self._pushed = {}  # device index -> weight fingerprint
+
+    # ------------------------------------------------------------------ weights -> library
+    def _fingerprint(self):
+        sd = self.state_dict()
+        return tuple((k, v.data_ptr(), v._version) for k, v in sd.items() if v.dtype.is_floating_point)
+
+    def _model_desc(self):
+        cfg = self.config
+        md = _lib.ModelDesc()
+        md.desc_dim = cfg["descriptor_dim"]
+        md.num_heads = cfg["num_heads"]
+        kenc = list(cfg["keypoint_encoder"])
+        if len(kenc) > _lib.MAX_KENC or len(cfg["GNN_layers"]) > _lib.MAX_LAYERS:
+            raise ValueError("config exceeds E2EMV_MAX_KENC / E2EMV_MAX_LAYERS")
+        md.n_kenc = len(kenc)
+        for i, c in enumerate(kenc):
+            md.kenc[i] = c
+        md.n_layers = len(cfg["GNN_layers"])
+        for i, name in enumerate(cfg["GNN_layers"]):
+            if name not in ("self", "cross"):
+                raise ValueError(f"GNN layer type {name!r}")
+            md.layer_types[i] = 1 if name == "cross" else 0
+        md.conf_mlp = 1 if cfg["conf_mlp"] else 0
+        return md
+
+    def _push_weights(self, ctx):
+        fp = self._fingerprint()
+        if self._pushed.get(ctx.device) == fp:
+            return
+        for k, v in self.state_dict().items():
+            if not v.dtype.is_floating_point:
+                continue  # num_batches_tracked
+            h = v.detach().to("cpu", torch.float32).contiguous()
+            shape = (ctypes.c_int64 * max(h.dim(), 1))(*h.shape)
+            ctx.call("e2emv_set_weight", k.encode(), ctypes.c_void_p(h.data_ptr()), shape, h.dim())
+        md = self._model_desc()
+        ctx.call("e2emv_commit_weights", ctypes.byref(md))
+        self._pushed[ctx.device] = fp
+
+    # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _tuple_size(data):
+        t = 0
+        while f"keypoints{t}" in data:
+            t += 1
+        return t
+
+    def forward(self, data):
+        cfg = self.config
+        T = self._tuple_size(data)
+        if T < 2:
+            raise KeyError("MultiViewMatcher.forward needs keypoints0, keypoints1, ...")
+        dev = self.bin_score.device
+        if dev.type != "cuda":
+            raise RuntimeError("MultiViewMatcher runs only on an MI355X: call .cuda() first (there is no CPU path; "
+                               "the CPU oracle lives in oracle/ and is test infrastructure)")
+        ctx = _lib.context(dev)
+        self._push_weights(ctx)
+        kpts, scores, descs = [], [], []
+        fd = _lib.ForwardDesc()
+        for m in range(T):
+            k = data[f"keypoints{m}"].to(dev, torch.float32).contiguous()
+            s = data[f"scores{m}"].to(dev, torch.float32).contiguous()
+            d = data[f"descriptors{m}"].to(dev)
+            if d.dtype not in (torch.float32, torch.float16):
+                d = d.float()
+            d = d.contiguous()
+            kpts.append(k), scores.append(s), descs.append(d)
+            if f"image{m}" in data:
+                h, w = data[f"image{m}"].shape[-2:]
+            else:
+                h, w = data[f"image_size{m}"]
+            fd.img_w[m], fd.img_h[m] = float(w), float(h)
+        B, N = kpts[0].shape[:2]
+        D = cfg["descriptor_dim"]
+        for m in range(T):
+            if kpts[m].shape != (B, N, 2) or scores[m].shape != (B, N) or descs[m].shape != (B, D, N):
+                raise AssertionError(f"image {m}: keypoints {tuple(kpts[m].shape)} scores {tuple(scores[m].shape)} "
+                                     f"descriptors {tuple(descs[m].shape)} (all images of a call share B and N)")
+        if len({d.dtype for d in descs}) != 1:
+            raise AssertionError("mixed descriptor dtypes")
+        out = {}
+        pairs = [(i, j) for j in range(T) for i in range(j)]
+        if N == 0:  # upstream: no keypoints -> empty matches
+            for i, j in pairs:
+                out[f"scores_{i}_{j}"] = torch.full((B, 1, 1), 0.0, device=dev)
+                out[f"matches{i}_{i}_{j}"] = torch.empty((B, 0), dtype=torch.int64, device=dev)
+                out[f"matches{j}_{i}_{j}"] = torch.empty((B, 0), dtype=torch.int64, device=dev)
+                out[f"conf_scores_{i}_{j}"] = torch.empty((B, 0, 1), device=dev)
+            return out
+        full = bool(cfg.get("full_output", False)) or not self.training
+        fd.batch, fd.tuple_size, fd.n_kpts = B, T, N
+        fd.sinkhorn_iters = int(cfg["sinkhorn_iterations"])
+        fd.match_threshold = float(cfg["match_threshold"])
+        fd.desc_dtype = _lib.DESC_F16 if descs[0].dtype == torch.float16 else _lib.DESC_F32
+        fd.flags = (_lib.FLAG_FULL_OUTPUT if full else 0) | (_lib.FLAG_MULTI_FRAME if cfg["multi_frame_matching"] else 0)
+        P = len(pairs)
+        logZ = [torch.empty((B, N + 1, N + 1), dtype=torch.float32, device=dev) for _ in range(P)]
+        none = [None] * P
+        if full:
+            m0 = [torch.empty((B, N), dtype=torch.int64, device=dev) for _ in range(P)]
+            m1 = [torch.empty((B, N), dtype=torch.int64, device=dev) for _ in range(P)]
+            s0 = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(P)]
+            s1 = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(P)]
+            cf = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(P)]
+        else:
+            m0 = m1 = s0 = s1 = cf = none
+        keep = []
+        args = []
+        for lst in (kpts, scores, descs, logZ, m0, m1, s0, s1, cf):
+            p, arr = _lib.ptr_array(lst)
+            keep.append(arr)
+            args.append(p)
+        with torch.cuda.device(dev):
+            ctx.call("e2emv_matcher_forward", ctypes.byref(fd), *args, _lib.stream_ptr(dev))
+        for p, (i, j) in enumerate(pairs):
+            out[f"scores_{i}_{j}"] = logZ[p]
+            if full:
+                out[f"matches{i}_{i}_{j}"] = m0[p]
+                out[f"matches{j}_{i}_{j}"] = m1[p]
+                out[f"matching_scores{i}_{i}_{j}"] = s0[p]
+                out[f"matching_scores{j}_{i}_{j}"] = s1[p]
+                out[f"conf_scores_{i}_{j}"] = cf[p].unsqueeze(-1)
+        return out
+
+
+SuperGlue = MultiViewMatcher  # the north-star's name for the same forward()

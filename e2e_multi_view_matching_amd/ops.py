@@ -1,0 +1,72 @@
+"""Stand-alone operators of the hot path (thin ctypes wrappers, torch = memory only)."""
+import torch
+
+from . import _lib
+
+
+def _ctx(t):
+    if not t.is_cuda:
+        raise RuntimeError("e2e_multi_view_matching_amd operators need CUDA/HIP tensors on an MI355X (no CPU fallback)")
+    return _lib.context(t.device)
+
+
+def log_optimal_transport(scores, bin_score, iters):
+    """Upstream ``log_optimal_transport``: scores [B,M,N] -> log assignment [B,M+1,N+1]."""
+    ctx = _ctx(scores)
+    s = scores.to(torch.float32).contiguous()
+    B, M, N = s.shape
+    Z = torch.empty((B, M + 1, N + 1), dtype=torch.float32, device=s.device)
+    with torch.cuda.device(s.device):
+        ctx.call("e2emv_sinkhorn", B, M, N, _lib.ptr(s), float(bin_score), int(iters), _lib.ptr(Z), _lib.stream_ptr(s.device))
+    return Z
+
+
+def extract_matches(logZ, match_threshold):
+    """Mutual arg-max block of ``SuperGlue.forward`` on logZ [B,M+1,N+1]."""
+    ctx = _ctx(logZ)
+    z = logZ.to(torch.float32).contiguous()
+    B, M, N = z.shape[0], z.shape[1] - 1, z.shape[2] - 1
+    dev = z.device
+    m0 = torch.empty((B, M), dtype=torch.int64, device=dev)
+    m1 = torch.empty((B, N), dtype=torch.int64, device=dev)
+    s0 = torch.empty((B, M), dtype=torch.float32, device=dev)
+    s1 = torch.empty((B, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ctx.call("e2emv_extract_matches", B, M, N, _lib.ptr(z), float(match_threshold), _lib.ptr(m0), _lib.ptr(m1),
+                 _lib.ptr(s0), _lib.ptr(s1), _lib.stream_ptr(dev))
+    return m0, m1, s0, s1
+
+
+def gemm_nt(A, W, bias=None, residual=None, A2=None, scale=1.0, relu=False):
+    """C = act(scale * [A | A2] W^T + bias) (+ residual); A [M,K1] or [Bt,M,K1], W [N,K] or [Bt,N,K]."""
+    ctx = _ctx(A)
+    batched = A.dim() == 3
+    A_ = A.contiguous().float()
+    W_ = W.contiguous().float()
+    A2_ = A2.contiguous().float() if A2 is not None else None
+    if not batched:
+        A_, W_ = A_.unsqueeze(0), W_.unsqueeze(0)
+        A2_ = A2_.unsqueeze(0) if A2_ is not None else None
+    Bt, M, K1 = A_.shape
+    N, K = W_.shape[1], W_.shape[2]
+    C = torch.empty((Bt, M, N), dtype=torch.float32, device=A.device)
+    R = residual.contiguous().float().reshape(Bt, M, N) if residual is not None else None
+    b = bias.contiguous().float() if bias is not None else None
+    with torch.cuda.device(A.device):
+        ctx.call("e2emv_gemm_nt", Bt, M, N, K, K1, _lib.ptr(A_), K1, M * K1, _lib.ptr(A2_), (K - K1), M * (K - K1),
+                 _lib.ptr(W_), K, (N * K if W.dim() == 3 else 0), _lib.ptr(b), _lib.ptr(R), N, M * N, _lib.ptr(C), N, M * N,
+                 float(scale), 1 if relu else 0, _lib.stream_ptr(A.device))
+    return C if batched else C[0]
+
+
+def attention(qkv, B, T, n_valid, H, cross):
+    """qkv [B*T, n_rows, 3D] head-major -> out [B*T, n_rows, D]."""
+    ctx = _ctx(qkv)
+    q = qkv.contiguous().float()
+    n_img, n_rows, D3 = q.shape
+    D = D3 // 3
+    out = torch.zeros((n_img, n_rows, D), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        ctx.call("e2emv_attention", B, T, n_rows, n_valid, D, H, _lib.ptr(q), 1 if cross else 0, _lib.ptr(out),
+                 _lib.stream_ptr(q.device))
+    return out

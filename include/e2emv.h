@@ -1,0 +1,182 @@
+/*
+ * e2emv.h - C ABI of libe2emv.so: the MI355X (gfx950) implementation of the
+ * matcher -> Sinkhorn -> weighted-8-point hot path of barbararoessle/e2e_multi_view_matching.
+ *
+ * The reference has NO native/FFI seam for this path: the seam is two Python callables,
+ *   MultiViewMatcher.forward(data) -> dict      (absent submodule; call sites
+ *       helpers.py:246, eval_pairs.py:212, eval_multi_view.py:160)
+ *   estimate_relative_pose_w8pt(...) -> (T, info)
+ *       (pose_optimization/two_view/estimate_relative_pose.py:84-128)
+ * The Python package e2e_multi_view_matching_amd re-creates those callables on top of the
+ * entry points below through ctypes (INTEGRATION.md shows the binding).  Every function is
+ * extern "C", takes plain pointers and sizes, never throws, and returns 0 or a negative
+ * e2emv_status; the message for the last failure of a context is e2emv_last_error().
+ *
+ * Pointers named d_* are DEVICE pointers (hipMalloc / torch.cuda / e2emv_malloc memory on
+ * the context's device).  Everything else is host memory.  `stream` is a hipStream_t passed
+ * as void* (NULL = the default stream); all compute calls are asynchronous w.r.t. it.
+ * The caller owns every input/output buffer; the library owns only its context (weights,
+ * workspace arena grown lazily, never shrunk).  One context per (process, device); calls on
+ * one context must be serialised by the caller; different contexts are independent.
+ */
+#ifndef E2EMV_H
+#define E2EMV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E2EMV_ABI_VERSION 1
+#define E2EMV_MAX_TUPLE 8
+#define E2EMV_MAX_LAYERS 64
+#define E2EMV_MAX_KENC 8
+
+typedef struct e2emv_ctx e2emv_ctx;
+
+typedef enum {
+    E2EMV_OK = 0,
+    E2EMV_EINVAL = -1, /* bad argument / NULL pointer                                     */
+    E2EMV_ENOMEM = -2, /* device or host allocation failed                                */
+    E2EMV_EHIP = -3,   /* HIP runtime error (no device, launch failure, ...)              */
+    E2EMV_ESHAPE = -4, /* unsupported or inconsistent shape                               */
+    E2EMV_ESTATE = -5  /* weights missing / not committed                                 */
+} e2emv_status;
+
+/* ---- lifecycle -------------------------------------------------------------------- */
+int e2emv_version(void);
+/* Fails with E2EMV_EHIP when no gfx950 device is usable: there is NO CPU fallback. */
+int e2emv_create(e2emv_ctx** out, int device);
+void e2emv_destroy(e2emv_ctx* ctx);
+const char* e2emv_last_error(const e2emv_ctx* ctx);
+
+/* ---- memory helpers (so a harness without torch can drive the library) ------------ */
+int e2emv_malloc(e2emv_ctx* ctx, void** d_ptr, size_t bytes);
+int e2emv_free(e2emv_ctx* ctx, void* d_ptr);
+int e2emv_h2d(e2emv_ctx* ctx, void* d_dst, const void* src, size_t bytes, void* stream);
+int e2emv_d2h(e2emv_ctx* ctx, void* dst, const void* d_src, size_t bytes, void* stream);
+int e2emv_sync(e2emv_ctx* ctx, void* stream);
+
+/* ---- weights ----------------------------------------------------------------------
+ * Replaces MultiViewMatcher.load_state_dict (helpers.py:47-52).  Keys are the upstream
+ * SuperGlue parameter names the reference's checkpoints use:
+ *   kenc.encoder.{0,3,..}.{weight,bias}, kenc.encoder.{1,4,..}.{weight,bias,running_mean,
+ *   running_var}, gnn.layers.{i}.attn.proj.{0,1,2}.{weight,bias}, gnn.layers.{i}.attn.merge.*,
+ *   gnn.layers.{i}.mlp.{0,3}.*, gnn.layers.{i}.mlp.1.* (BatchNorm), final_proj.*, bin_score,
+ *   conf_mlp.{0,3}.*, conf_mlp.1.*   (a leading "module." is stripped).
+ * Tensors are host fp32, dense row-major, Conv1d weights [out,in,1] or [out,in].
+ * e2emv_commit_weights folds eval-mode BatchNorm into the preceding conv, re-orders the
+ * attention channels from upstream's c = dd*H + h to head-major, and uploads.             */
+typedef struct {
+    int32_t desc_dim;                        /* D, 256                                    */
+    int32_t num_heads;                       /* H, 4 (head dim D/H must be 64)            */
+    int32_t n_kenc;                          /* hidden keypoint-encoder layers            */
+    int32_t kenc[E2EMV_MAX_KENC];            /* [32,64,128,256]                           */
+    int32_t n_layers;                        /* L = len(GNN_layers)                       */
+    int32_t layer_types[E2EMV_MAX_LAYERS];   /* 0 = 'self', 1 = 'cross'                   */
+    int32_t conf_mlp;                        /* 1: conf_mlp.* weights present             */
+} e2emv_model_desc;
+
+int e2emv_set_weight(e2emv_ctx* ctx, const char* key, const float* data, const int64_t* shape, int ndim);
+int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* model);
+
+/* ---- matcher forward --------------------------------------------------------------
+ * Replaces MultiViewMatcher.forward(data) (call sites above).  B tuples of T images with
+ * N keypoints each; P = T(T-1)/2 pairs ordered (0,1),(0,2),(1,2),(0,3)... i.e. for j in
+ * range(T): for i in range(j) - the order helpers.py:250-251 iterates.                    */
+#define E2EMV_FLAG_FULL_OUTPUT 1 /* also produce matches / scores / confidences           */
+#define E2EMV_FLAG_MULTI_FRAME 2 /* joint GNN over all T images (cross = all other images) */
+#define E2EMV_DESC_F32 0
+#define E2EMV_DESC_F16 1
+
+typedef struct {
+    int32_t batch;          /* B                                                          */
+    int32_t tuple_size;     /* T <= E2EMV_MAX_TUPLE                                       */
+    int32_t n_kpts;         /* N (same for every image of the call)                       */
+    int32_t sinkhorn_iters; /* 100                                                        */
+    float match_threshold;  /* 0.2                                                        */
+    int32_t desc_dtype;     /* E2EMV_DESC_F32 | E2EMV_DESC_F16                            */
+    int32_t flags;
+    float img_w[E2EMV_MAX_TUPLE], img_h[E2EMV_MAX_TUPLE]; /* data['image{m}'].shape[-1/-2] */
+} e2emv_forward_desc;
+
+/* d_kpts[m]   [B,N,2] f32 pixel xy      (data['keypoints{m}'])
+ * d_kscores[m][B,N]   f32               (data['scores{m}'])
+ * d_desc[m]   [B,D,N] f32|f16, N contiguous (data['descriptors{m}'])
+ * outputs, one pointer per pair p (any may be NULL = not wanted):
+ * d_logZ[p]     [B,N+1,N+1] f32  result['scores_{i}_{j}']
+ * d_matches0[p] [B,N] int64      result['matches{i}_{i}_{j}'] (-1 = unmatched; int64 because
+ *                                the reference uses it as a fancy index, estimate_relative_pose.py:26-30)
+ * d_matches1[p] [B,N] int64      result['matches{j}_{i}_{j}']
+ * d_mscores0/1[p] [B,N] f32      matching scores
+ * d_conf[p]     [B,N] f32        result['conf_scores_{i}_{j}'] (caller views it [B,N,1])  */
+int e2emv_matcher_forward(e2emv_ctx* ctx, const e2emv_forward_desc* fd,
+                          const float* const* d_kpts, const float* const* d_kscores, const void* const* d_desc,
+                          float* const* d_logZ, int64_t* const* d_matches0, int64_t* const* d_matches1,
+                          float* const* d_mscores0, float* const* d_mscores1, float* const* d_conf,
+                          void* stream);
+
+/* ---- Sinkhorn / matching as stand-alone operators ---------------------------------
+ * log_optimal_transport(scores, bin_score, iters) of upstream superglue.py (used inside the
+ * forward above): d_scores [B,M,N] f32 -> d_logZ [B,M+1,N+1] f32.                         */
+int e2emv_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* d_scores, float bin_score, int iters,
+                   float* d_logZ, void* stream);
+/* mutual arg-max block of SuperGlue.forward on d_logZ [B,M+1,N+1]. */
+int e2emv_extract_matches(e2emv_ctx* ctx, int B, int M, int N, const float* d_logZ, float match_threshold,
+                          int64_t* d_matches0, int64_t* d_matches1, float* d_mscores0, float* d_mscores1,
+                          void* stream);
+
+/* ---- two-view pose ----------------------------------------------------------------
+ * get_kpts (estimate_relative_pose.py:16-31): d_kpts1_g[b,n] = d_kpts1[b, matches[b,n]]
+ * (index -1 wraps to the last keypoint), d_conf_out = (matches >= 0) * d_conf.             */
+int e2emv_gather_matched(e2emv_ctx* ctx, int B, int N0, int N1, const float* d_kpts1, const int64_t* d_matches,
+                         const float* d_conf, float* d_kpts1_g, float* d_conf_out, void* stream);
+
+/* estimate_relative_pose_w8pt (estimate_relative_pose.py:84-128).
+ * d_kpts0/1 [B,N,2]; d_intr0/1 [B,kdim,kdim] (kdim 3 or 4, or batch-broadcast when
+ * intr_batch == 1); d_conf [B,N]; d_T_gt [B,4,4] needed iff choose_closest.
+ * Outputs: d_T [B,4,4]; d_kpts0n/d_kpts1n [B,N,2]; d_conf_n [B,N] (normalised weights);
+ * d_inliers [B,N] u8 (written iff determine_inliers); d_posdepth [B,N] u8; d_F [B,3,3]
+ * (the estimated essential matrix, may be NULL); d_status [B] int32 (bit0: sum(conf)<=1e-6,
+ * bit1: non-finite result), may be NULL.  Returns E2EMV_ESHAPE when N < 8 (the Python shim
+ * maps that to the reference's (None, None), estimate_relative_pose.py:85-86).             */
+int e2emv_w8pt(e2emv_ctx* ctx, int B, int N, const float* d_kpts0, const float* d_kpts1, const float* d_intr0,
+               const float* d_intr1, int kdim, int intr_batch, const float* d_conf, int choose_closest,
+               const float* d_T_gt, int determine_inliers, float* d_T, float* d_kpts0n, float* d_kpts1n,
+               float* d_conf_n, uint8_t* d_inliers, uint8_t* d_posdepth, float* d_F, int32_t* d_status,
+               void* stream);
+
+/* compute_rotation_error / compute_translation_error_as_angle(reduce=False)
+ * (compute_pose_error.py:3-22), radians; entries with |t0||t1| <= 1e-6 give 0.             */
+int e2emv_pose_errors(e2emv_ctx* ctx, int B, const float* d_T, const float* d_T_gt, float* d_rot_err,
+                      float* d_transl_err, void* stream);
+
+/* ---- building blocks exported for per-kernel parity tests and micro-benchmarks ----- */
+/* C[z][m][n] = act(sum_k A[z][m][k] W[z][n][k] * scale + bias[n]) (+ R[z][m][n]); all f32;
+ * A may be split in two K-segments (A: k < K1, A2: K1 <= k < K).  flags: bit0 relu.        */
+int e2emv_gemm_nt(e2emv_ctx* ctx, int batch, int M, int Nout, int K, int K1, const float* d_A, int64_t lda,
+                  int64_t strideA, const float* d_A2, int64_t lda2, int64_t strideA2, const float* d_W,
+                  int64_t ldw, int64_t strideW, const float* d_bias, const float* d_R, int64_t ldr,
+                  int64_t strideR, float* d_C, int64_t ldc, int64_t strideC, float scale, int flags,
+                  void* stream);
+/* Multi-head attention over head-major channels: d_qkv [n_img, n_rows, 3*D] (q|k|v), image
+ * g = b*T + t attends to itself (cross == 0) or to every other image of its tuple;
+ * n_valid keys/queries per image; output d_out [n_img, n_rows, D].                         */
+int e2emv_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv,
+                    int cross, float* d_out, void* stream);
+
+/* ---- timing hooks used by bench.py (HIP events on the caller's stream) -------------
+ * After e2emv_profile(ctx, 1) every kernel family launched by the library is bracketed by
+ * HIP events on its stream; e2emv_profile_read returns accumulated milliseconds and launch
+ * counts per family since the last reset (host-synchronising).                             */
+#define E2EMV_PROF_SLOTS 16
+int e2emv_profile(e2emv_ctx* ctx, int enable);
+int e2emv_profile_read(e2emv_ctx* ctx, float* ms, int64_t* launches, int n_slots, int reset);
+const char* e2emv_profile_name(int slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E2EMV_H */

@@ -1,0 +1,108 @@
+"""Per-kernel parity (-m gpu): HIP building blocks through the C ABI vs torch fp64 / the oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 64), (1024, 512, 512), (65, 33, 256)])
+def test_gemm_nt_plain(gpu, M, N, K):
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)  # asymmetric operands: catches transposed C layouts
+    b = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T + b.double()
+    out = E.gemm_nt(A.to(gpu), W.to(gpu), bias=b.to(gpu)).cpu()
+    assert _rel(out, ref) < 2e-6
+
+
+def test_gemm_nt_epilogues_and_split_k(gpu):
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(7)
+    M, N, K1, K2 = 257, 512, 256, 256
+    A, A2 = torch.randn(M, K1, generator=g), torch.randn(M, K2, generator=g)
+    W, b, R = torch.randn(N, K1 + K2, generator=g), torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = torch.relu(0.5 * (torch.cat([A, A2], 1).double() @ W.double().T) + b.double()) + R.double()
+    out = E.gemm_nt(A.to(gpu), W.to(gpu), bias=b.to(gpu), residual=R.to(gpu), A2=A2.to(gpu), scale=0.5, relu=True).cpu()
+    assert _rel(out, ref) < 2e-6
+
+
+def test_gemm_nt_batched_is_score_matrix(gpu):
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(11)
+    d0, d1 = torch.randn(3, 200, 256, generator=g), torch.randn(3, 136, 256, generator=g)
+    ref = torch.einsum("bnd,bmd->bnm", d0.double(), d1.double()) / 16.0
+    out = E.gemm_nt(d0.to(gpu), d1.to(gpu), scale=1 / 16.0).cpu()
+    assert _rel(out, ref) < 2e-6
+
+
+def _attention_ref(qkv, B, T, n_valid, H, cross):
+    n_img, n_rows, D3 = qkv.shape
+    D = D3 // 3
+    d = D // H
+    q = qkv[..., :D].view(n_img, n_rows, H, d).double()
+    k = qkv[..., D:2 * D].view(n_img, n_rows, H, d).double()
+    v = qkv[..., 2 * D:].view(n_img, n_rows, H, d).double()
+    out = torch.zeros(n_img, n_rows, H, d, dtype=torch.float64)
+    for g in range(n_img):
+        b, t = divmod(g, T)
+        srcs = [b * T + s for s in range(T) if s != t] if cross else [g]
+        kk = torch.cat([k[s, :n_valid] for s in srcs], 0)
+        vv = torch.cat([v[s, :n_valid] for s in srcs], 0)
+        sc = torch.einsum("nhd,mhd->hnm", q[g, :n_valid], kk) / d ** 0.5
+        out[g, :n_valid] = torch.einsum("hnm,mhd->nhd", torch.softmax(sc, -1), vv)
+    return out.view(n_img, n_rows, D)
+
+
+@pytest.mark.parametrize("B,T,n_rows,n_valid,cross", [(2, 2, 128, 128, 0), (2, 2, 256, 200, 1), (1, 3, 256, 131, 1),
+                                                       (1, 2, 128, 5, 0)])
+def test_attention(gpu, B, T, n_rows, n_valid, cross):
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(n_valid)
+    qkv = torch.randn(B * T, n_rows, 3 * 256, generator=g) * 1.5
+    ref = _attention_ref(qkv, B, T, n_valid, 4, cross)
+    out = E.attention(qkv.to(gpu), B, T, n_valid, 4, cross).cpu()
+    err = (out[:, :n_valid].double() - ref[:, :n_valid]).abs().max()
+    assert float(err) < 2e-5, float(err)
+
+
+def test_attention_spiked_key_forces_rescale(gpu):
+    """Online-softmax rescale branch: one key dominates late in the stream."""
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(2, 256, 768, generator=g)
+    qkv[0, 200, 256:512] = qkv[0, 17, 0:256] * 6.0  # key 200 aligned with query 17, all heads
+    ref = _attention_ref(qkv, 1, 2, 256, 4, 0)
+    out = E.attention(qkv.to(gpu), 1, 2, 256, 4, 0).cpu()
+    assert float((out.double() - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("B,M,N,iters", [(3, 128, 128, 100), (2, 100, 77, 20), (1, 1024, 1024, 100), (2, 33, 250, 5),
+                                         (1, 16, 16, 0), (1, 2048, 2048, 10)])
+def test_sinkhorn_vs_oracle(gpu, B, M, N, iters):
+    import e2e_multi_view_matching_amd as E
+    from oracle.sinkhorn import log_optimal_transport
+    g = torch.Generator().manual_seed(B * 1000 + M + N)
+    s = torch.randn(B, M, N, generator=g) * 3.0
+    ref = log_optimal_transport(s, 1.0, iters)
+    out = E.log_optimal_transport(s.to(gpu), 1.0, iters).cpu()
+    assert out.shape == ref.shape
+    assert float((out - ref).abs().max()) < 1e-4
+
+
+def test_extract_matches_vs_oracle(gpu):
+    import e2e_multi_view_matching_amd as E
+    from oracle.sinkhorn import extract_matches, log_optimal_transport
+    g = torch.Generator().manual_seed(5)
+    s = torch.randn(3, 150, 97, generator=g) * 6.0
+    Z = log_optimal_transport(s, 1.0, 50)
+    i0, i1, s0, s1 = extract_matches(Z, 0.2)
+    m0, m1, ms0, ms1 = E.extract_matches(Z.to(gpu), 0.2)
+    assert torch.equal(m0.cpu(), i0) and torch.equal(m1.cpu(), i1)
+    assert float((ms0.cpu() - s0).abs().max()) < 1e-6 and float((ms1.cpu() - s1).abs().max()) < 1e-6
+    assert (i0 >= 0).sum() > 0

@@ -1,0 +1,107 @@
+"""Matcher forward parity (-m gpu): MultiViewMatcher (HIP) vs oracle.matcher (torch CPU)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north-star: scores within 1e-4 fp32, assignment indices bit-exact
+
+
+def _randomize_bn(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+
+
+def _run(cfg, data_kw, gpu, seed=0, w_id=False):
+    from e2e_multi_view_matching_amd import MultiViewMatcher
+    from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
+    from oracle.matcher import matcher_forward
+    torch.manual_seed(seed)
+    model = MultiViewMatcher(cfg).eval()
+    _randomize_bn(model, seed)
+    if w_id:
+        identity_like_state(model)
+    data = make_tuples(seed=seed, **data_kw)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ocfg = dict(model.config)
+    ocfg["full_output"] = True
+    ref = matcher_forward(data, sd, ocfg)
+    model = model.to(gpu)
+    with torch.no_grad():
+        out = model({k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in data.items()})
+    return out, ref, data
+
+
+def _compare(out, ref, pairs):
+    for i, j in pairs:
+        z, zr = out[f"scores_{i}_{j}"].cpu(), ref[f"scores_{i}_{j}"]
+        assert float((z - zr).abs().max()) < TOL, (i, j, float((z - zr).abs().max()))
+        for key in (f"matches{i}_{i}_{j}", f"matches{j}_{i}_{j}"):
+            assert torch.equal(out[key].cpu(), ref[key]), key
+        c, cr = out[f"conf_scores_{i}_{j}"].cpu(), ref[f"conf_scores_{i}_{j}"]
+        assert c.shape == cr.shape and float((c - cr).abs().max()) < TOL
+
+
+@pytest.mark.parametrize("conf_mlp", [False, True])
+def test_pair_random_weights(gpu, conf_mlp):
+    cfg = {"GNN_layers": ["self", "cross"] * 2, "sinkhorn_iterations": 20, "conf_mlp": conf_mlp, "match_threshold": 0.0}
+    out, ref, _ = _run(cfg, dict(batch=2, tuple_size=2, n_kpts=256), gpu, seed=1)
+    _compare(out, ref, [(0, 1)])
+
+
+def test_pair_identity_weights_gives_real_matches(gpu):
+    cfg = {"GNN_layers": ["self", "cross"] * 2, "sinkhorn_iterations": 50, "conf_mlp": True}
+    out, ref, data = _run(cfg, dict(batch=2, tuple_size=2, n_kpts=256), gpu, seed=2, w_id=True)
+    _compare(out, ref, [(0, 1)])
+    m = out["matches0_0_1"].cpu()
+    gt = data["gt_matches0_0_1"]
+    assert ((m == gt) & (gt >= 0)).sum() > 0.8 * (gt >= 0).sum()
+
+
+def test_ragged_keypoint_count(gpu):
+    cfg = {"GNN_layers": ["self", "cross"], "sinkhorn_iterations": 10}
+    out, ref, _ = _run(cfg, dict(batch=1, tuple_size=2, n_kpts=203), gpu, seed=3, w_id=True)
+    _compare(out, ref, [(0, 1)])
+
+
+def test_multi_frame_tuple3(gpu):
+    cfg = {"GNN_layers": ["self", "cross", "cross"], "sinkhorn_iterations": 10, "multi_frame_matching": True, "tuple_size": 3}
+    out, ref, _ = _run(cfg, dict(batch=2, tuple_size=3, n_kpts=128), gpu, seed=4, w_id=True)
+    _compare(out, ref, [(0, 1), (0, 2), (1, 2)])
+
+
+def test_pairwise_mode_on_tuple3(gpu):
+    cfg = {"GNN_layers": ["self", "cross"], "sinkhorn_iterations": 10, "multi_frame_matching": False, "tuple_size": 3}
+    out, ref, _ = _run(cfg, dict(batch=1, tuple_size=3, n_kpts=128), gpu, seed=5, w_id=True)
+    _compare(out, ref, [(0, 1), (0, 2), (1, 2)])
+
+
+def test_fp16_descriptors_match_fp16_rounded_oracle(gpu):
+    cfg = {"GNN_layers": ["self", "cross"], "sinkhorn_iterations": 10}
+    from e2e_multi_view_matching_amd import MultiViewMatcher
+    from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
+    from oracle.matcher import matcher_forward
+    torch.manual_seed(0)
+    model = identity_like_state(MultiViewMatcher(cfg).eval())
+    data = make_tuples(batch=1, tuple_size=2, n_kpts=128, seed=9, desc_dtype=torch.float16)
+    rounded = {k: (v.float() if torch.is_tensor(v) and v.dtype == torch.float16 else v) for k, v in data.items()}
+    ref = matcher_forward(rounded, model.state_dict(), {**model.config, "full_output": True})
+    model = model.to(gpu)
+    out = model({k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in data.items()})
+    _compare(out, ref, [(0, 1)])
+
+
+def test_config_full_output_is_honoured_after_construction(gpu):
+    from e2e_multi_view_matching_amd import MultiViewMatcher
+    from e2e_multi_view_matching_amd.synthetic import make_tuples
+    model = MultiViewMatcher({"GNN_layers": ["self"], "sinkhorn_iterations": 2}).to(gpu).train()
+    data = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in make_tuples(batch=1, n_kpts=64).items()}
+    model.config["full_output"] = False
+    assert set(model(data)) == {"scores_0_1"}
+    model.config["full_output"] = True  # helpers.py:245
+    assert "matches0_0_1" in model(data) and model(data)["conf_scores_0_1"].shape == (1, 64, 1)
