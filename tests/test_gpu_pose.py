@@ -43,7 +43,8 @@ def test_w8pt_vs_oracle(gpu, B, N, seed, closest):
     assert (info["inliers"].cpu() != i64["inliers"]).sum() <= 1 + 0.002 * B * N
     Fh = info["F"].cpu().double()
     F64 = i64["F"]
-    assert float((Fh - F64).abs().max() / F64.abs().max()) < 1e-5
+    # N == 8 selects the smallest NON-null singular vector (thin-SVD quirk): conditioned by sigma7/sigma8
+    assert float((Fh - F64).abs().max() / F64.abs().max()) < (1e-5 if N > 8 else 1e-4)
 
 
 def test_w8pt_fewer_than_8_points_is_none(gpu):
