@@ -19,6 +19,8 @@
 //  * register-staged double buffering (global_load_dwordx4 -> ds_write_b128), one barrier
 //    per K tile; 73.7 KB LDS -> 2 blocks/CU = 2 waves/SIMD to cover the barrier.
 //  * XCD-aware tile order: the N-tiles that share an A panel run on the same XCD (same L2).
+#include <algorithm>
+
 #include "common.h"
 
 namespace e2emv {
@@ -38,58 +40,59 @@ struct GemmParams {
     int64_t lda, lda2, ldw, ldr, ldc;
     int64_t sA, sA2, sW, sR, sC;
     int M, N, K, K1;
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n, total;  // total = batch * tiles_m * tiles_n
     float scale;
     int relu;
+    int vec_store;  // 1: N % 4 == 0 and C/R rows 16-byte aligned -> dwordx4 epilogue
 };
 
+// Persistent kernel: gridDim.x = 8 * slots workgroups (2 per CU); workgroup (xcd = id & 7,
+// slot = id >> 3) walks tiles xcd*per_xcd + slot, + slots, ... of its XCD's contiguous tile range,
+// so the tiles in flight on one XCD are neighbours (shared A panels stay in that L2).  The K
+// tiles of consecutive output tiles form ONE software-pipelined stream: the first K tile of
+// the next output tile is prefetched under the last MFMAs of the current one and the
+// epilogue's stores drain under the next tile's MFMAs - no lockstep load/store bursts.
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                   // [2][BM][LDK]
-    float* Bs = smem + 2 * BM * LDK;    // [2][BN][LDK]
+    float* As = smem;                   // [2][BM][LDK]  activations
+    float* Bs = smem + 2 * BM * LDK;    // [2][BN][LDK]  weights
 
-    // XCD-aware bijective remap of the linear block id -> tile id
-    const int total = p.tiles_m * p.tiles_n;
-    const int per_xcd = (total + 7) / 8;
-    const int lin = blockIdx.x;
-    const int tile = (lin % 8) * per_xcd + lin / 8;
-    if (tile >= total) return;
-    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
-    const int z = blockIdx.z;
-    const float* A = p.A + z * p.sA;
-    const float* A2 = p.A2 ? p.A2 + z * p.sA2 : nullptr;
-    const float* W = p.W + z * p.sW;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int per_xcd = (p.total + 7) / 8;
+    const int t_begin = xcd * per_xcd;
+    const int t_end = min(t_begin + per_xcd, p.total);
+    int tile = t_begin + slot;
+    if (tile >= t_end) return;
+    const int tiles_mn = p.tiles_m * p.tiles_n;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
-
-    // global->LDS staging map: 4 float4 per thread per operand
     const int ld_row = tid >> 3;        // 0..31 (+32*i)
     const int ld_c4 = (tid & 7) * 4;    // float offset inside the K tile
+    const int nk = p.K / BK;
+
+    // operand pointers of the tile whose K tiles are being PREFETCHED
     const float* a_ptr[4];
     const float* a2_ptr[4];
     const float* w_ptr[4];
+    auto setup = [&](int t) {
+        const int z = t / tiles_mn, r = t - z * tiles_mn;
+        const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
+        const float* A = p.A + z * p.sA;
+        const float* A2 = p.A2 ? p.A2 + z * p.sA2 : nullptr;
+        const float* W = p.W + z * p.sW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int ra = min(m0 + ld_row + 32 * i, p.M - 1);
-        int rw = min(n0 + ld_row + 32 * i, p.N - 1);
-        a_ptr[i] = A + (int64_t)ra * p.lda + ld_c4;
-        a2_ptr[i] = A2 ? A2 + (int64_t)ra * p.lda2 + ld_c4 : nullptr;
-        w_ptr[i] = W + (int64_t)rw * p.ldw + ld_c4;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int ra = min(tm * BM + ld_row + 32 * i, p.M - 1);
+            const int rw = min(tn * BN + ld_row + 32 * i, p.N - 1);
+            a_ptr[i] = A + (int64_t)ra * p.lda + ld_c4;
+            a2_ptr[i] = A2 ? A2 + (int64_t)ra * p.lda2 + ld_c4 : nullptr;
+            w_ptr[i] = W + (int64_t)rw * p.ldw + ld_c4;
+        }
+    };
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = p.K / BK;
     f32x4 ra[4], rb[4];
     auto gload = [&](int kt) {
         const int k = kt * BK;
@@ -108,54 +111,106 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
         }
     };
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const float* as = &As[(cur * BM + wr * 64 + l31) * LDK + lh * 4];
-        const float* bs = &Bs[(cur * BN + wc * 64 + l31) * LDK + lh * 4];
+    // acc[j][i]: weights tile j (MFMA A operand, rows -> registers) x activation tile i (B operand,
+    // rows -> lanes).  C/D layout: lane = activation row m, registers = 4-runs of output channels n.
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    };
+    auto compute = [&](int buf) {
+        const float* as = &As[(buf * BM + wr * 64 + l31) * LDK + lh * 4];
+        const float* bs = &Bs[(buf * BN + wc * 64 + l31) * LDK + lh * 4];
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
-            f32x4 a0 = *reinterpret_cast<const f32x4*>(as + c * 8);
-            f32x4 a1 = *reinterpret_cast<const f32x4*>(as + 32 * LDK + c * 8);
-            f32x4 b0 = *reinterpret_cast<const f32x4*>(bs + c * 8);
-            f32x4 b1 = *reinterpret_cast<const f32x4*>(bs + 32 * LDK + c * 8);
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(as + c * 8);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(as + 32 * LDK + c * 8);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(bs + c * 8);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(bs + 32 * LDK + c * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], x0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], x1[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], x0[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], x1[e], acc[1][1], 0, 0, 0);
             }
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
-        __syncthreads();
-    }
-
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* C = p.C + z * p.sC;
-    const float* R = p.R ? p.R + z * p.sR : nullptr;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wc * 64 + j * 32 + l31;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+    };
+    auto epilogue = [&](int t) {
+        const int z = t / tiles_mn, r = t - z * tiles_mn;
+        const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
+        float* C = p.C + z * p.sC;
+        const float* R = p.R ? p.R + z * p.sR : nullptr;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            const int m = tm * BM + wr * 64 + i * 32 + l31;
+            if (m >= p.M) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M) {
-                    float v = acc[i][j][r] * p.scale + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (R) v += R[(int64_t)m * p.ldr + n];
-                    C[(int64_t)m * p.ldc + n] = v;
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = tn * BN + wc * 64 + j * 32 + 8 * g + 4 * lh;
+                    if (n >= p.N) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e] * p.scale;
+                    if (p.vec_store) {
+                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        if (R) v += *reinterpret_cast<const f32x4*>(R + (int64_t)m * p.ldr + n);
+                        *reinterpret_cast<f32x4*>(C + (int64_t)m * p.ldc + n) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e < p.N) {
+                                float x = v[e] + (p.bias ? p.bias[n + e] : 0.f);
+                                if (p.relu) x = fmaxf(x, 0.f);
+                                if (R) x += R[(int64_t)m * p.ldr + n + e];
+                                C[(int64_t)m * p.ldc + n + e] = x;
+                            }
+                        }
+                    }
                 }
             }
         }
+    };
+
+    zero_acc();
+    setup(tile);
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (;;) {
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            gload(kt + 1);
+            compute(buf);
+            lstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // last K tile of this output tile: prefetch the next output tile's first K tile under it
+        const int next = tile + slots;
+        const bool more = next < t_end;
+        if (more) {
+            setup(next);
+            gload(0);
+        }
+        compute(buf);
+        epilogue(tile);
+        if (!more) break;
+        zero_acc();
+        lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        tile = next;
     }
 }
 
@@ -174,18 +229,21 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
     p.M = a.M; p.N = a.N; p.K = a.K; p.K1 = K1;
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + BN - 1) / BN;
+    p.total = p.tiles_m * p.tiles_n * a.batch;
     p.scale = a.scale;
     p.relu = a.relu ? 1 : 0;
-    const int total = p.tiles_m * p.tiles_n;
-    const int per_xcd = (total + 7) / 8;
+    p.vec_store = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((uintptr_t)a.C % 16 == 0) && (a.sC % 4 == 0) &&
+                  (!a.bias || (uintptr_t)a.bias % 16 == 0) &&
+                  (!a.R || ((a.ldr % 4 == 0) && ((uintptr_t)a.R % 16 == 0) && (a.sR % 4 == 0)));
+    const int per_xcd = (p.total + 7) / 8;
+    const int slots = std::min(per_xcd, std::max(1, ctx->num_cus * 2 / 8));
     const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK;
     static bool attr_set = false;
     if (!attr_set) {
         E2EMV_HIP(ctx, hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid(per_xcd * 8, 1, a.batch);
-    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3(8 * slots), dim3(256), lds, s, p);
     E2EMV_CHECK_LAUNCH(ctx, "gemm_nt_kernel");
     return E2EMV_OK;
 }

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of the building-block kernels through the C ABI (HIP events via torch)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import e2e_multi_view_matching_amd as E  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="gemm,attn,sinkhorn")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    if "gemm" in args.what:
+        print("== gemm_nt  (M, N, K) -> us, TFLOP/s")
+        for (M, N, K) in [(65536, 256, 256), (65536, 256, 512), (65536, 256, 1024), (65536, 256, 2048), (65536, 512, 512),
+                          (65536, 768, 256), (65536, 256, 128), (32768, 256, 256), (131072, 256, 256), (65536, 128, 256)]:
+            A = torch.randn(M, K, device=dev)
+            W = torch.randn(N, K, device=dev)
+            b = torch.randn(N, device=dev)
+            C = torch.empty(M, N, device=dev)
+            from e2e_multi_view_matching_amd import _lib
+            ctx = _lib.context(dev)
+
+            def run():
+                ctx.call("e2emv_gemm_nt", 1, M, N, K, K, _lib.ptr(A), K, 0, None, 0, 0, _lib.ptr(W), K, 0, _lib.ptr(b), None, 0, 0,
+                         _lib.ptr(C), N, 0, 1.0, 0, _lib.stream_ptr(dev))
+            ms = timeit(run)
+            print(f"  {M:7d} {N:5d} {K:5d}  {ms * 1e3:9.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF")
+    if "attn" in args.what:
+        print("== attention (B pairs, N) -> us, TFLOP/s")
+        for (B, N) in [(32, 1024), (8, 1024), (32, 512), (8, 2048)]:
+            qkv = torch.randn(B * 2, N, 768, device=dev)
+            for cross in (0, 1):
+                ms = timeit(lambda: E.attention(qkv, B, 2, N, 4, cross), iters=10)
+                fl = B * 2 * 4.0 * N * N * 256
+                print(f"  B={B:3d} N={N:5d} cross={cross}  {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.1f} TF")
+    if "sinkhorn" in args.what:
+        print("== sinkhorn 100 iters (B, N) -> ms, algorithmic GB/s")
+        for (B, N) in [(32, 1024), (8, 1024), (8, 2048), (64, 512)]:
+            s = torch.randn(B, N, N, device=dev)
+            ms = timeit(lambda: E.log_optimal_transport(s, 1.0, 100), iters=5, warm=1)
+            by = B * 202 * (N + 1) ** 2 * 4
+            print(f"  B={B:3d} N={N:5d}  {ms:8.3f} ms  {by / ms / 1e6:8.1f} GB/s")
+
+
+if __name__ == "__main__":
+    main()
