@@ -19,6 +19,7 @@
 // The final sweep writes logZ = couplings + u + v + log(M+N) densely ([M+1][N+1], the API
 // layout) and fuses the row/column arg-max needed by the match block, so Z is never re-read.
 #include <cmath>
+#include <utility>
 
 #include "common.h"
 
@@ -71,7 +72,9 @@ struct SkParams {
     int64_t ldV;
     float* pm;          // [B][chunks][ldS] partial column max
     float* ps;          // [B][chunks][ldS] partial column sum-exp
-    float* uM;          // [B] dustbin-row potential of the running iteration
+    float* v_next;      // [B][ldV]  written by sinkhorn_combine (ping-pong with v)
+    float* upm;         // [B][chunks] partial max of u over a chunk's rows
+    float* ups;         // [B][chunks] partial sum-exp of u over a chunk's rows
     // final sweep
     float* logZ;        // [B][M+1][N+1] or null
     float* max0;        // [B][M] row max of the core (value of logZ)
@@ -153,6 +156,10 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep(SkParams p) {
     float* lm = lds + (wave * 2 + 0) * (KT * 256);
     float* ls = lds + (wave * 2 + 1) * (KT * 256);
     if (!FINAL) {
+        // (max, sum-exp) of this wave's u values: feeds the dustbin column v_N in sinkhorn_combine
+        const float uwm = fmaxf(fmaxf(ur[0], ur[1]), fmaxf(ur[2], ur[3]));
+        const float uwm_s = (uwm == -INFINITY) ? 0.f : uwm;
+        const float uws = __expf(ur[0] - uwm_s) + __expf(ur[1] - uwm_s) + __expf(ur[2] - uwm_s) + __expf(ur[3] - uwm_s);
         // column partials over this wave's 4 rows: (max, sum exp) of S_ij + u_i
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
@@ -189,6 +196,16 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep(SkParams p) {
             const int64_t o = ((int64_t)b * p.chunks + chunk) * p.ldS + c;
             *reinterpret_cast<f32x4*>(p.pm + o) = M4;
             *reinterpret_cast<f32x4*>(p.ps + o) = S4;
+        }
+        __syncthreads();  // the fold is done with the LDS image: reuse its head for the u partials
+        if (lane == 0) { lds[wave] = uwm; lds[4 + wave] = uws; }
+        __syncthreads();
+        if (tid == 0) {
+            const float M4 = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
+            float S4 = 0.f;
+            for (int w = 0; w < 4; ++w) S4 += lds[4 + w] * __expf(lds[w] - M4);
+            p.upm[(int64_t)b * p.chunks + chunk] = M4;
+            p.ups[(int64_t)b * p.chunks + chunk] = S4;
         }
     } else {
         // final: write logZ rows, row arg-max (first max wins), column partial arg-max
@@ -257,59 +274,54 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep(SkParams p) {
     }
 }
 
-// One workgroup per pair: fold column partials -> v, dustbin column v_N and next u_M.
+// Fold the column partials into v.  grid (ceil(ldV/256), B), one column per thread, so the M/16
+// partial rows are read as coalesced 1-KiB wave loads.  Every workgroup first recomputes the
+// dustbin-ROW potential u_M of this iteration from the previous v (N+1 values, L2-resident);
+// workgroup x == 0 also produces the dustbin-COLUMN potential v_N from the u partials.
+// v is double-buffered (reads p.v, writes p.v_next) because workgroups of one launch overlap.
 __global__ __launch_bounds__(256) void sinkhorn_combine(SkParams p) {
     __shared__ float red[8];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    float* ub = p.u + (int64_t)b * (p.M + 1);
-    float* vb = p.v + (int64_t)b * p.ldV;
-    const float uM = p.uM[b];
-    if (tid == 0) ub[p.M] = uM;  // dustbin-row potential of THIS iteration (read by the final sweep)
-    const float lognu = p.norm;  // log_nu_j for j < N
-    float vmax = -INFINITY;
-    // v_j = log_nu - LSE_i(S_ij + u_i  U  alpha + u_M)
-    for (int c = tid * 4; c < p.ldS; c += 1024) {
-        f32x4 Mx, Sx;
-        const float yb = p.alpha + uM;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { Mx[e] = yb; Sx[e] = 1.f; }
-        const int64_t o0 = (int64_t)b * p.chunks * p.ldS + c;
-#pragma unroll 4
-        for (int ch = 0; ch < p.chunks; ++ch) {
-            f32x4 m = *reinterpret_cast<const f32x4*>(p.pm + o0 + (int64_t)ch * p.ldS);
-            f32x4 s = *reinterpret_cast<const f32x4*>(p.ps + o0 + (int64_t)ch * p.ldS);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float nm = fmaxf(Mx[e], m[e]);
-                Sx[e] = Sx[e] * __expf(Mx[e] - nm) + s[e] * __expf(m[e] - nm);
-                Mx[e] = nm;
-            }
-        }
-        f32x4 vo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            vo[e] = lognu - (Mx[e] + __logf(Sx[e]));
-            if (c + e < p.N) vmax = fmaxf(vmax, vo[e]); else vo[e] = 0.f;
-        }
-        *reinterpret_cast<f32x4*>(vb + c) = vo;
-    }
-    // v_N = log_nu_N - (alpha + LSE(u_0..u_M)),  log_nu_N = log M + norm
-    float um = (tid == 0) ? uM : -INFINITY;
-    for (int i = tid; i < p.M; i += 256) um = fmaxf(um, ub[i]);
-    um = block_max(um, red);
-    float us = (tid == 0) ? __expf(uM - um) : 0.f;
-    for (int i = tid; i < p.M; i += 256) us += __expf(ub[i] - um);
-    us = block_sum(us, red);
-    const float vN = (__logf((float)p.M) + p.norm) - (p.alpha + um + __logf(us));
-    // u_M(next) = log_mu_M - (alpha + LSE(v_0..v_N)),  log_mu_M = log N + norm
-    vmax = fmaxf(block_max(vmax, red), vN);
-    __syncthreads();  // v writes of this block visible to its own re-read below
-    float vs = (tid == 0) ? __expf(vN - vmax) : 0.f;
-    for (int j = tid; j < p.N; j += 256) vs += __expf(vb[j] - vmax);
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float* vprev = p.v + (int64_t)b * p.ldV;
+    float* vb = p.v_next + (int64_t)b * p.ldV;
+    // u_M = log_mu_M - (alpha + LSE(v_0..v_N)),  log_mu_M = log N + norm
+    float vm = -INFINITY;
+    for (int j = tid; j <= p.N; j += 256) vm = fmaxf(vm, vprev[j]);
+    vm = block_max(vm, red);
+    float vs = 0.f;
+    for (int j = tid; j <= p.N; j += 256) vs += __expf(vprev[j] - vm);
     vs = block_sum(vs, red);
-    if (tid == 0) {
-        vb[p.N] = vN;
-        p.uM[b] = (__logf((float)p.N) + p.norm) - (p.alpha + vmax + __logf(vs));
+    const float uM = (__logf((float)p.N) + p.norm) - (p.alpha + vm + __logf(vs));
+    // v_j = log_nu - LSE_i(S_ij + u_i  U  alpha + u_M)
+    const int j = blockIdx.x * 256 + tid;
+    if (j < p.N) {
+        float Mx = p.alpha + uM, Sx = 1.f;
+        const float* pm = p.pm + (int64_t)b * p.chunks * p.ldS + j;
+        const float* ps = p.ps + (int64_t)b * p.chunks * p.ldS + j;
+#pragma unroll 8
+        for (int ch = 0; ch < p.chunks; ++ch) {
+            const float m = pm[(int64_t)ch * p.ldS], s = ps[(int64_t)ch * p.ldS];
+            const float nm = fmaxf(Mx, m);
+            Sx = Sx * __expf(Mx - nm) + s * __expf(m - nm);
+            Mx = nm;
+        }
+        vb[j] = p.norm - (Mx + __logf(Sx));
+    } else if (j > p.N && j < p.ldV) {
+        vb[j] = 0.f;
+    }
+    if (blockIdx.x == 0) {
+        // v_N = log_nu_N - (alpha + LSE(u_0..u_M)),  log_nu_N = log M + norm
+        float um = (tid == 0) ? uM : -INFINITY;
+        for (int c = tid; c < p.chunks; c += 256) um = fmaxf(um, p.upm[(int64_t)b * p.chunks + c]);
+        um = block_max(um, red);
+        float us = (tid == 0) ? __expf(uM - um) : 0.f;
+        for (int c = tid; c < p.chunks; c += 256)
+            us += p.ups[(int64_t)b * p.chunks + c] * __expf(p.upm[(int64_t)b * p.chunks + c] - um);
+        us = block_sum(us, red);
+        if (tid == 0) {
+            vb[p.N] = (__logf((float)p.M) + p.norm) - (p.alpha + um + __logf(us));
+            p.u[(int64_t)b * (p.M + 1) + p.M] = uM;  // read by the final sweep
+        }
     }
 }
 
@@ -317,8 +329,6 @@ __global__ void sinkhorn_init(SkParams p, int B) {
     const int b = blockIdx.x;
     float* vb = p.v + (int64_t)b * p.ldV;
     for (int j = threadIdx.x; j < p.ldV; j += blockDim.x) vb[j] = 0.f;
-    if (threadIdx.x == 0)  // u_M of iteration 1: v = 0 -> LSE over N+1 equal entries alpha
-        p.uM[b] = (__logf((float)p.N) + p.norm) - (p.alpha + __logf((float)(p.N + 1)));
 }
 
 // degenerate iters == 0: u = 0 (the reference returns couplings + 0 + 0 - norm)
@@ -432,9 +442,9 @@ size_t sinkhorn_ws_bytes(int B, int M, int N) {
     size_t f = 0;
     auto al = [](size_t n) { return (n * 4 + 255) & ~size_t(255); };
     f += al((size_t)B * (M + 1));                 // u
-    f += al((size_t)B * (ldS + 4));               // v
+    f += 2 * al((size_t)B * (ldS + 4));           // v ping-pong
     f += 2 * al((size_t)B * chunks * ldS);        // pm / ps (re-used as pv / pi)
-    f += al(B);                                   // uM
+    f += 2 * al((size_t)B * chunks);              // upm / ups
     f += 2 * al((size_t)B * M);                   // max0, idx0
     return f;
 }
@@ -463,34 +473,37 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
     char* w = ws;
     p.u = (float*)w; w += al((size_t)B * (M + 1));
     p.ldV = ldS + 4;
-    p.v = (float*)w; w += al((size_t)B * p.ldV);
+    float* v0 = (float*)w; w += al((size_t)B * p.ldV);
+    float* v1 = (float*)w; w += al((size_t)B * p.ldV);
     p.pm = (float*)w; w += al((size_t)B * p.chunks * ldS);
     p.ps = (float*)w; w += al((size_t)B * p.chunks * ldS);
-    p.uM = (float*)w; w += al(B);
+    p.upm = (float*)w; w += al((size_t)B * p.chunks);
+    p.ups = (float*)w; w += al((size_t)B * p.chunks);
     p.max0 = (float*)w; w += al((size_t)B * M);
     p.idx0 = (int*)w; w += al((size_t)B * M);
     p.pv = p.pm;
     p.pi = (int*)p.ps;
     p.logZ = out.logZ;
+    p.v = v0;
+    p.v_next = v1;
     const int KT = (int)((ldS + 255) / 256);
+    auto sweep = [&](bool final) {
+        switch (KT) {
+            case 1: launch_sweeps<1>(p, B, final, s); break;
+            case 2: launch_sweeps<2>(p, B, final, s); break;
+            case 3: case 4: launch_sweeps<4>(p, B, final, s); break;
+            default: launch_sweeps<8>(p, B, final, s); break;
+        }
+    };
 
     hipLaunchKernelGGL(sinkhorn_init, dim3(B), dim3(256), 0, s, p, B);
     if (iters <= 0) hipLaunchKernelGGL(sinkhorn_zero_u, dim3(B), dim3(256), 0, s, p);
     for (int it = 0; it < iters; ++it) {
-        switch (KT) {
-            case 1: launch_sweeps<1>(p, B, false, s); break;
-            case 2: launch_sweeps<2>(p, B, false, s); break;
-            case 3: case 4: launch_sweeps<4>(p, B, false, s); break;
-            default: launch_sweeps<8>(p, B, false, s); break;
-        }
-        hipLaunchKernelGGL(sinkhorn_combine, dim3(B), dim3(256), 0, s, p);
+        sweep(false);
+        hipLaunchKernelGGL(sinkhorn_combine, dim3((unsigned)((p.ldV + 255) / 256), B), dim3(256), 0, s, p);
+        std::swap(p.v, p.v_next);
     }
-    switch (KT) {
-        case 1: launch_sweeps<1>(p, B, true, s); break;
-        case 2: launch_sweeps<2>(p, B, true, s); break;
-        case 3: case 4: launch_sweeps<4>(p, B, true, s); break;
-        default: launch_sweeps<8>(p, B, true, s); break;
-    }
+    sweep(true);
     E2EMV_CHECK_LAUNCH(ctx, "sinkhorn kernels");
     if (out.m0 || out.m1 || out.ms0 || out.ms1) {
         MatchParams mp{};
