@@ -62,6 +62,7 @@ struct e2emv_ctx {
     std::map<std::string, e2emv::HostTensor> raw;
     // committed model
     bool committed = false;
+    bool fuse_merge = true;  // fold attn.merge into MLP0 at commit time (E2EMV_NO_FUSE_MERGE=1 disables)
     e2emv_model_desc model{};
     float* d_warena = nullptr;
     size_t warena_floats = 0;

@@ -1,6 +1,7 @@
 // Context lifecycle, memory helpers, weight ingestion (BN folding + head-major re-ordering),
 // workspace arena and the HIP-event profiling hooks of libe2emv.so.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -90,6 +91,7 @@ int e2emv_create(e2emv_ctx** out, int device) {
     if (!ctx) return E2EMV_ENOMEM;
     ctx->device = device;
     ctx->num_cus = p.multiProcessorCount;
+    if (const char* e = getenv("E2EMV_NO_FUSE_MERGE")) ctx->fuse_merge = !(e[0] == '1');
     *out = ctx;
     return E2EMV_OK;
 }
@@ -271,6 +273,27 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         loff[l].bm = pk.add(b);
         if ((rc = get_conv(ctx, base + ".mlp.0", 2 * D, 2 * D, w, b))) return rc;
         if ((rc = fold_bn(ctx, base + ".mlp.1", 2 * D, 2 * D, w, b))) return rc;
+        if (ctx->fuse_merge) {
+            // MLP0([x | merge(o)]) = W0x x + (W0m Wmerge) o + (b0 + W0m bmerge): the merge conv is
+            // linear and feeds nothing else, so it is folded into MLP0's second K segment (fp64 on
+            // the host).  Saves one GEMM (2 N D^2 flops) and one activation round trip per layer.
+            std::vector<double> acc((size_t)2 * D * D, 0.0);
+            const float* bmerge = &pk.host[loff[l].bm];
+            for (int o = 0; o < 2 * D; ++o) {
+                const float* w0m = &w[(size_t)o * 2 * D + D];
+                double* ao = &acc[(size_t)o * D];
+                double bb = b[o];
+                for (int k = 0; k < D; ++k) {
+                    const double wk = w0m[k];
+                    const float* wr = &wm[(size_t)k * D];
+                    for (int c = 0; c < D; ++c) ao[c] += wk * (double)wr[c];
+                    bb += wk * (double)bmerge[k];
+                }
+                b[o] = (float)bb;
+            }
+            for (int o = 0; o < 2 * D; ++o)
+                for (int c = 0; c < D; ++c) w[(size_t)o * 2 * D + D + c] = (float)acc[(size_t)o * D + c];
+        }
         loff[l].w0 = pk.add(w);
         loff[l].b0 = pk.add(b);
         if ((rc = get_conv(ctx, base + ".mlp.3", D, 2 * D, w, b))) return rc;

@@ -220,15 +220,19 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         rc = launch_attention(ctx, B, T, n_rows, N, D, H, qkv, L.type, att, s);
         prof_end(ctx, s);
         if (rc) return rc;
-        // message = merge(attention)
-        g = GemmArgs();
-        g.M = (int)Mtot; g.N = D; g.K = D; g.K1 = D; g.A = att; g.lda = D; g.W = L.w_merge; g.ldw = D; g.bias = L.b_merge;
-        g.C = msg; g.ldc = D;
-        prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
-        if (rc) return rc;
+        const float* second = att;  // MLP0's second K segment: attention output (merge folded into W0)
+        if (!ctx->fuse_merge) {
+            // message = merge(attention)
+            g = GemmArgs();
+            g.M = (int)Mtot; g.N = D; g.K = D; g.K1 = D; g.A = att; g.lda = D; g.W = L.w_merge; g.ldw = D; g.bias = L.b_merge;
+            g.C = msg; g.ldc = D;
+            prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
+            if (rc) return rc;
+            second = msg;
+        }
         // hidden = relu(BN(W0 [x | message] + b0))   (concat never materialised: two K segments)
         g = GemmArgs();
-        g.M = (int)Mtot; g.N = 2 * D; g.K = 2 * D; g.K1 = D; g.A = x; g.lda = D; g.A2 = msg; g.lda2 = D;
+        g.M = (int)Mtot; g.N = 2 * D; g.K = 2 * D; g.K1 = D; g.A = x; g.lda = D; g.A2 = second; g.lda2 = D;
         g.W = L.w_mlp0; g.ldw = 2 * D; g.bias = L.b_mlp0; g.relu = true; g.C = hid; g.ldc = 2 * D;
         prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
         if (rc) return rc;
