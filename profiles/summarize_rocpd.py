@@ -11,7 +11,7 @@ def main(db_path, out_path=None):
     lines = ["| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
     for name, calls, tot, avg, pct in rows:
         short = name.split("(")[0][-70:]
-        lines.append(f"| {short} | {calls} | {tot / 1e6:.3f} | {avg / 1e3:.2f} | {pct:.2f} |")
+        lines.append(f"| {short} | {calls} | {tot / 1e3:.3f} | {avg:.2f} | {pct:.2f} |")  # rocpd view units: microseconds
     text = "\n".join(lines)
     if out_path:
         with open(out_path, "a") as fh:
