@@ -18,6 +18,8 @@
 // MFMAs through the same K-slot permutation as gemm.hip); V tiles unpadded (ds_read_b32 of
 // 32 consecutive floats).  128 MFMAs (8192 cycles) per wave per 64-key tile against ~1.3k
 // VALU cycles of softmax: the kernel is MFMA-issue bound by construction.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace e2emv {
@@ -37,7 +39,8 @@ struct AttnParams {
     int nq, groups, gper;
 };
 
-__global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
+template <int DBG>
+__global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) float Ks[ATT_KV * KLD];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_KV * HD];
 
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
 
     gload(0);
     for (int tile = 0; tile < n_tiles; ++tile) {
+        if (!(DBG & 4) || tile == 0) {
         __syncthreads();  // everyone is done reading the previous tile
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -107,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
         }
         __syncthreads();
         if (tile + 1 < n_tiles) gload(tile + 1);
+        }
 
         const int kt = tile % tiles_per_img;
         const int valid_in_tile = p.n_valid - kt * ATT_KV;  // >= 1
@@ -139,13 +144,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnParams p) {
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                S[r] = __builtin_amdgcn_exp2f(S[r] - m_new);
+                if (!(DBG & 1)) S[r] = __builtin_amdgcn_exp2f(S[r] - m_new);
                 ps += S[r];
             }
             l_run = l_run * alpha + ps;
             m_run = m_new;
+            if (!(DBG & 2)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { O0[r] *= alpha; O1[r] *= alpha; }
+                for (int r = 0; r < 16; ++r) { O0[r] *= alpha; O1[r] *= alpha; }
+            }
             // O^T[d][q] += V^T[d][key] P^T[key][q]
             const float* vp = &Vs[(sub * 32 + 4 * lh) * HD + l31];
 #pragma unroll
@@ -185,7 +192,16 @@ int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int 
     p.groups = B * T * H;
     p.gper = (p.groups + 7) / 8;
     dim3 grid(8 * p.gper * p.nq);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, s, p);
+    static int dbg = -1;  // E2EMV_ATTN_DEBUG: ablation variants for profiling only (results are wrong when != 0)
+    if (dbg < 0) { const char* e = getenv("E2EMV_ATTN_DEBUG"); dbg = e ? atoi(e) : 0; }
+    switch (dbg) {
+        case 1: hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL(attention_kernel<3>, grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, s, p); break;
+        case 7: hipLaunchKernelGGL(attention_kernel<7>, grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(256), 0, s, p); break;
+    }
     E2EMV_CHECK_LAUNCH(ctx, "attention_kernel");
     return E2EMV_OK;
 }

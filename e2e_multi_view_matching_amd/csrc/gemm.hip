@@ -14,11 +14,18 @@
 //  * LDS rows padded to 36 floats: the ds_read_b128 operand fetch (lane = row, 16 B of K) is
 //    bank-conflict free (16 rows x 16 B cover the 64 banks: 36*i mod 64 distinct for 16 i).
 //  * K-slot permutation: one ds_read_b128 feeds FOUR MFMAs - lanes 0-31 hold k = 8c+e,
-//    lanes 32-63 hold k = 8c+4+e for MFMA e; A and B use the same map, the sum over k is
+//    lanes 32-63 hold k = 8c+4+e for MFMA e; both operands use the same map, the sum over k is
 //    unchanged.  4 x b128 reads per 16 MFMAs -> LDS is idle, the kernel is MFMA-issue bound.
-//  * register-staged double buffering (global_load_dwordx4 -> ds_write_b128), one barrier
-//    per K tile; 73.7 KB LDS -> 2 blocks/CU = 2 waves/SIMD to cover the barrier.
-//  * XCD-aware tile order: the N-tiles that share an A panel run on the same XCD (same L2).
+//  * transposed accumulators: weights are the MFMA A operand, activations the B operand, so a
+//    lane owns ONE output row and its registers hold runs of 4 consecutive output channels:
+//    bias / residual / store are 16-byte accesses (4x fewer epilogue instructions).
+//  * persistent: 3 workgroups per CU (single 36.9 KB LDS buffer, register prefetch, two
+//    barriers per K tile, 3 waves per SIMD); a workgroup walks a strided list of output tiles
+//    and the K tiles of consecutive output tiles form ONE pipelined stream (the next tile's
+//    first loads are issued under the last MFMAs, the epilogue stores drain under the next
+//    tile) - removes the lockstep load/store bursts of one-tile-per-workgroup launches.
+//  * XCD-aware tile ranges: the tiles in flight on one XCD are neighbours (shared A panels
+//    stay in that XCD's L2).
 #include <algorithm>
 
 #include "common.h"
@@ -52,10 +59,10 @@ struct GemmParams {
 // tiles of consecutive output tiles form ONE software-pipelined stream: the first K tile of
 // the next output tile is prefetched under the last MFMAs of the current one and the
 // epilogue's stores drain under the next tile's MFMAs - no lockstep load/store bursts.
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                   // [2][BM][LDK]  activations
-    float* Bs = smem + 2 * BM * LDK;    // [2][BN][LDK]  weights
+    float* As = smem;               // [BM][LDK]  activations
+    float* Bs = smem + BM * LDK;    // [BN][LDK]  weights
 
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int per_xcd = (p.total + 7) / 8;
@@ -182,34 +189,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
         }
     };
 
+    // Single LDS buffer, register prefetch, two barriers per K tile; 36.9 KB of LDS lets 3 workgroups
+    // share a CU (3 waves per SIMD): while one wave sits at a barrier or in its epilogue the other two
+    // keep the SIMD's MFMA pipe busy (2 waves/SIMD measured 81 % MFMA-busy in the main loop).
     zero_acc();
     setup(tile);
     gload(0);
-    lstore(0);
-    __syncthreads();
-    int buf = 0;
     for (;;) {
         for (int kt = 0; kt + 1 < nk; ++kt) {
-            gload(kt + 1);
-            compute(buf);
-            lstore(buf ^ 1);
+            __syncthreads();  // previous K tile fully consumed
+            lstore(0);
             __syncthreads();
-            buf ^= 1;
+            gload(kt + 1);
+            // NB: hipcc sinks these global loads below the MFMA block (it re-uses their registers for
+            // the LDS fragments).  Pinning them above with sched_barrier(0) was measured 8-13 % SLOWER
+            // (K=2048: 563 -> 645 us): with 3 waves/SIMD the latency is covered by the other waves and
+            // the early loads only lengthen the live ranges.  Left to the compiler on purpose.
+            compute(0);
         }
         // last K tile of this output tile: prefetch the next output tile's first K tile under it
         const int next = tile + slots;
         const bool more = next < t_end;
+        __syncthreads();
+        lstore(0);
+        __syncthreads();
         if (more) {
             setup(next);
             gload(0);
         }
-        compute(buf);
+        compute(0);
         epilogue(tile);
         if (!more) break;
         zero_acc();
-        lstore(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
         tile = next;
     }
 }
@@ -236,13 +247,8 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
                   (!a.bias || (uintptr_t)a.bias % 16 == 0) &&
                   (!a.R || ((a.ldr % 4 == 0) && ((uintptr_t)a.R % 16 == 0) && (a.sR % 4 == 0)));
     const int per_xcd = (p.total + 7) / 8;
-    const int slots = std::min(per_xcd, std::max(1, ctx->num_cus * 2 / 8));
-    const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        E2EMV_HIP(ctx, hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    const int slots = std::min(per_xcd, std::max(1, ctx->num_cus * 3 / 8));
+    const size_t lds = sizeof(float) * (BM + BN) * LDK;
     hipLaunchKernelGGL(gemm_nt_kernel, dim3(8 * slots), dim3(256), lds, s, p);
     E2EMV_CHECK_LAUNCH(ctx, "gemm_nt_kernel");
     return E2EMV_OK;
