@@ -152,14 +152,18 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s);
 int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* qkv,
                      int cross, float* out, hipStream_t s);
 
-// Sinkhorn on an internal score buffer S [B][M][ldS] (ldS % 4 == 0); writes logZ dense
-// [B][M+1][N+1] (optional) and, when wanted, the match outputs.
+// Sinkhorn on an internal score buffer S [n_groups * group_batch][M][ldS] (ldS % 4 == 0).  Batch
+// element bb belongs to output group bb / group_batch (= the image pair of a tuple): each group
+// has its own dense logZ [group_batch][M+1][N+1] (optional) and match outputs.
+constexpr int kMaxGroups = E2EMV_MAX_TUPLE * (E2EMV_MAX_TUPLE - 1) / 2;
 struct SinkhornOut {
-    float* logZ = nullptr;
-    int64_t* m0 = nullptr;
-    int64_t* m1 = nullptr;
-    float* ms0 = nullptr;
-    float* ms1 = nullptr;
+    int n_groups = 1;
+    int group_batch = 0;  // 0: = B (single group)
+    float* logZ[kMaxGroups] = {nullptr};
+    int64_t* m0[kMaxGroups] = {nullptr};
+    int64_t* m1[kMaxGroups] = {nullptr};
+    float* ms0[kMaxGroups] = {nullptr};
+    float* ms1[kMaxGroups] = {nullptr};
 };
 size_t sinkhorn_ws_bytes(int B, int M, int N);
 int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t ldS, float alpha, int iters,

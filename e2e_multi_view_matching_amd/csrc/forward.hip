@@ -139,9 +139,9 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
     // ---- workspace ----
     auto al = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
     const size_t sz_x = al((size_t)Mtot * D * 4), sz_qkv = al((size_t)Mtot * 3 * D * 4), sz_hid = al((size_t)Mtot * 2 * D * 4);
-    const size_t sz_S = al((size_t)B * N * ldS * 4);
-    const size_t sz_sk = sinkhorn_ws_bytes(B, N, N);
-    const size_t sz_match = full ? 2 * al((size_t)B * N * 8) + 2 * al((size_t)B * N * 4) : 0;
+    const size_t sz_S = al((size_t)P * B * N * ldS * 4);
+    const size_t sz_sk = sinkhorn_ws_bytes(P * B, N, N);
+    const size_t sz_match = full ? (size_t)P * (al((size_t)B * N * 8) + al((size_t)B * N * 4)) : 0;
     const size_t need = sz_x * 3 + sz_qkv + sz_hid + sz_S + sz_sk + sz_match + 4096;
     int rc = ws_reserve(ctx, need);
     if (rc) return rc;
@@ -153,13 +153,13 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
     float* hid = (float*)w; w += sz_hid;
     float* S = (float*)w; w += sz_S;
     char* skws = w; w += sz_sk;
-    int64_t* tmp_m0 = nullptr; int64_t* tmp_m1 = nullptr; float* tmp_ms0 = nullptr; float* tmp_ms1 = nullptr;
-    if (full) {
-        tmp_m0 = (int64_t*)w; w += al((size_t)B * N * 8);
-        tmp_m1 = (int64_t*)w; w += al((size_t)B * N * 8);
-        tmp_ms0 = (float*)w; w += al((size_t)B * N * 4);
-        tmp_ms1 = (float*)w; w += al((size_t)B * N * 4);
-    }
+    std::vector<int64_t*> tmp_m0(P, nullptr);
+    std::vector<float*> tmp_ms0(P, nullptr);
+    if (full)
+        for (int q = 0; q < P; ++q) {
+            tmp_m0[q] = (int64_t*)w; w += al((size_t)B * N * 8);
+            tmp_ms0[q] = (float*)w; w += al((size_t)B * N * 4);
+        }
 
     // ---- ingest ----
     const std::vector<int>& kd = ctx->kenc_dims;  // [3, c0, ..., D]
@@ -254,8 +254,12 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         if (rc) return rc;
     }
 
-    // ---- per pair: scores -> Sinkhorn -> matches -> confidence ----
+    // ---- all pairs: scores -> ONE Sinkhorn over P*B problems -> matches; then the conf head per pair ----
     const int64_t tuple_stride = (int64_t)T * n_rows * D;
+    SinkhornOut so;
+    so.n_groups = P;
+    so.group_batch = B;
+    std::vector<bool> want_conf(P, false);
     int pidx = 0;
     for (int j = 0; j < T; ++j)
         for (int i = 0; i < j; ++i, ++pidx) {
@@ -263,47 +267,49 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
             g.batch = B; g.M = N; g.N = N; g.K = D; g.K1 = D;
             g.A = mdesc + (int64_t)i * n_rows * D; g.lda = D; g.sA = tuple_stride;
             g.W = mdesc + (int64_t)j * n_rows * D; g.ldw = D; g.sW = tuple_stride;
-            g.C = S; g.ldc = ldS; g.sC = (int64_t)N * ldS;
+            g.C = S + (int64_t)pidx * B * N * ldS; g.ldc = ldS; g.sC = (int64_t)N * ldS;
             g.scale = 1.0f / sqrtf((float)D);
             prof_begin(ctx, PS_SCORE, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
             if (rc) return rc;
-            const bool want_conf = full && d_conf && d_conf[pidx];
-            SinkhornOut so;
-            so.logZ = d_logZ ? d_logZ[pidx] : nullptr;
+            want_conf[pidx] = full && d_conf && d_conf[pidx];
+            so.logZ[pidx] = d_logZ ? d_logZ[pidx] : nullptr;
             if (full) {
-                so.m0 = (d_m0 && d_m0[pidx]) ? d_m0[pidx] : (want_conf ? tmp_m0 : nullptr);
-                so.m1 = d_m1 ? d_m1[pidx] : nullptr;
-                so.ms0 = (d_ms0 && d_ms0[pidx]) ? d_ms0[pidx] : (want_conf ? tmp_ms0 : nullptr);
-                so.ms1 = d_ms1 ? d_ms1[pidx] : nullptr;
+                so.m0[pidx] = (d_m0 && d_m0[pidx]) ? d_m0[pidx] : (want_conf[pidx] ? tmp_m0[pidx] : nullptr);
+                so.m1[pidx] = d_m1 ? d_m1[pidx] : nullptr;
+                so.ms0[pidx] = (d_ms0 && d_ms0[pidx]) ? d_ms0[pidx] : (want_conf[pidx] ? tmp_ms0[pidx] : nullptr);
+                so.ms1[pidx] = d_ms1 ? d_ms1[pidx] : nullptr;
             }
-            prof_begin(ctx, PS_SINKHORN, s);
-            rc = launch_sinkhorn(ctx, B, N, N, S, ldS, ctx->bin_score, fd->sinkhorn_iters, fd->match_threshold, so, skws, s);
-            prof_end(ctx, s);
-            if (rc) return rc;
-            if (want_conf) {
-                const bool use_mlp = ctx->model.conf_mlp != 0;
-                float* gathered = msg;          // [B][n_rows][D]
-                float* chid = hid;              // [B][n_rows][D]
-                if (use_mlp) {
-                    prof_begin(ctx, PS_CONF, s);
-                    hipLaunchKernelGGL(conf_gather_kernel, dim3((n_rows + 3) / 4, B), dim3(256), 0, s, N, n_rows, D,
-                                       mdesc + (int64_t)j * n_rows * D, tuple_stride, so.m0, gathered);
-                    prof_end(ctx, s);
-                    GemmArgs c;
-                    c.batch = B; c.M = n_rows; c.N = D; c.K = 2 * D; c.K1 = D;
-                    c.A = mdesc + (int64_t)i * n_rows * D; c.lda = D; c.sA = tuple_stride;
-                    c.A2 = gathered; c.lda2 = D; c.sA2 = (int64_t)n_rows * D;
-                    c.W = ctx->w_conf0; c.ldw = 2 * D; c.bias = ctx->b_conf0; c.relu = true;
-                    c.C = chid; c.ldc = D; c.sC = (int64_t)n_rows * D;
-                    prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, c, s); prof_end(ctx, s);
-                    if (rc) return rc;
-                }
+        }
+    prof_begin(ctx, PS_SINKHORN, s);
+    rc = launch_sinkhorn(ctx, P * B, N, N, S, ldS, ctx->bin_score, fd->sinkhorn_iters, fd->match_threshold, so, skws, s);
+    prof_end(ctx, s);
+    if (rc) return rc;
+    pidx = 0;
+    for (int j = 0; j < T; ++j)
+        for (int i = 0; i < j; ++i, ++pidx) {
+            if (!want_conf[pidx]) continue;
+            const bool use_mlp = ctx->model.conf_mlp != 0;
+            float* gathered = msg;          // [B][n_rows][D]
+            float* chid = hid;              // [B][n_rows][D]
+            if (use_mlp) {
                 prof_begin(ctx, PS_CONF, s);
-                hipLaunchKernelGGL(conf_final_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, N, n_rows, D, chid, ctx->w_conf1,
-                                   ctx->b_conf1, so.m0, so.ms0, use_mlp ? 1 : 0, d_conf[pidx]);
+                hipLaunchKernelGGL(conf_gather_kernel, dim3((n_rows + 3) / 4, B), dim3(256), 0, s, N, n_rows, D,
+                                   mdesc + (int64_t)j * n_rows * D, tuple_stride, so.m0[pidx], gathered);
                 prof_end(ctx, s);
-                E2EMV_CHECK_LAUNCH(ctx, "conf kernels");
+                GemmArgs c;
+                c.batch = B; c.M = n_rows; c.N = D; c.K = 2 * D; c.K1 = D;
+                c.A = mdesc + (int64_t)i * n_rows * D; c.lda = D; c.sA = tuple_stride;
+                c.A2 = gathered; c.lda2 = D; c.sA2 = (int64_t)n_rows * D;
+                c.W = ctx->w_conf0; c.ldw = 2 * D; c.bias = ctx->b_conf0; c.relu = true;
+                c.C = chid; c.ldc = D; c.sC = (int64_t)n_rows * D;
+                prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, c, s); prof_end(ctx, s);
+                if (rc) return rc;
             }
+            prof_begin(ctx, PS_CONF, s);
+            hipLaunchKernelGGL(conf_final_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, N, n_rows, D, chid, ctx->w_conf1,
+                               ctx->b_conf1, so.m0[pidx], so.ms0[pidx], use_mlp ? 1 : 0, d_conf[pidx]);
+            prof_end(ctx, s);
+            E2EMV_CHECK_LAUNCH(ctx, "conf kernels");
         }
     return E2EMV_OK;
 }

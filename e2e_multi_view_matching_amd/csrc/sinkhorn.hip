@@ -76,7 +76,8 @@ struct SkParams {
     float* upm;         // [B][chunks] partial max of u over a chunk's rows
     float* ups;         // [B][chunks] partial sum-exp of u over a chunk's rows
     // final sweep
-    float* logZ;        // [B][M+1][N+1] or null
+    float* logZ[kMaxGroups];  // per output group: [group_batch][M+1][N+1] or null
+    int group_batch;    // batch elements per output group
     float* max0;        // [B][M] row max of the core (value of logZ)
     int* idx0;          // [B][M]
     float* pv;          // [B][chunks][ldS] partial column max value (final)
@@ -95,9 +96,10 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep(SkParams p) {
 
     if (FINAL && chunk == p.chunks) {
         // dustbin row of logZ: (alpha + u_M) + v_j + log(M+N)
-        if (p.logZ) {
+        float* const zbase = p.logZ[b / p.group_batch];
+        if (zbase) {
             const float uM = p.u[(int64_t)b * (p.M + 1) + p.M];
-            float* zr = p.logZ + ((int64_t)b * (p.M + 1) + p.M) * (p.N + 1);
+            float* zr = zbase + ((int64_t)(b % p.group_batch) * (p.M + 1) + p.M) * (p.N + 1);
             for (int j = tid; j <= p.N; j += 256) zr[j] = ((p.alpha + uM) + vb[j]) - p.norm;
         }
         return;
@@ -210,6 +212,8 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep(SkParams p) {
     } else {
         // final: write logZ rows, row arg-max (first max wins), column partial arg-max
         int* li = reinterpret_cast<int*>(ls);
+        float* const zbase = p.logZ[b / p.group_batch];
+        const int bl = b % p.group_batch;
         float cm[KT][4];
         int ci[KT][4];
 #pragma unroll
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep(SkParams p) {
             const bool rvalid = row < p.M;  // wave-uniform
             float best = -INFINITY;
             int bj = 0x7fffffff;
-            float* zr = p.logZ ? p.logZ + ((int64_t)b * (p.M + 1) + row) * (p.N + 1) : nullptr;
+            float* zr = zbase ? zbase + ((int64_t)bl * (p.M + 1) + row) * (p.N + 1) : nullptr;
 #pragma unroll
             for (int k = 0; k < KT; ++k)
 #pragma unroll
@@ -347,10 +351,11 @@ struct MatchParams {
     const int* pi;
     const int* idx1_in;  // [B][N] when the column arg-max is already final (dense path), else null
     float thr;
-    int64_t* m0;
-    int64_t* m1;
-    float* ms0;
-    float* ms1;
+    int group_batch;
+    int64_t* m0[kMaxGroups];
+    int64_t* m1[kMaxGroups];
+    float* ms0[kMaxGroups];
+    float* ms1[kMaxGroups];
 };
 
 // Mutual check (match block of SuperGlue.forward).  One workgroup per pair, indices in LDS.
@@ -360,6 +365,11 @@ __global__ __launch_bounds__(256) void match_finalize(MatchParams p) {
     int* i1 = sidx + p.M;
     int* v0 = sidx + p.M + p.N;
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int grp = b / p.group_batch, bl = b % p.group_batch;
+    int64_t* const om0 = p.m0[grp];
+    int64_t* const om1 = p.m1[grp];
+    float* const oms0 = p.ms0[grp];
+    float* const oms1 = p.ms1[grp];
     for (int i = tid; i < p.M; i += 256) i0[i] = p.idx0[(int64_t)b * p.M + i];
     for (int j = tid; j < p.N; j += 256) {
         if (p.idx1_in) {
@@ -382,8 +392,8 @@ __global__ __launch_bounds__(256) void match_finalize(MatchParams p) {
         const float sc = mutual ? __expf(p.max0[(int64_t)b * p.M + i]) : 0.f;
         const bool valid = mutual && sc > p.thr;
         v0[i] = valid;
-        if (p.ms0) p.ms0[(int64_t)b * p.M + i] = sc;
-        if (p.m0) p.m0[(int64_t)b * p.M + i] = valid ? (int64_t)j : (int64_t)-1;
+        if (oms0) oms0[(int64_t)bl * p.M + i] = sc;
+        if (om0) om0[(int64_t)bl * p.M + i] = valid ? (int64_t)j : (int64_t)-1;
     }
     __syncthreads();
     for (int j = tid; j < p.N; j += 256) {
@@ -392,8 +402,8 @@ __global__ __launch_bounds__(256) void match_finalize(MatchParams p) {
         // mscores1 = where(mutual1, mscores0.gather(idx1), 0): mscores0[i] is exp(max0[i]) iff i is mutual
         const bool mut_i = i1[i0[i]] == i;
         const float sc = (mutual && mut_i) ? __expf(p.max0[(int64_t)b * p.M + i]) : 0.f;
-        if (p.ms1) p.ms1[(int64_t)b * p.N + j] = sc;
-        if (p.m1) p.m1[(int64_t)b * p.N + j] = (mutual && v0[i]) ? (int64_t)i : (int64_t)-1;
+        if (oms1) oms1[(int64_t)bl * p.N + j] = sc;
+        if (om1) om1[(int64_t)bl * p.N + j] = (mutual && v0[i]) ? (int64_t)i : (int64_t)-1;
     }
 }
 
@@ -483,7 +493,15 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
     p.idx0 = (int*)w; w += al((size_t)B * M);
     p.pv = p.pm;
     p.pi = (int*)p.ps;
-    p.logZ = out.logZ;
+    const int gb = out.group_batch > 0 ? out.group_batch : B;
+    if (out.n_groups < 1 || out.n_groups > kMaxGroups || gb * out.n_groups != B)
+        return set_err(ctx, E2EMV_EINVAL, "sinkhorn: %d groups x %d != batch %d", out.n_groups, gb, B);
+    p.group_batch = gb;
+    bool want_match = false;
+    for (int g = 0; g < kMaxGroups; ++g) {
+        p.logZ[g] = g < out.n_groups ? out.logZ[g] : nullptr;
+        if (g < out.n_groups && (out.m0[g] || out.m1[g] || out.ms0[g] || out.ms1[g])) want_match = true;
+    }
     p.v = v0;
     p.v_next = v1;
     const int KT = (int)((ldS + 255) / 256);
@@ -505,12 +523,15 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
     }
     sweep(true);
     E2EMV_CHECK_LAUNCH(ctx, "sinkhorn kernels");
-    if (out.m0 || out.m1 || out.ms0 || out.ms1) {
+    if (want_match) {
         MatchParams mp{};
         mp.M = M; mp.N = N; mp.chunks = p.chunks; mp.ldS = ldS;
         mp.max0 = p.max0; mp.idx0 = p.idx0; mp.pv = p.pv; mp.pi = p.pi; mp.idx1_in = nullptr;
         mp.thr = match_thr;
-        mp.m0 = out.m0; mp.m1 = out.m1; mp.ms0 = out.ms0; mp.ms1 = out.ms1;
+        mp.group_batch = gb;
+        for (int g = 0; g < out.n_groups; ++g) {
+            mp.m0[g] = out.m0[g]; mp.m1[g] = out.m1[g]; mp.ms0[g] = out.ms0[g]; mp.ms1[g] = out.ms1[g];
+        }
         hipLaunchKernelGGL(match_finalize, dim3(B), dim3(256), sizeof(int) * (2 * M + N), s, mp);
         E2EMV_CHECK_LAUNCH(ctx, "match_finalize");
     }
@@ -541,7 +562,7 @@ extern "C" int e2emv_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* 
         S = Sp;
     }
     SinkhornOut out;
-    out.logZ = d_logZ;
+    out.logZ[0] = d_logZ;
     rc = launch_sinkhorn(ctx, B, M, N, S, ldS, bin_score, iters, 0.f, out, ws, s);
     prof_end(ctx, s);
     return rc;
@@ -567,7 +588,8 @@ extern "C" int e2emv_extract_matches(e2emv_ctx* ctx, int B, int M, int N, const 
     MatchParams mp{};
     mp.M = M; mp.N = N; mp.chunks = 0; mp.ldS = 0;
     mp.max0 = max0; mp.idx0 = idx0; mp.idx1_in = idx1; mp.thr = match_threshold;
-    mp.m0 = d_matches0; mp.m1 = d_matches1; mp.ms0 = d_mscores0; mp.ms1 = d_mscores1;
+    mp.group_batch = B;
+    mp.m0[0] = d_matches0; mp.m1[0] = d_matches1; mp.ms0[0] = d_mscores0; mp.ms1[0] = d_mscores1;
     hipLaunchKernelGGL(match_finalize, dim3(B), dim3(256), sizeof(int) * (2 * M + N), s, mp);
     prof_end(ctx, s);
     E2EMV_CHECK_LAUNCH(ctx, "extract_matches kernels");

@@ -117,3 +117,23 @@ def test_pose_auc_hand_computed():
     R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
     et, er = compute_pose_error(T, R, np.array([-1.0, 0, 0]))
     assert abs(er - np.rad2deg(0.1)) < 1e-9 and abs(et) < 1e-9  # translation sign ambiguity folded
+
+
+def test_config1_plumbing_on_the_cpu_path():
+    """BASELINE.json configs[0]: tuple_size 2, 256 keypoints, 256-d, batch 4, 5 Sinkhorn iterations, CPU only.
+    The oracle (same op sequence as the reference's PyTorch path) runs matcher -> w8pt end to end."""
+    from e2e_multi_view_matching_amd import MultiViewMatcher
+    from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
+    from oracle import w8pt as O
+    from oracle.matcher import matcher_forward
+    from oracle.metrics import pair_errors, pose_auc
+    torch.manual_seed(0)
+    shell = identity_like_state(MultiViewMatcher({"sinkhorn_iterations": 5, "conf_mlp": True}).eval())  # weights only
+    data = make_tuples(batch=4, tuple_size=2, n_kpts=256, seed=11)
+    out = matcher_forward(data, shell.state_dict(), {**shell.config, "full_output": True})
+    assert out["scores_0_1"].shape == (4, 257, 257) and out["matches0_0_1"].dtype == torch.int64
+    assert out["conf_scores_0_1"].shape == (4, 256, 1)
+    T, info = O.run_weighted_8_point(data, out, 0, 1)
+    err = pair_errors(T.numpy(), data["T_0to1"].numpy())
+    assert np.all(err < 5.0)
+    assert pose_auc(err, [5, 10, 20])[2] > 0.9
