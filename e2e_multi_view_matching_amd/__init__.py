@@ -7,7 +7,8 @@ Everything computes in libe2emv.so (hand-written HIP for gfx950) through ctypes.
 """
 from .matcher import MultiViewMatcher, SuperGlue  # noqa: F401
 from .metrics import compute_pose_error, pose_auc  # noqa: F401
-from .ops import attention, extract_matches, gemm_nt, log_optimal_transport  # noqa: F401
+from .ops import (attention, attention_bf16x3, extract_matches, gemm_bf16x3, gemm_nt,  # noqa: F401
+                  log_optimal_transport)
 from .pose import (compute_rotation_error, compute_translation_error_as_angle, estimate_relative_pose_w8pt,  # noqa: F401
                    get_kpts, normalize, pose_errors, run_weighted_8_point)
 

@@ -16,6 +16,7 @@ MAX_TUPLE, MAX_LAYERS, MAX_KENC, PROF_SLOTS = 8, 64, 8, 16
 FLAG_FULL_OUTPUT, FLAG_MULTI_FRAME = 1, 2
 DESC_F32, DESC_F16 = 0, 1
 OK, EINVAL, ENOMEM, EHIP, ESHAPE, ESTATE = 0, -1, -2, -3, -4, -5
+PRECISION_F32, PRECISION_BF16X3 = 0, 1
 
 c_void_p, c_int, c_float, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_char_p
 c_int64, c_size_t = ctypes.c_int64, ctypes.c_size_t
@@ -63,6 +64,10 @@ SIGNATURES = {
                               c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                               c_int64, c_float, c_int, c_void_p]),
     "e2emv_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "e2emv_set_precision": (c_int, [c_void_p, c_int]),
+    "e2emv_gemm_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "e2emv_attention_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                       c_void_p]),
     "e2emv_profile": (c_int, [c_void_p, c_int]),
     "e2emv_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int64), c_int, c_int]),
     "e2emv_profile_name": (c_char_p, [c_int]),

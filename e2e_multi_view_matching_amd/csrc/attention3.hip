@@ -1,0 +1,245 @@
+// Fused multi-head attention on the bf16 matrix pipe with fp32-class accuracy (operand splitting,
+// see gemm3.hip): every contraction is the 6-term product of 3-way bf16 splits accumulated in fp32.
+//
+// Same transposed, lane-owns-a-query structure as attention.hip:
+//   S^T[key][q]  = sum over 6 (Ki, Qj) plane pairs of mfma_32x32x16_bf16(A = K rows, B = Q rows)
+//   O^T[d][q]   += sum over 6 (Vi, Pj) plane pairs of mfma(A = V^T rows, B = P^T)
+// Q|K arrive as S3 planes [row][3][2D] (q pre-scaled by log2(e)/sqrt(d) in the producing GEMM),
+// V arrives TRANSPOSED, [img][3][D][n_rows] (gemm3's V^T epilogue), because the MFMA operand of
+// the P.V product needs 8 consecutive KEYS per lane.  The softmax probabilities are split into
+// three bf16 planes in registers; with the S^T accumulator layout (row = (r&3)+8(r>>2)+4(lane>>5))
+// registers 8u..8u+7 of a lane are exactly the 8 K-slots that lane must supply for the u-th
+// 16-key MFMA, provided the V^T tile is stored in LDS with the matching key order inside each
+// 16-key group (pos = (k&3) + 4*((k>>3)&1) + 8*((k>>2)&1)) - so P never leaves its lane.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace e2emv {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int A3_Q = 128, A3_KV = 64, A3_HD = 64;
+constexpr int A3_LD = 72;                 // LDS row: 64 bf16 + 8 pad = 144 B (36 dwords: conflict-free b128 reads)
+constexpr int A3_PLANE = 64 * A3_LD;      // bf16 elements per LDS plane tile
+
+struct Attn3Params {
+    const uint16_t* qk;   // S3 [n_img*n_rows][3][2D]
+    const uint16_t* vt;   // [n_img][3][D][n_rows]
+    uint16_t* out;        // S3 [n_img*n_rows][3][D] or null
+    float* out32;         // fp32 [n_img*n_rows][D] or null
+    int B, T, n_rows, n_valid, D, H, cross;
+    int nq, groups, gper;
+};
+
+__device__ __forceinline__ void split3f(float v, __bf16& a, __bf16& b, __bf16& c) {
+    a = (__bf16)v;
+    const float r1 = v - (float)a;
+    b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    c = (__bf16)r2;
+}
+
+__global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Params p) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[3 * A3_PLANE];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[3 * A3_PLANE];
+
+    const int lin = blockIdx.x;
+    const int xcd = lin & 7, idx = lin >> 3;
+    const int g = xcd * p.gper + idx / p.nq;
+    if (g >= p.groups) return;
+    const int qt = idx % p.nq;
+    const int img = g / p.H, head = g % p.H;
+    const int b = img / p.T, t = img % p.T;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int64_t qk_ld = 2 * (int64_t)p.D;        // plane width of the q|k matrix
+    const int64_t qk_row = 3 * qk_ld;              // bf16 per row
+
+    // ---- Q fragments (B operand): lane (q, lh) holds Q_pl[q][16 s + 8 lh .. +7]
+    const int q_row = qt * A3_Q + wave * 32 + l31;
+    bf16x8 Qf[3][4];
+    {
+        const uint16_t* qp = p.qk + ((int64_t)img * p.n_rows + q_row) * qk_row + head * A3_HD + lh * 8;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Qf[pl][s] = *reinterpret_cast<const bf16x8*>(qp + pl * qk_ld + s * 16);
+    }
+
+    f32x16 O0, O1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int n_src = p.cross ? p.T - 1 : 1;
+    const int tiles_per_img = (p.n_valid + A3_KV - 1) / A3_KV;
+    const int n_tiles = n_src * tiles_per_img;
+
+    // staging: 6 x 16-byte chunks of K and of V^T per thread: chunk i -> plane i>>1, row tid/8 + 32*(i&1), chunk tid&7
+    const int st_row = tid >> 3, st_ch = tid & 7;
+    u32x4 rk[6], rv[6];
+    auto src_img = [&](int si) {
+        if (!p.cross) return img;
+        const int tt = si < t ? si : si + 1;
+        return b * p.T + tt;
+    };
+    auto gload = [&](int tile) {
+        const int si = tile / tiles_per_img, kt = tile % tiles_per_img;
+        const int simg = src_img(si);
+        const uint16_t* kbase = p.qk + ((int64_t)simg * p.n_rows + kt * A3_KV) * qk_row + p.D + head * A3_HD + st_ch * 8;
+        const uint16_t* vbase = p.vt + ((int64_t)simg * 3 * p.D + head * A3_HD) * p.n_rows + kt * A3_KV + st_ch * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int pl = i >> 1, row = st_row + 32 * (i & 1);
+            rk[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)row * qk_row + pl * qk_ld);
+            rv[i] = *reinterpret_cast<const u32x4*>(vbase + ((int64_t)pl * p.D + row) * p.n_rows);
+        }
+    };
+    // V^T LDS position of this thread's two 4-key halves (key order permuted inside 16-key groups)
+    const int v_grp = st_ch >> 1, v_pos = 4 * (st_ch & 1);
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int pl = i >> 1, row = st_row + 32 * (i & 1);
+            *reinterpret_cast<u32x4*>(&Ks[pl * A3_PLANE + row * A3_LD + st_ch * 8]) = rk[i];
+            uint16_t* vd = &Vs[pl * A3_PLANE + row * A3_LD + 16 * v_grp + v_pos];
+            *reinterpret_cast<u32x2*>(vd) = u32x2{rv[i][0], rv[i][1]};
+            *reinterpret_cast<u32x2*>(vd + 8) = u32x2{rv[i][2], rv[i][3]};
+        }
+    };
+
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // plane of the A operand (K or V^T), smallest terms first
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};  // plane of the B operand (Q or P)
+
+    gload(0);
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (tile + 1 < n_tiles) gload(tile + 1);
+
+        const int kt = tile % tiles_per_img;
+        const int valid_in_tile = p.n_valid - kt * A3_KV;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (sub * 32 >= valid_in_tile) break;
+            f32x16 S;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[r] = 0.f;
+            const uint16_t* kp = &Ks[(sub * 32 + l31) * A3_LD + lh * 8];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 kf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const bf16x8*>(kp + pl * A3_PLANE + s * 16);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[q]], Qf[PB[q]][s], S, 0, 0, 0);
+            }
+            if (valid_in_tile < sub * 32 + 32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= valid_in_tile) S[r] = -INFINITY;
+                }
+            }
+            float mx = S[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float ps = 0.f;
+            bf16x8 Pf[3][2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(S[r] - m_new);
+                ps += pv;
+                __bf16 a, bb, c;
+                split3f(pv, a, bb, c);
+                Pf[0][r >> 3][r & 7] = a;
+                Pf[1][r >> 3][r & 7] = bb;
+                Pf[2][r >> 3][r & 7] = c;
+            }
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { O0[r] *= alpha; O1[r] *= alpha; }
+            // O^T[d][q] += V^T[d][keys] P^T[keys][q]; 16-key group index inside the tile = 2*sub + u
+            const uint16_t* vp = &Vs[l31 * A3_LD + lh * 8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bf16x8 v0[3], v1[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    v0[pl] = *reinterpret_cast<const bf16x8*>(vp + pl * A3_PLANE + 16 * (2 * sub + u));
+                    v1[pl] = *reinterpret_cast<const bf16x8*>(vp + pl * A3_PLANE + 32 * A3_LD + 16 * (2 * sub + u));
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0[PA[q]], Pf[PB[q]][u], O0, 0, 0, 0);
+                    O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1[PA[q]], Pf[PB[q]][u], O1, 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    if (p.out32) {
+        float* op = p.out32 + ((int64_t)img * p.n_rows + q_row) * p.D + head * A3_HD + 4 * lh;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            f32x4 a, c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = O0[gq * 4 + e] * inv; c[e] = O1[gq * 4 + e] * inv; }
+            *reinterpret_cast<f32x4*>(op + 8 * gq) = a;
+            *reinterpret_cast<f32x4*>(op + 32 + 8 * gq) = c;
+        }
+    }
+    if (p.out) {
+        uint16_t* op = p.out + ((int64_t)img * p.n_rows + q_row) * 3 * p.D + head * A3_HD + 4 * lh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                bf16x4 h0, h1, h2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = (dt ? O1[gq * 4 + e] : O0[gq * 4 + e]) * inv;
+                    __bf16 a, bb, c;
+                    split3f(v, a, bb, c);
+                    h0[e] = a; h1[e] = bb; h2[e] = c;
+                }
+                uint16_t* dst = op + 32 * dt + 8 * gq;
+                *reinterpret_cast<bf16x4*>(dst) = h0;
+                *reinterpret_cast<bf16x4*>(dst + p.D) = h1;
+                *reinterpret_cast<bf16x4*>(dst + 2 * p.D) = h2;
+            }
+    }
+}
+
+int launch_attention3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const uint16_t* qk,
+                      const uint16_t* vt, int cross, uint16_t* out3, float* out32, hipStream_t s) {
+    if (D != H * A3_HD) return set_err(ctx, E2EMV_ESHAPE, "attention3: head dim must be 64 (D=%d H=%d)", D, H);
+    if (n_rows % A3_Q || n_valid <= 0 || n_valid > n_rows)
+        return set_err(ctx, E2EMV_ESHAPE, "attention3: n_rows=%d must be a multiple of %d and >= n_valid=%d", n_rows, A3_Q, n_valid);
+    if (cross && T < 2) return set_err(ctx, E2EMV_ESHAPE, "attention3: cross layer needs T >= 2");
+    Attn3Params p;
+    p.qk = qk; p.vt = vt; p.out = out3; p.out32 = out32; p.B = B; p.T = T; p.n_rows = n_rows; p.n_valid = n_valid; p.D = D; p.H = H;
+    p.cross = cross;
+    p.nq = (n_valid + A3_Q - 1) / A3_Q;
+    p.groups = B * T * H;
+    p.gper = (p.groups + 7) / 8;
+    hipLaunchKernelGGL(attention3_kernel, dim3(8 * p.gper * p.nq), dim3(256), 0, s, p);
+    E2EMV_CHECK_LAUNCH(ctx, "attention3_kernel");
+    return E2EMV_OK;
+}
+
+}  // namespace e2emv

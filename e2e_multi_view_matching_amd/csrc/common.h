@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <type_traits>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -45,6 +46,10 @@ struct LayerWeights {
     float* w_mlp1 = nullptr;  // [D][2D]
     float* b_mlp1 = nullptr;
     int type = 0;             // 0 self, 1 cross
+    // bf16x3 planes ("S3": [out][3][in]) of the three big GEMMs
+    uint16_t* w3_qkv = nullptr;
+    uint16_t* w3_mlp0 = nullptr;
+    uint16_t* w3_mlp1 = nullptr;
 };
 
 struct ProfEvent {
@@ -66,6 +71,9 @@ struct e2emv_ctx {
     e2emv_model_desc model{};
     float* d_warena = nullptr;
     size_t warena_floats = 0;
+    uint16_t* d_w3arena = nullptr;
+    size_t w3arena_elems = 0;
+    int precision = 0;  // E2EMV_PRECISION_F32 | E2EMV_PRECISION_BF16X3 (dense GNN contractions)
     // keypoint encoder: layer 0 (3->c0) used by the ingest kernel, the rest through the GEMM
     float* kenc_w0 = nullptr;  // [c0][3] folded
     float* kenc_b0 = nullptr;  // [c0]
@@ -144,6 +152,12 @@ struct GemmArgs {
     int64_t ldr = 0, sR = 0;
     float* C = nullptr;
     int64_t ldc = 0, sC = 0;
+    uint16_t* C3 = nullptr;  // optional bf16x3-plane output (S3 [M][3][ldc3]); C may then be null
+    int64_t ldc3 = 0;
+    uint16_t* Vt = nullptr;  // optional: columns >= vt_n0 go out transposed as bf16x3 planes (attention3's V^T)
+    int vt_n0 = 0, n_rows = 0;
+    int q_cols = 0;          // columns < q_cols are scaled by q_scale
+    float q_scale = 1.f;
     float scale = 1.f;
     bool relu = false;
 };
@@ -151,6 +165,35 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s);
 
 int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* qkv,
                      int cross, float* out, hipStream_t s);
+
+// ---- bf16x3 split-operand path (gemm3.hip / attention3.hip): fp32-class accuracy on the bf16 pipe ----
+// "S3" = matrix stored as three bf16 planes per row: row r = [plane0 | plane1 | plane2], each ld wide.
+struct Gemm3Args {
+    int M = 0, N = 0, K = 0, K1 = 0;
+    const uint16_t* A = nullptr;
+    int64_t lda = 0;
+    const uint16_t* A2 = nullptr;
+    int64_t lda2 = 0;
+    const uint16_t* W = nullptr;
+    int64_t ldw = 0;
+    const float* bias = nullptr;
+    const float* R = nullptr;
+    int64_t ldr = 0;
+    float* C32 = nullptr;
+    int64_t ldc32 = 0;
+    uint16_t* C3 = nullptr;
+    int64_t ldc3 = 0;
+    uint16_t* Vt = nullptr;
+    int vt_n0 = 0, n_rows = 0;
+    int q_cols = 0;
+    float q_scale = 1.f;
+    bool relu = false;
+};
+int launch_gemm3(e2emv_ctx* ctx, const Gemm3Args& a, hipStream_t s);
+int launch_split3(e2emv_ctx* ctx, const float* src, int64_t rows, int C, int64_t ld_src, uint16_t* dst, int64_t ld,
+                  hipStream_t s);
+int launch_attention3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const uint16_t* qk,
+                      const uint16_t* vt, int cross, uint16_t* out3, float* out32, hipStream_t s);
 
 // Sinkhorn on an internal score buffer S [n_groups * group_batch][M][ldS] (ldS % 4 == 0).  Batch
 // element bb belongs to output group bb / group_batch (= the image pair of a tuple): each group

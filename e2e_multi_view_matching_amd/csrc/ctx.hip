@@ -1,5 +1,6 @@
 // Context lifecycle, memory helpers, weight ingestion (BN folding + head-major re-ordering),
 // workspace arena and the HIP-event profiling hooks of libe2emv.so.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -92,6 +93,7 @@ int e2emv_create(e2emv_ctx** out, int device) {
     ctx->device = device;
     ctx->num_cus = p.multiProcessorCount;
     if (const char* e = getenv("E2EMV_NO_FUSE_MERGE")) ctx->fuse_merge = !(e[0] == '1');
+    if (const char* e = getenv("E2EMV_PRECISION")) ctx->precision = (strcmp(e, "bf16x3") == 0) ? E2EMV_PRECISION_BF16X3 : E2EMV_PRECISION_F32;
     *out = ctx;
     return E2EMV_OK;
 }
@@ -102,6 +104,7 @@ void e2emv_destroy(e2emv_ctx* ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_warena) (void)hipFree(ctx->d_warena);
+    if (ctx->d_w3arena) (void)hipFree(ctx->d_w3arena);
     for (auto& pe : ctx->prof_events) {
         (void)hipEventDestroy(pe.a);
         (void)hipEventDestroy(pe.b);
@@ -177,6 +180,38 @@ struct Packer {
     }
 };
 
+// fp32 -> bf16 (round to nearest even) and back, host side - same arithmetic as the device split
+inline uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// weights [rows][cols] fp32 -> S3 [rows][3][cols] bf16 planes appended to `out`; returns the offset
+size_t add_split3(std::vector<uint16_t>& out, const std::vector<float>& w, int rows, int cols) {
+    size_t off = (out.size() + 127) & ~size_t(127);
+    out.resize(off + (size_t)rows * 3 * cols);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            const float v = w[(size_t)r * cols + c];
+            const uint16_t a = f2bf(v);
+            const float r1 = v - bf2f(a);
+            const uint16_t b = f2bf(r1);
+            const float r2 = r1 - bf2f(b);
+            const uint16_t d = f2bf(r2);
+            uint16_t* o = &out[off + (size_t)r * 3 * cols];
+            o[c] = a; o[cols + c] = b; o[2 * cols + c] = d;
+        }
+    return off;
+}
+
 const HostTensor* find(e2emv_ctx* ctx, const std::string& k) {
     auto it = ctx->raw.find(k);
     return it == ctx->raw.end() ? nullptr : &it->second;
@@ -248,7 +283,9 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     // ---- GNN layers ----
     struct LOff {
         size_t wqkv, bqkv, wm, bm, w0, b0, w1, b1;
+        size_t w3qkv, w3m0, w3m1;
     };
+    std::vector<uint16_t> pk3;  // bf16x3 planes of the big GEMM weights
     std::vector<LOff> loff(m->n_layers);
     for (int l = 0; l < m->n_layers; ++l) {
         std::string base = "gnn.layers." + std::to_string(l);
@@ -264,6 +301,7 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         }
         loff[l].wqkv = pk.add(wqkv);
         loff[l].bqkv = pk.add(bqkv);
+        loff[l].w3qkv = add_split3(pk3, wqkv, 3 * D, D);
         if ((rc = get_conv(ctx, base + ".attn.merge", D, D, w, b))) return rc;
         std::vector<float> wm((size_t)D * D);
         for (int o = 0; o < D; ++o)
@@ -296,9 +334,11 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         }
         loff[l].w0 = pk.add(w);
         loff[l].b0 = pk.add(b);
+        loff[l].w3m0 = add_split3(pk3, w, 2 * D, 2 * D);
         if ((rc = get_conv(ctx, base + ".mlp.3", D, 2 * D, w, b))) return rc;
         loff[l].w1 = pk.add(w);
         loff[l].b1 = pk.add(b);
+        loff[l].w3m1 = add_split3(pk3, w, D, 2 * D);
     }
     if ((rc = get_conv(ctx, "final_proj", D, D, w, b))) return rc;
     size_t wf = pk.add(w), bf = pk.add(b);
@@ -329,8 +369,23 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         ctx->d_warena = (float*)p;
         ctx->warena_floats = pk.host.size();
     }
+    if (pk3.size() > ctx->w3arena_elems) {
+        E2EMV_HIP(ctx, hipDeviceSynchronize());
+        if (ctx->d_w3arena) E2EMV_HIP(ctx, hipFree(ctx->d_w3arena));
+        ctx->d_w3arena = nullptr;
+        ctx->w3arena_elems = 0;
+        void* p3 = nullptr;
+        if (hipMalloc(&p3, std::max<size_t>(pk3.size(), 1) * sizeof(uint16_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            return set_err(ctx, E2EMV_ENOMEM, "bf16x3 weight arena allocation failed");
+        }
+        ctx->d_w3arena = (uint16_t*)p3;
+        ctx->w3arena_elems = pk3.size();
+    }
     E2EMV_HIP(ctx, hipDeviceSynchronize());  // no forward may be in flight while weights change
     E2EMV_HIP(ctx, hipMemcpy(ctx->d_warena, pk.host.data(), pk.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!pk3.empty())
+        E2EMV_HIP(ctx, hipMemcpy(ctx->d_w3arena, pk3.data(), pk3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     float* base = ctx->d_warena;
     ctx->kenc_dims = dims;
     ctx->kenc_w0 = base + kw_off[0];
@@ -353,6 +408,9 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         L.w_mlp1 = base + loff[l].w1;
         L.b_mlp1 = base + loff[l].b1;
         L.type = m->layer_types[l] ? 1 : 0;
+        L.w3_qkv = ctx->d_w3arena + loff[l].w3qkv;
+        L.w3_mlp0 = ctx->d_w3arena + loff[l].w3m0;
+        L.w3_mlp1 = ctx->d_w3arena + loff[l].w3m1;
     }
     ctx->w_final = base + wf;
     ctx->b_final = base + bf;
@@ -371,6 +429,16 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
 }
 
 extern "C" {
+
+int e2emv_set_precision(e2emv_ctx* ctx, int precision) {
+    if (!ctx) return E2EMV_EINVAL;
+    if (precision != E2EMV_PRECISION_F32 && precision != E2EMV_PRECISION_BF16X3)
+        return set_err(ctx, E2EMV_EINVAL, "unknown precision %d", precision);
+    if (precision == E2EMV_PRECISION_BF16X3 && !ctx->fuse_merge)
+        return set_err(ctx, E2EMV_ESTATE, "bf16x3 needs the merge conv folded into MLP0 (unset E2EMV_NO_FUSE_MERGE)");
+    ctx->precision = precision;
+    return E2EMV_OK;
+}
 
 int e2emv_profile(e2emv_ctx* ctx, int enable) {
     if (!ctx) return E2EMV_EINVAL;

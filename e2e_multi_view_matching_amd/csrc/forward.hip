@@ -142,7 +142,11 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
     const size_t sz_S = al((size_t)P * B * N * ldS * 4);
     const size_t sz_sk = sinkhorn_ws_bytes(P * B, N, N);
     const size_t sz_match = full ? (size_t)P * (al((size_t)B * N * 8) + al((size_t)B * N * 4)) : 0;
-    const size_t need = sz_x * 3 + sz_qkv + sz_hid + sz_S + sz_sk + sz_match + 4096;
+    const bool b3 = ctx->precision == E2EMV_PRECISION_BF16X3 && ctx->fuse_merge;
+    // bf16x3 attention path: x as S3 planes (6D bytes/row) and V^T planes (6D bytes/row); the q|k planes
+    // (S3, 2D wide = 12D bytes/row) live in the fp32 q|k|v buffer, which has exactly that size
+    const size_t sz_x3 = b3 ? al((size_t)Mtot * 3 * D * 2) : 0;
+    const size_t need = sz_x * 3 + sz_qkv + sz_hid + sz_S + sz_sk + sz_match + sz_x3 + 4096;
     int rc = ws_reserve(ctx, need);
     if (rc) return rc;
     char* w = ctx->d_ws;
@@ -153,6 +157,11 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
     float* hid = (float*)w; w += sz_hid;
     float* S = (float*)w; w += sz_S;
     char* skws = w; w += sz_sk;
+    uint16_t* qk3 = nullptr; uint16_t* vt3 = nullptr;
+    if (b3) {
+        vt3 = (uint16_t*)w; w += sz_x3;
+        qk3 = (uint16_t*)qkv;
+    }
     std::vector<int64_t*> tmp_m0(P, nullptr);
     std::vector<float*> tmp_ms0(P, nullptr);
     if (full)
@@ -210,6 +219,20 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
     for (size_t l = 0; l < ctx->layers.size(); ++l) {
         const LayerWeights& L = ctx->layers[l];
         GemmArgs g;
+        if (b3) {
+            // q|k|v by the fp32 GEMM, emitted as bf16x3 planes (q|k as S3 with the softmax scale folded into q,
+            // V transposed for the P.V MFMA); attention itself runs on the bf16 pipe with 6-term split products
+            g = GemmArgs();
+            g.M = (int)Mtot; g.N = 3 * D; g.K = D; g.K1 = D; g.A = x; g.lda = D; g.W = L.w_qkv; g.ldw = D; g.bias = L.b_qkv;
+            g.C3 = qk3; g.ldc3 = 2 * D; g.Vt = vt3; g.vt_n0 = 2 * D; g.n_rows = n_rows;
+            g.q_cols = D; g.q_scale = 0.125f * 1.4426950408889634f;
+            prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
+            if (rc) return rc;
+            prof_begin(ctx, PS_ATTN, s);
+            rc = launch_attention3(ctx, B, T, n_rows, N, D, H, qk3, vt3, L.type, nullptr, att, s);
+            prof_end(ctx, s);
+            if (rc) return rc;
+        } else {
         // q|k|v = x Wqkv^T + b
         g = GemmArgs();
         g.M = (int)Mtot; g.N = 3 * D; g.K = D; g.K1 = D; g.A = x; g.lda = D; g.W = L.w_qkv; g.ldw = D; g.bias = L.b_qkv;
@@ -220,6 +243,7 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         rc = launch_attention(ctx, B, T, n_rows, N, D, H, qkv, L.type, att, s);
         prof_end(ctx, s);
         if (rc) return rc;
+        }
         const float* second = att;  // MLP0's second K segment: attention output (merge folded into W0)
         if (!ctx->fuse_merge) {
             // message = merge(attention)

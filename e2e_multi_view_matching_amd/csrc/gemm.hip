@@ -34,6 +34,7 @@ namespace e2emv {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 constexpr int BM = 128, BN = 128, BK = 32, LDK = 36;
 
@@ -44,6 +45,12 @@ struct GemmParams {
     const float* bias;
     const float* R;
     float* C;
+    uint16_t* C3;   // optional output as bf16x3 planes, S3 [M][3][ldc3] (batch 1 only); C may then be null
+    int64_t ldc3;
+    uint16_t* Vt;   // optional: columns n >= vt_n0 are written TRANSPOSED as bf16x3 planes [img][3][N - vt_n0][n_rows]
+    int vt_n0, n_rows;
+    int q_cols;     // columns n < q_cols are multiplied by q_scale (attention query pre-scale)
+    float q_scale;
     int64_t lda, lda2, ldw, ldr, ldc;
     int64_t sA, sA2, sW, sR, sC;
     int M, N, K, K1;
@@ -59,7 +66,11 @@ struct GemmParams {
 // tiles of consecutive output tiles form ONE software-pipelined stream: the first K tile of
 // the next output tile is prefetched under the last MFMAs of the current one and the
 // epilogue's stores drain under the next tile's MFMAs - no lockstep load/store bursts.
-__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmParams p) {
+// EXT = true adds the bf16x3-plane outputs (C3, V^T with swapped operand roles, q pre-scale) used by the
+// q|k|v GEMM of the split-operand attention path; it gets a 256-VGPR budget (2 workgroups/CU) so that the
+// plain kernel (EXT = false, every other GEMM) keeps its spill-free 168-VGPR / 3-workgroups-per-CU build.
+template <bool EXT>
+__global__ __launch_bounds__(256, EXT ? 2 : 3) void gemm_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;               // [BM][LDK]  activations
     float* Bs = smem + BM * LDK;    // [BN][LDK]  weights
@@ -129,9 +140,12 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
     };
-    auto compute = [&](int buf) {
-        const float* as = &As[(buf * BM + wr * 64 + l31) * LDK + lh * 4];
-        const float* bs = &Bs[(buf * BN + wc * 64 + l31) * LDK + lh * 4];
+    // SWAP = false: weights are the MFMA A operand (rows -> registers), activations B (rows -> lanes);
+    // SWAP = true : roles exchanged (lane = output channel, registers = runs of 4 rows) for V^T tiles
+    auto compute = [&](auto swap_tag) {
+        constexpr bool SWAP = decltype(swap_tag)::value;
+        const float* as = &As[(wr * 64 + l31) * LDK + lh * 4];
+        const float* bs = &Bs[(wc * 64 + l31) * LDK + lh * 4];
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(as + c * 8);
@@ -140,17 +154,62 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmParams p) {
             const f32x4 w1 = *reinterpret_cast<const f32x4*>(bs + 32 * LDK + c * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], x0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], x1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], x0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], x1[e], acc[1][1], 0, 0, 0);
+                if (SWAP) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], w0[e], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], w0[e], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], w1[e], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], w1[e], acc[1][1], 0, 0, 0);
+                } else {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], x0[e], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], x1[e], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], x0[e], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], x1[e], acc[1][1], 0, 0, 0);
+                }
             }
+        }
+    };
+    auto split4 = [&](const f32x4& v, bf16x4& h0, bf16x4& h1, bf16x4& h2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 a = (__bf16)v[e];
+            const float r1 = v[e] - (float)a;
+            const __bf16 b2 = (__bf16)r1;
+            h0[e] = a; h1[e] = b2; h2[e] = (__bf16)(r1 - (float)b2);
+        }
+    };
+    // V^T tiles (SWAP accumulators): lane = channel n, registers = 4 consecutive rows m -> 8-byte stores along the keys
+    auto epilogue_vt = [&](int t) {
+        const int r = t % tiles_mn;
+        const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
+        const int nv = p.N - p.vt_n0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = tn * BN + wc * 64 + j * 32 + l31;
+            if (n >= p.N) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int m = tm * BM + wr * 64 + i * 32 + 8 * g + 4 * lh;
+                    if (m >= p.M) continue;
+                    const int img = m / p.n_rows, ml = m - img * p.n_rows;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e] * p.scale + bv;
+                    bf16x4 h0, h1, h2;
+                    split4(v, h0, h1, h2);
+                    uint16_t* dst = p.Vt + ((int64_t)(img * 3) * nv + (n - p.vt_n0)) * p.n_rows + ml;
+                    *reinterpret_cast<bf16x4*>(dst) = h0;
+                    *reinterpret_cast<bf16x4*>(dst + (int64_t)nv * p.n_rows) = h1;
+                    *reinterpret_cast<bf16x4*>(dst + 2 * (int64_t)nv * p.n_rows) = h2;
+                }
         }
     };
     auto epilogue = [&](int t) {
         const int z = t / tiles_mn, r = t - z * tiles_mn;
         const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
-        float* C = p.C + z * p.sC;
+        float* C = p.C ? p.C + z * p.sC : nullptr;
         const float* R = p.R ? p.R + z * p.sR : nullptr;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -172,7 +231,16 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmParams p) {
                             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                         }
                         if (R) v += *reinterpret_cast<const f32x4*>(R + (int64_t)m * p.ldr + n);
-                        *reinterpret_cast<f32x4*>(C + (int64_t)m * p.ldc + n) = v;
+                        if (EXT && n < p.q_cols) v *= p.q_scale;
+                        if (!EXT || p.C) *reinterpret_cast<f32x4*>(C + (int64_t)m * p.ldc + n) = v;
+                        if (EXT && p.C3) {  // bf16x3 planes for the split-operand attention (attention3.hip)
+                            bf16x4 h0, h1, h2;
+                            split4(v, h0, h1, h2);
+                            uint16_t* d3 = p.C3 + (int64_t)m * 3 * p.ldc3 + n;
+                            *reinterpret_cast<bf16x4*>(d3) = h0;
+                            *reinterpret_cast<bf16x4*>(d3 + p.ldc3) = h1;
+                            *reinterpret_cast<bf16x4*>(d3 + 2 * p.ldc3) = h2;
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -196,6 +264,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmParams p) {
     setup(tile);
     gload(0);
     for (;;) {
+        const bool vt = EXT && ((tile % tiles_mn) % p.tiles_n) * BN >= p.vt_n0;  // workgroup-uniform
         for (int kt = 0; kt + 1 < nk; ++kt) {
             __syncthreads();  // previous K tile fully consumed
             lstore(0);
@@ -205,7 +274,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmParams p) {
             // the LDS fragments).  Pinning them above with sched_barrier(0) was measured 8-13 % SLOWER
             // (K=2048: 563 -> 645 us): with 3 waves/SIMD the latency is covered by the other waves and
             // the early loads only lengthen the live ranges.  Left to the compiler on purpose.
-            compute(0);
+            if (EXT && vt) compute(std::true_type{}); else compute(std::false_type{});
         }
         // last K tile of this output tile: prefetch the next output tile's first K tile under it
         const int next = tile + slots;
@@ -217,8 +286,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmParams p) {
             setup(next);
             gload(0);
         }
-        compute(0);
-        epilogue(tile);
+        if (EXT && vt) compute(std::true_type{}); else compute(std::false_type{});
+        if (EXT && vt) epilogue_vt(tile); else epilogue(tile);
         if (!more) break;
         zero_acc();
         tile = next;
@@ -235,6 +304,12 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
         return set_err(ctx, E2EMV_ESHAPE, "gemm: operands must be 16-byte aligned with leading dims %% 4 == 0");
     GemmParams p;
     p.A = a.A; p.A2 = a.A2; p.W = a.W; p.bias = a.bias; p.R = a.R; p.C = a.C;
+    p.C3 = a.C3; p.ldc3 = a.ldc3;
+    p.Vt = a.Vt; p.vt_n0 = a.Vt ? a.vt_n0 : (1 << 30); p.n_rows = a.n_rows > 0 ? a.n_rows : a.M;
+    p.q_cols = a.q_cols; p.q_scale = a.q_scale;
+    if (!a.C && !a.C3) return set_err(ctx, E2EMV_EINVAL, "gemm: no output");
+    if (a.Vt && (a.vt_n0 % BN || p.n_rows % 128 || a.M % p.n_rows || a.batch != 1))
+        return set_err(ctx, E2EMV_ESHAPE, "gemm: V^T output needs vt_n0 %% 128 == 0, whole images and batch 1");
     p.lda = a.lda; p.lda2 = a.lda2; p.ldw = a.ldw; p.ldr = a.ldr; p.ldc = a.ldc;
     p.sA = a.sA; p.sA2 = a.sA2; p.sW = a.sW; p.sR = a.sR; p.sC = a.sC;
     p.M = a.M; p.N = a.N; p.K = a.K; p.K1 = K1;
@@ -243,13 +318,20 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
     p.total = p.tiles_m * p.tiles_n * a.batch;
     p.scale = a.scale;
     p.relu = a.relu ? 1 : 0;
-    p.vec_store = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((uintptr_t)a.C % 16 == 0) && (a.sC % 4 == 0) &&
+    p.vec_store = (a.N % 4 == 0) && (!a.C || ((a.ldc % 4 == 0) && ((uintptr_t)a.C % 16 == 0) && (a.sC % 4 == 0))) &&
                   (!a.bias || (uintptr_t)a.bias % 16 == 0) &&
                   (!a.R || ((a.ldr % 4 == 0) && ((uintptr_t)a.R % 16 == 0) && (a.sR % 4 == 0)));
+    if ((p.C3 || a.Vt) && (!p.vec_store || a.batch != 1 || (p.C3 && a.ldc3 % 4)))
+        return set_err(ctx, E2EMV_ESHAPE, "gemm: the bf16x3 side output needs the vector epilogue and batch 1");
     const int per_xcd = (p.total + 7) / 8;
     const int slots = std::min(per_xcd, std::max(1, ctx->num_cus * 3 / 8));
     const size_t lds = sizeof(float) * (BM + BN) * LDK;
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(8 * slots), dim3(256), lds, s, p);
+    if (p.C3 || a.Vt || a.q_cols > 0) {
+        const int slots2 = std::min(per_xcd, std::max(1, ctx->num_cus * 2 / 8));
+        hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(8 * slots2), dim3(256), lds, s, p);
+    } else {
+        hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3(8 * slots), dim3(256), lds, s, p);
+    }
     E2EMV_CHECK_LAUNCH(ctx, "gemm_nt_kernel");
     return E2EMV_OK;
 }

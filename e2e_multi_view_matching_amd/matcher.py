@@ -39,6 +39,10 @@ DEFAULT_CONFIG = {
     "tuple_size": 2,
     "conf_mlp": False,
     "full_output": False,
+    # arithmetic of the dense q|k|v + attention contractions: "f32" (fp32 MFMA) or "bf16x3" (fp32 operands
+    # split into three bf16 planes, 6 bf16-MFMA products, fp32 accumulate - fp32-class accuracy).  None = the
+    # library default (environment variable E2EMV_PRECISION, else "f32").
+    "mfma_precision": None,
 }
 
 
@@ -155,6 +159,8 @@ class MultiViewMatcher(nn.Module):
                                "the CPU oracle lives in oracle/ and is test infrastructure)")
         ctx = _lib.context(dev)
         self._push_weights(ctx)
+        if cfg.get("mfma_precision") is not None:
+            ctx.call("e2emv_set_precision", {"f32": _lib.PRECISION_F32, "bf16x3": _lib.PRECISION_BF16X3}[cfg["mfma_precision"]])
         kpts, scores, descs = [], [], []
         fd = _lib.ForwardDesc()
         for m in range(T):

@@ -70,3 +70,30 @@ def attention(qkv, B, T, n_valid, H, cross):
         ctx.call("e2emv_attention", B, T, n_rows, n_valid, D, H, _lib.ptr(q), 1 if cross else 0, _lib.ptr(out),
                  _lib.stream_ptr(q.device))
     return out
+
+
+def gemm_bf16x3(A, W, bias=None, relu=False):
+    """bf16x3 split-operand GEMM building block on fp32 tensors: act(A W^T + bias)."""
+    ctx = _ctx(A)
+    A_, W_ = A.contiguous().float(), W.contiguous().float()
+    M, K = A_.shape
+    N = W_.shape[0]
+    C = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    b = bias.contiguous().float() if bias is not None else None
+    with torch.cuda.device(A.device):
+        ctx.call("e2emv_gemm_bf16x3", M, N, K, _lib.ptr(A_), _lib.ptr(W_), _lib.ptr(b), _lib.ptr(C), 1 if relu else 0,
+                 _lib.stream_ptr(A.device))
+    return C
+
+
+def attention_bf16x3(qkv, B, T, n_valid, H, cross):
+    """bf16x3 split-operand attention building block; same contract as `attention`."""
+    ctx = _ctx(qkv)
+    q = qkv.contiguous().float()
+    n_img, n_rows, D3 = q.shape
+    D = D3 // 3
+    out = torch.empty((n_img, n_rows, D), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        ctx.call("e2emv_attention_bf16x3", B, T, n_rows, n_valid, D, H, _lib.ptr(q), 1 if cross else 0, _lib.ptr(out),
+                 _lib.stream_ptr(q.device))
+    return out

@@ -167,6 +167,24 @@ int e2emv_gemm_nt(e2emv_ctx* ctx, int batch, int M, int Nout, int K, int K1, con
 int e2emv_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv,
                     int cross, float* d_out, void* stream);
 
+/* ---- arithmetic of the dense GNN contractions -----------------------------------------
+ * E2EMV_PRECISION_F32    : v_mfma_f32_32x32x2_f32, exact fp32 products (default).
+ * E2EMV_PRECISION_BF16X3 : fp32 operands split into three bf16 planes, six bf16 MFMA products per
+ *                          block accumulated in fp32 - fp32-class rounding (|err| ~ 2^-24 per
+ *                          product) at 2.67x the fp32-MFMA ceiling.  Same API, same outputs within
+ *                          the 1e-4 parity bar (tests/test_gpu_matcher.py runs both).
+ * Also selectable with the environment variable E2EMV_PRECISION=f32|bf16x3 read at e2emv_create. */
+#define E2EMV_PRECISION_F32 0
+#define E2EMV_PRECISION_BF16X3 1
+int e2emv_set_precision(e2emv_ctx* ctx, int precision);
+/* building blocks of the bf16x3 path on fp32 buffers (split / merge done internally; for tests):
+ * C = act(A W^T + bias), A [M,K], W [N,K], C [M,N]; flags bit0 relu. */
+int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const float* d_A, const float* d_W, const float* d_bias,
+                      float* d_C, int flags, void* stream);
+/* same contract as e2emv_attention. */
+int e2emv_attention_bf16x3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv,
+                           int cross, float* d_out, void* stream);
+
 /* ---- timing hooks used by bench.py (HIP events on the caller's stream) -------------
  * After e2emv_profile(ctx, 1) every kernel family launched by the library is bracketed by
  * HIP events on its stream; e2emv_profile_read returns accumulated milliseconds and launch

@@ -106,3 +106,34 @@ def test_extract_matches_vs_oracle(gpu):
     assert torch.equal(m0.cpu(), i0) and torch.equal(m1.cpu(), i1)
     assert float((ms0.cpu() - s0).abs().max()) < 1e-6 and float((ms1.cpu() - s1).abs().max()) < 1e-6
     assert (i0 >= 0).sum() > 0
+
+
+# ---------------------------------------------------------------- bf16x3 split-operand building blocks
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 64), (1024, 512, 512), (65, 36, 256)])
+def test_gemm_bf16x3_has_fp32_class_accuracy(gpu, M, N, K):
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g) * 2)   # rows spanning ~4 decades
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T + b.double()
+    out3 = E.gemm_bf16x3(A.to(gpu), W.to(gpu), bias=b.to(gpu)).cpu()
+    out32 = E.gemm_nt(A.to(gpu), W.to(gpu), bias=b.to(gpu)).cpu()
+    # error relative to sum |a||w| (the natural fp32 GEMM error scale)
+    scale = (A.double().abs() @ W.double().abs().T) + b.double().abs()
+    e3 = float(((out3.double() - ref).abs() / scale).max())
+    e32 = float(((out32.double() - ref).abs() / scale).max())
+    assert e3 < 4e-7, (e3, e32)          # fp32 unit roundoff is 6e-8; K-term accumulation grows it
+    assert e3 < 4 * e32 + 1e-7, (e3, e32)
+
+
+@pytest.mark.parametrize("B,T,n_rows,n_valid,cross", [(2, 2, 128, 128, 0), (2, 2, 256, 200, 1), (1, 3, 256, 131, 1),
+                                                       (1, 2, 128, 5, 0)])
+def test_attention_bf16x3(gpu, B, T, n_rows, n_valid, cross):
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(n_valid)
+    qkv = torch.randn(B * T, n_rows, 3 * 256, generator=g) * 1.5
+    ref = _attention_ref(qkv, B, T, n_valid, 4, cross)
+    out = E.attention_bf16x3(qkv.to(gpu), B, T, n_valid, 4, cross).cpu()
+    err = (out[:, :n_valid].double() - ref[:, :n_valid]).abs().max()
+    assert float(err) < 2e-5, float(err)

@@ -17,6 +17,15 @@ def _randomize_bn(module, seed):
             m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
 
 
+def test_deep_random_network_18_layers(gpu):
+    """Full depth (9 x (self, cross)), random weights + random BatchNorm statistics: rounding differences
+    accumulate over 18 layers - both arithmetic modes must stay inside the 1e-4 bar with exact indices."""
+    for precision in PRECISIONS:
+        cfg = {"sinkhorn_iterations": 30, "conf_mlp": True, "match_threshold": 0.0, "mfma_precision": precision}
+        out, ref, _ = _run(cfg, dict(batch=1, tuple_size=2, n_kpts=192), gpu, seed=21)
+        _compare(out, ref, [(0, 1)])
+
+
 def _run(cfg, data_kw, gpu, seed=0, w_id=False):
     from e2e_multi_view_matching_amd import MultiViewMatcher
     from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
@@ -30,6 +39,7 @@ def _run(cfg, data_kw, gpu, seed=0, w_id=False):
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     ocfg = dict(model.config)
     ocfg["full_output"] = True
+    ocfg.pop("mfma_precision", None)
     ref = matcher_forward(data, sd, ocfg)
     model = model.to(gpu)
     with torch.no_grad():
@@ -47,15 +57,21 @@ def _compare(out, ref, pairs):
         assert c.shape == cr.shape and float((c - cr).abs().max()) < TOL
 
 
+PRECISIONS = ["f32", "bf16x3"]
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("conf_mlp", [False, True])
-def test_pair_random_weights(gpu, conf_mlp):
-    cfg = {"GNN_layers": ["self", "cross"] * 2, "sinkhorn_iterations": 20, "conf_mlp": conf_mlp, "match_threshold": 0.0}
+def test_pair_random_weights(gpu, conf_mlp, precision):
+    cfg = {"GNN_layers": ["self", "cross"] * 2, "sinkhorn_iterations": 20, "conf_mlp": conf_mlp, "match_threshold": 0.0,
+           "mfma_precision": precision}
     out, ref, _ = _run(cfg, dict(batch=2, tuple_size=2, n_kpts=256), gpu, seed=1)
     _compare(out, ref, [(0, 1)])
 
 
-def test_pair_identity_weights_gives_real_matches(gpu):
-    cfg = {"GNN_layers": ["self", "cross"] * 2, "sinkhorn_iterations": 50, "conf_mlp": True}
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_pair_identity_weights_gives_real_matches(gpu, precision):
+    cfg = {"GNN_layers": ["self", "cross"] * 2, "sinkhorn_iterations": 50, "conf_mlp": True, "mfma_precision": precision}
     out, ref, data = _run(cfg, dict(batch=2, tuple_size=2, n_kpts=256), gpu, seed=2, w_id=True)
     _compare(out, ref, [(0, 1)])
     m = out["matches0_0_1"].cpu()
@@ -63,14 +79,17 @@ def test_pair_identity_weights_gives_real_matches(gpu):
     assert ((m == gt) & (gt >= 0)).sum() > 0.8 * (gt >= 0).sum()
 
 
-def test_ragged_keypoint_count(gpu):
-    cfg = {"GNN_layers": ["self", "cross"], "sinkhorn_iterations": 10}
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_ragged_keypoint_count(gpu, precision):
+    cfg = {"GNN_layers": ["self", "cross"], "sinkhorn_iterations": 10, "mfma_precision": precision}
     out, ref, _ = _run(cfg, dict(batch=1, tuple_size=2, n_kpts=203), gpu, seed=3, w_id=True)
     _compare(out, ref, [(0, 1)])
 
 
-def test_multi_frame_tuple3(gpu):
-    cfg = {"GNN_layers": ["self", "cross", "cross"], "sinkhorn_iterations": 10, "multi_frame_matching": True, "tuple_size": 3}
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_multi_frame_tuple3(gpu, precision):
+    cfg = {"GNN_layers": ["self", "cross", "cross"], "sinkhorn_iterations": 10, "multi_frame_matching": True, "tuple_size": 3,
+           "mfma_precision": precision}
     out, ref, _ = _run(cfg, dict(batch=2, tuple_size=3, n_kpts=128), gpu, seed=4, w_id=True)
     _compare(out, ref, [(0, 1), (0, 2), (1, 2)])
 

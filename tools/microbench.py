@@ -44,6 +44,40 @@ def main():
                          _lib.ptr(C), N, 0, 1.0, 0, _lib.stream_ptr(dev))
             ms = timeit(run)
             print(f"  {M:7d} {N:5d} {K:5d}  {ms * 1e3:9.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF")
+    if "g3" in args.what:
+        print("== gemm_bf16x3 kernel alone (HIP events inside the library) (M, N, K) -> us, TFLOP/s fp32-equivalent")
+        from e2e_multi_view_matching_amd import _lib
+        ctx = _lib.context(dev)
+        for (M, N, K) in [(65536, 256, 256), (65536, 256, 512), (65536, 512, 512), (65536, 768, 256), (65536, 256, 2048)]:
+            A = torch.randn(M, K, device=dev)
+            W = torch.randn(N, K, device=dev)
+            for _ in range(2):
+                E.gemm_bf16x3(A, W)
+            ctx.call("e2emv_profile", 1)
+            _lib.profile_read(ctx, reset=True)
+            for _ in range(10):
+                E.gemm_bf16x3(A, W)
+            pr = _lib.profile_read(ctx, reset=True)["gemm"]
+            ctx.call("e2emv_profile", 0)
+            ms = pr["ms"] / pr["launches"]
+            print(f"  {M:7d} {N:5d} {K:5d}  {ms * 1e3:9.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF")
+    if "a3" in args.what:
+        print("== attention_bf16x3 kernel alone (B pairs, N) -> us, TFLOP/s fp32-equivalent")
+        from e2e_multi_view_matching_amd import _lib
+        ctx = _lib.context(dev)
+        for (B, N) in [(32, 1024), (8, 2048)]:
+            qkv = torch.randn(B * 2, N, 768, device=dev)
+            for cross in (0, 1):
+                for _ in range(2):
+                    E.attention_bf16x3(qkv, B, 2, N, 4, cross)
+                ctx.call("e2emv_profile", 1)
+                _lib.profile_read(ctx, reset=True)
+                for _ in range(5):
+                    E.attention_bf16x3(qkv, B, 2, N, 4, cross)
+                pr = _lib.profile_read(ctx, reset=True)["attention"]
+                ctx.call("e2emv_profile", 0)
+                ms = pr["ms"] / pr["launches"]
+                print(f"  B={B:3d} N={N:5d} cross={cross}  {ms * 1e3:9.1f} us  {B * 2 * 4.0 * N * N * 256 / ms / 1e9:7.1f} TF")
     if "attn" in args.what:
         print("== attention (B pairs, N) -> us, TFLOP/s")
         for (B, N) in [(32, 1024), (8, 1024), (32, 512), (8, 2048)]:
