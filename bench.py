@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--sinkhorn-iters", type=int, default=100)
     ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernel families with HIP events")
+    ap.add_argument("--ba", action="store_true", help="also run the two-view bundle adjustment (10 LM iterations) per pair "
+                    "inside the step (the reference's default eval mode w8pt_ba); off by default: SURVEY 8(d) defines the "
+                    "metric on matcher -> w8pt -> pose errors")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-for-value) bf16x3-attention measurement")
     args = ap.parse_args()
 
@@ -98,6 +101,10 @@ def main():
             errs = []
             for (i, j) in pairs:
                 Tp, info = E.run_weighted_8_point(data, res, i, j)
+                if args.ba:  # eval_pairs.py:250-255
+                    c = info["confidence"] * info["pos_depth_mask"].unsqueeze(-1)
+                    Tr, vb = E.run_bundle_adjust_2_view(info["kpts0_norm"], info["kpts1_norm"], c, Tp, n_iterations=10)
+                    Tp[vb] = Tr
                 errs.append(E.pose_errors(Tp, data[f"T_{i}to{j}"]))
         return res, errs
 

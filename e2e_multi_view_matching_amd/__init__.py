@@ -10,8 +10,8 @@ from .metrics import compute_pose_error, pose_auc  # noqa: F401
 from .ops import (attention, attention_bf16x3, extract_matches, gemm_bf16x3, gemm_nt,  # noqa: F401
                   log_optimal_transport)
 from .pose import (compute_rotation_error, compute_translation_error_as_angle, estimate_relative_pose_w8pt,  # noqa: F401
-                   get_kpts, normalize, pose_errors, run_weighted_8_point)
+                   get_kpts, normalize, pose_errors, run_bundle_adjust_2_view, run_weighted_8_point)
 
 __all__ = ["MultiViewMatcher", "SuperGlue", "estimate_relative_pose_w8pt", "run_weighted_8_point", "get_kpts",
-           "normalize", "compute_rotation_error", "compute_translation_error_as_angle", "pose_errors", "pose_auc",
+           "run_bundle_adjust_2_view", "normalize", "compute_rotation_error", "compute_translation_error_as_angle", "pose_errors", "pose_auc",
            "compute_pose_error", "log_optimal_transport", "extract_matches", "gemm_nt", "attention"]

@@ -140,3 +140,23 @@ def compute_translation_error_as_angle(T0, T1, reduce=True):
     n = torch.linalg.norm(T0[..., :3, 3], dim=-1) * torch.linalg.norm(T1[..., :3, 3], dim=-1)
     valid = (n > 1e-6).to(tr.device)
     return tr[valid].mean()
+
+
+def run_bundle_adjust_2_view(kpts0_norm, kpts1_norm, confidence, init_T021, n_iterations, check_lu_info_strict=False,
+                             check_precond_strict=False):
+    """``run_bundle_adjust_2_view`` (estimate_relative_pose.py:138-144): returns ``(refined T_021 of the valid samples
+    [n_valid,4,4], valid_batch [B] bool)`` so that ``pred_T021[valid] = refined`` works as at ``eval_pairs.py:252-255``.
+    The two ``*_strict`` flags only matter for singular systems, which the fp64 Schur solve reports the same way."""
+    dev = _dev_of(kpts0_norm, kpts1_norm, init_T021)
+    ctx = _lib.context(dev)
+    B, N = kpts0_norm.shape[:2]
+    k0, k1 = _prep(kpts0_norm, dev), _prep(kpts1_norm, dev)
+    cf = _prep(confidence.reshape(B, -1), dev)
+    Ti = _prep(init_T021, dev)
+    To = torch.empty((B, 4, 4), dtype=torch.float32, device=dev)
+    valid = torch.empty((B,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        ctx.call("e2emv_ba_2view", B, N, _lib.ptr(k0), _lib.ptr(k1), _lib.ptr(cf), _lib.ptr(Ti), int(n_iterations),
+                 _lib.ptr(To), _lib.ptr(valid), _lib.stream_ptr(dev))
+    vb = valid.bool()
+    return To[vb], vb

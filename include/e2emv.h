@@ -153,6 +153,14 @@ int e2emv_w8pt(e2emv_ctx* ctx, int B, int N, const float* d_kpts0, const float* 
 int e2emv_pose_errors(e2emv_ctx* ctx, int B, const float* d_T, const float* d_T_gt, float* d_rot_err,
                       float* d_transl_err, void* stream);
 
+/* Two-view Levenberg-Marquardt bundle adjustment: run_bundle_adjust_2_view / BundleAdjustGaussNewton2View.run
+ * (estimate_relative_pose.py:138-144, bundle_adjust_gauss_newton_2_view.py:127-201) - the refinement the reference
+ * applies to the w8pt pose in its default eval mode.  d_kpts0n/d_kpts1n [B,N,2] intrinsics-normalised keypoints
+ * (info["kpts*_norm"]), d_conf [B,N] (entries <= 0 are ignored), d_T_init [B,4,4].  d_T_out [B,4,4] = best pose
+ * (copy of d_T_init where d_valid[b] == 0, i.e. fewer than 7 usable matches).                                  */
+int e2emv_ba_2view(e2emv_ctx* ctx, int B, int N, const float* d_kpts0n, const float* d_kpts1n, const float* d_conf,
+                   const float* d_T_init, int n_iterations, float* d_T_out, uint8_t* d_valid, void* stream);
+
 /* ---- building blocks exported for per-kernel parity tests and micro-benchmarks ----- */
 /* C[z][m][n] = act(sum_k A[z][m][k] W[z][n][k] * scale + bias[n]) (+ R[z][m][n]); all f32;
  * A may be split in two K-segments (A: k < K1, A2: K1 <= k < K).  flags: bit0 relu.        */

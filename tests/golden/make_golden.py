@@ -45,11 +45,17 @@ def install_reference_shims():
     kornia.geometry = geometry
     coloredlogs = types.ModuleType("coloredlogs")
     coloredlogs.install = lambda *a, **k: None
+    # pytorch3d 0.7.5 names used by the BA file (so3.hat, se3_exp_map): oracle/pytorch3d_fns.py restatement
+    from oracle import pytorch3d_fns as P3
     p3d = types.ModuleType("pytorch3d")
     p3d.transforms = types.ModuleType("pytorch3d.transforms")
+    so3 = types.ModuleType("pytorch3d.transforms.so3")
+    so3.hat = P3.hat
+    p3d.transforms.so3 = so3
+    p3d.transforms.se3_exp_map = P3.se3_exp_map
     sys.modules.update({"kornia": kornia, "kornia.geometry": geometry, "kornia.geometry.epipolar": epi,
                         "kornia.geometry.epipolar.projection": proj, "coloredlogs": coloredlogs, "pytorch3d": p3d,
-                        "pytorch3d.transforms": p3d.transforms})
+                        "pytorch3d.transforms": p3d.transforms, "pytorch3d.transforms.so3": so3})
     sys.path.insert(0, REF)
 
 
@@ -116,6 +122,36 @@ def gen_w8pt():
     out["names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "w8pt_reference.npz"), **out)
     print("w8pt_reference.npz", len(out), "arrays")
+
+
+def gen_ba():
+    """Two-view bundle adjustment: the reference's own BundleAdjustGaussNewton2View (10 LM iterations) after its w8pt."""
+    install_reference_shims()
+    import warnings
+    warnings.filterwarnings("ignore")
+    from pose_optimization.two_view import estimate_relative_pose as R
+    from oracle import ba2view as OB
+    out, names = {}, []
+    for (B, N, seed, noise) in [(3, 96, 5, 1.0), (3, 96, 6, 0.5), (2, 200, 7, 0.5), (2, 64, 8, 2.0)]:
+        k0, k1, K0, K1, conf, Tgt = w8pt_scene(B, N, seed, 0.2, 4, noise=noise)
+        if seed == 6:
+            conf[2, 5:] = 0.0  # a sample with fewer than 7 usable matches -> excluded (valid_batch False)
+        T, info = R.estimate_relative_pose_w8pt(k0, k1, K0, K1, conf.unsqueeze(-1), determine_inliers=True)
+        c = info["confidence"].clone()
+        c[torch.logical_not(info["pos_depth_mask"])] = 0.0  # eval_pairs.py:251-252
+        Tref, valid = R.run_bundle_adjust_2_view(info["kpts0_norm"], info["kpts1_norm"], c, T.clone(), n_iterations=10)
+        T64, _ = OB.run_bundle_adjust_2_view(info["kpts0_norm"].double(), info["kpts1_norm"].double(), c.squeeze(-1).double(),
+                                             T.clone().double(), 10)
+        name = f"B{B}_N{N}_s{seed}"
+        names.append(name)
+        out[f"{name}/kpts0_norm"], out[f"{name}/kpts1_norm"] = info["kpts0_norm"].numpy(), info["kpts1_norm"].numpy()
+        out[f"{name}/conf"], out[f"{name}/T_init"], out[f"{name}/T_gt"] = c.numpy(), T.numpy(), Tgt.numpy()
+        out[f"{name}/T_refined"], out[f"{name}/valid"] = Tref.numpy(), valid.numpy()
+        # how far the reference's fp32 LU run is from the same algorithm in fp64 (LM iterations amplify rounding)
+        out[f"{name}/ref_fp32_noise"] = (Tref.double() - T64).abs().amax((1, 2)).numpy()
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "ba2view_reference.npz"), **out)
+    print("ba2view_reference.npz", {n: out[f"{n}/ref_fp32_noise"].tolist() for n in names})
 
 
 def gen_sinkhorn_hf():
@@ -214,3 +250,4 @@ if __name__ == "__main__":
     gen_sinkhorn_hf()
     gen_superglue_hf()
     gen_w8pt()
+    gen_ba()

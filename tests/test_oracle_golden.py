@@ -137,3 +137,22 @@ def test_config1_plumbing_on_the_cpu_path():
     err = pair_errors(T.numpy(), data["T_0to1"].numpy())
     assert np.all(err < 5.0)
     assert pose_auc(err, [5, 10, 20])[2] > 0.9
+
+
+def test_bundle_adjust_2_view_matches_the_reference_class():
+    """oracle/ba2view.py vs the reference's own BundleAdjustGaussNewton2View (golden).  Ten LM iterations amplify
+    fp32 rounding, so the bar per sample is 2e-4 plus twice the distance between the reference's fp32 run and the
+    same algorithm in fp64 (stored in the golden as ref_fp32_noise)."""
+    from oracle import ba2view as OB
+    z = np.load(os.path.join(G, "ba2view_reference.npz"))
+    for name in [str(n) for n in z["names"]]:
+        t = lambda k: torch.from_numpy(z[f"{name}/{k}"])
+        T, valid = OB.run_bundle_adjust_2_view(t("kpts0_norm"), t("kpts1_norm"), t("conf"), t("T_init"), 10)
+        assert np.array_equal(valid.numpy(), z[f"{name}/valid"]), name
+        noise = torch.from_numpy(z[f"{name}/ref_fp32_noise"])
+        d = (T - t("T_refined")).abs().amax((1, 2)).double()
+        assert bool((d < 2e-4 + 2 * noise).all()), (name, d.tolist(), noise.tolist())
+        T64, _ = OB.run_bundle_adjust_2_view(t("kpts0_norm").double(), t("kpts1_norm").double(), t("conf").double(),
+                                             t("T_init").double(), 10)
+        assert float(((T64 - t("T_refined").double()).abs().amax((1, 2)) - noise).abs().max()) < 1e-9
+    assert not z["B3_N96_s6/valid"].all()  # the < 7 matches sample is excluded like the reference does
