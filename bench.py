@@ -156,13 +156,11 @@ def main():
             tt = torch.tensor([alt_elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             alt_elapsed = float(tt.item())
-        res32 = None
         ctx.call("e2emv_set_precision", _lib.PRECISION_F32)
         alt = {"ms_per_step": round(1000.0 * alt_elapsed / args.steps, 3),
                "value": round(B * len(pairs) * world * args.steps / alt_elapsed, 2), "unit": "pairs/s",
                "note": "same workload with e2emv_set_precision(BF16X3): q|k|v emitted as three bf16 planes, attention = 6 "
                        "bf16-MFMA products per block accumulated in fp32 (fp32-class accuracy, parity tests run both modes)"}
-        del res32
 
     # ---- AUC leg (not timed): identity-like weights give real matches; errors gathered over ranks
     _, errs = step(model_id)
@@ -216,12 +214,10 @@ def main():
             out["sinkhorn_roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": round(gbs / PEAK_HBM_GBS, 4),
                                         "note": "algorithmic bytes (2 sweeps/iter model) / time; the kernel streams S once per iteration"}
-        other = sorted(((v["ms"], k) for k, v in prof.items() if k not in ("gemm", "attention")), reverse=True)
         fam2 = "attention" if fam == "gemm" else "gemm"
         a2 = fl[fam2] * args.steps / (prof[fam2]["ms"] * 1e-3) / 1e12
         out["roofline_second"] = {"kernel": fam2, "achieved": round(a2, 2), "unit": "TFLOP/s",
                                   "frac": round(a2 / PEAK_F32_MFMA_TFLOPS, 4)}
-        del other
 
     # ---- CPU baseline: the oracle (torch CPU, same unfused op sequence as the reference) on a bounded sample
     if world == 1 and args.cpu_pairs > 0:

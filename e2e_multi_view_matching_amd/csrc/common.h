@@ -14,8 +14,6 @@
 
 namespace e2emv {
 
-constexpr int kWave = 64;  // CDNA wavefront
-
 // profile slots (kernel families)
 enum ProfSlot {
     PS_INGEST = 0,
@@ -117,22 +115,9 @@ int set_err(e2emv_ctx* ctx, int code, const char* fmt, ...);
             return e2emv::set_err(ctx, E2EMV_EHIP, "launch of %s failed: %s", what, hipGetErrorString(_e)); \
     } while (0)
 
-// workspace: returns a device pointer to at least `bytes` (256-B aligned); grows the arena
-// (synchronising) when needed.  The arena is carved by a bump offset per top-level call.
+// workspace: makes ctx->d_ws at least `bytes` large, growing the arena (synchronising) when needed; each
+// top-level entry point carves it with 256-byte aligned offsets.
 int ws_reserve(e2emv_ctx* ctx, size_t bytes);
-
-struct WsBump {
-    e2emv_ctx* ctx;
-    size_t off = 0;
-    explicit WsBump(e2emv_ctx* c) : ctx(c) {}
-    template <typename T>
-    T* take(size_t n) {
-        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
-        T* p = reinterpret_cast<T*>(ctx->d_ws + off);
-        off += bytes;
-        return p;
-    }
-};
 
 // RAII-less profiling bracket
 void prof_begin(e2emv_ctx* ctx, int slot, hipStream_t s);
