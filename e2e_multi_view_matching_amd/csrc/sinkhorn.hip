@@ -85,7 +85,9 @@ struct SkParams {
 };
 
 // One sweep of S: u for 16 rows + column partials of S + u.  KT = ceil(ldS / 256).
-template <int KT, bool FINAL>
+// FULL = (N == ldS == KT*256): every lane owns valid columns only, so the per-element column guards (which
+// hipcc turns into ~90 exec-mask branches) disappear - the case of the 256/512/1024/2048-keypoint configs.
+template <int KT, bool FINAL, bool FULL>
 __global__ __launch_bounds__(256) void sinkhorn_sweep(SkParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][2][KT*256]
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep(SkParams p) {
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         col[k] = 4 * (lane + 64 * k);
-        f32x4 t = (col[k] < p.ldS) ? *reinterpret_cast<const f32x4*>(vb + col[k]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 t = (FULL || col[k] < p.ldS) ? *reinterpret_cast<const f32x4*>(vb + col[k]) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) vv[k][e] = t[e];
     }
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep(SkParams p) {
         const int row = min(row0 + r, p.M - 1);
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-            f32x4 t = (col[k] < p.ldS) ? *reinterpret_cast<const f32x4*>(Sb + (int64_t)row * p.ldS + col[k])
+            f32x4 t = (FULL || col[k] < p.ldS) ? *reinterpret_cast<const f32x4*>(Sb + (int64_t)row * p.ldS + col[k])
                                        : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[r][k][e] = t[e];
@@ -138,14 +140,14 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep(SkParams p) {
             for (int k = 0; k < KT; ++k)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (col[k] + e < p.N) mx = fmaxf(mx, z[r][k][e] + vv[k][e]);
+                    if (FULL || col[k] + e < p.N) mx = fmaxf(mx, z[r][k][e] + vv[k][e]);
             mx = wave_max(mx);
             float sm = 0.f;
 #pragma unroll
             for (int k = 0; k < KT; ++k)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (col[k] + e < p.N) sm += __expf(z[r][k][e] + vv[k][e] - mx);
+                    if (FULL || col[k] + e < p.N) sm += __expf(z[r][k][e] + vv[k][e] - mx);
             sm = wave_sum(sm) + __expf(p.alpha + vN - mx);
             ur[r] = p.norm - (mx + __logf(sm));
             if (rvalid && lane == 0) p.u[(int64_t)b * (p.M + 1) + row0 + r] = ur[r];
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void sinkhorn_sweep(SkParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int j = col[k] + e;
-                    if (j < p.N) {
+                    if (FULL || j < p.N) {
                         // same association as the reference: ((couplings + u) + v) - norm
                         const float zz = ((z[r][k][e] + ur[r]) + vv[k][e]) - p.norm;
                         if (rvalid) {
@@ -462,10 +464,14 @@ size_t sinkhorn_ws_bytes(int B, int M, int N) {
 template <int KT>
 static void launch_sweeps(const SkParams& p, int B, bool final, hipStream_t s) {
     const size_t lds = sizeof(float) * 8 * KT * 256;
-    if (!final)
-        hipLaunchKernelGGL((sinkhorn_sweep<KT, false>), dim3(p.chunks, B), dim3(256), lds, s, p);
-    else
-        hipLaunchKernelGGL((sinkhorn_sweep<KT, true>), dim3(p.chunks + 1, B), dim3(256), lds, s, p);
+    const bool full = p.N == p.ldS && p.N == KT * 256;
+    if (!final) {
+        if (full) hipLaunchKernelGGL((sinkhorn_sweep<KT, false, true>), dim3(p.chunks, B), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((sinkhorn_sweep<KT, false, false>), dim3(p.chunks, B), dim3(256), lds, s, p);
+    } else {
+        if (full) hipLaunchKernelGGL((sinkhorn_sweep<KT, true, true>), dim3(p.chunks + 1, B), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((sinkhorn_sweep<KT, true, false>), dim3(p.chunks + 1, B), dim3(256), lds, s, p);
+    }
 }
 
 int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t ldS, float alpha, int iters,
