@@ -201,9 +201,22 @@ def main():
         fam = max(("gemm", "attention"), key=lambda k: prof[k]["ms"])
         ms, n = prof[fam]["ms"], prof[fam]["launches"]
         achieved = fl[fam] * args.steps / (ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": {"gemm": "gemm_nt_kernel", "attention": "attention_kernel"}[fam],
+        kname = {"gemm": "gemm_nt_kernel", "attention": "attention_kernel"}[fam]
+        # HBM bytes per launch of that kernel from the rocprofv3 --pmc passes of this same command (FETCH_SIZE x 2 per
+        # MI355X_MICROARCH.md, calibrated on sinkhorn_sweep's known byte count) - profiles/summarize_pmc.py
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                k = json.load(fh)["kernels"][kname]
+            traffic = int(k["read_bytes"] + k["write_bytes"])
+        except Exception:
+            traffic = None
+        out["roofline"] = {"bound": "mfma", "kernel": kname,
                            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                           "traffic_note": "HBM bytes per launch (read + write), PMC passes committed under profiles/; "
+                                           "algorithmic flops include the merge conv that is folded into MLP0 (executed "
+                                           "flops are 18/20 of algorithmic)",
                            "avg_launch_ms": round(ms / max(n, 1), 4), "launches_per_step": n // args.steps}
         sk = prof["sinkhorn"]
         sk_bytes = B * P * (2 * args.sinkhorn_iters + 2) * (N + 1) ** 2 * 4
