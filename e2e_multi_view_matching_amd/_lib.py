@@ -32,7 +32,8 @@ class ForwardDesc(ctypes.Structure):
     _fields_ = [("batch", ctypes.c_int32), ("tuple_size", ctypes.c_int32), ("n_kpts", ctypes.c_int32),
                 ("sinkhorn_iters", ctypes.c_int32), ("match_threshold", ctypes.c_float),
                 ("desc_dtype", ctypes.c_int32), ("flags", ctypes.c_int32),
-                ("img_w", ctypes.c_float * MAX_TUPLE), ("img_h", ctypes.c_float * MAX_TUPLE)]
+                ("img_w", ctypes.c_float * MAX_TUPLE), ("img_h", ctypes.c_float * MAX_TUPLE),
+                ("n_kpts_img", ctypes.c_int32 * MAX_TUPLE)]
 
 
 # every symbol include/e2emv.h declares: name -> (restype, argtypes)

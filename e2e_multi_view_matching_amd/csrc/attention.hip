@@ -18,6 +18,7 @@
 // MFMAs through the same K-slot permutation as gemm.hip); V tiles unpadded (ds_read_b32 of
 // 32 consecutive floats).  128 MFMAs (8192 cycles) per wave per 64-key tile against ~1.3k
 // VALU cycles of softmax: the kernel is MFMA-issue bound by construction.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -35,7 +36,8 @@ constexpr int KLD = 68;      // padded K row (floats)
 struct AttnParams {
     const float* qkv;
     float* out;
-    int B, T, n_rows, n_valid, D, H, cross;
+    int B, T, n_rows, D, H, cross;
+    int nv[E2EMV_MAX_TUPLE];  // valid keypoints (queries and keys) of image t of a tuple
     int nq, groups, gper;
 };
 
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
     const int qt = idx % p.nq;
     const int img = g / p.H, head = g % p.H;
     const int b = img / p.T, t = img % p.T;
+    if (qt * ATT_Q >= p.nv[t]) return;  // shorter image of a ragged tuple: no queries in this tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -77,21 +80,29 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
     float m_run = -1e30f, l_run = 0.f;
 
     const int n_src = p.cross ? p.T - 1 : 1;
-    const int tiles_per_img = (p.n_valid + ATT_KV - 1) / ATT_KV;
-    const int n_tiles = n_src * tiles_per_img;
+    auto src_t = [&](int si) { return !p.cross ? t : (si < t ? si : si + 1); };
+    int n_tiles = 0;
+    for (int si = 0; si < n_src; ++si) n_tiles += (p.nv[src_t(si)] + ATT_KV - 1) / ATT_KV;
+    // linear key-tile index -> (source image of the tuple, tile inside it); sources may differ in length
+    auto locate = [&](int tile, int& tt, int& kt) {
+        int si = 0;
+        for (;; ++si) {
+            const int n = (p.nv[src_t(si)] + ATT_KV - 1) / ATT_KV;
+            if (tile < n || si + 1 == n_src) break;
+            tile -= n;
+        }
+        tt = src_t(si);
+        kt = tile;
+    };
 
     // staging map: 4 float4 of K and of V per thread
     const int st_row = tid >> 4;         // 0..15 (+16*i)
     const int st_c4 = (tid & 15) * 4;
     f32x4 rk[4], rv[4];
-    auto src_img = [&](int si) {
-        if (!p.cross) return img;
-        int tt = si < t ? si : si + 1;
-        return b * p.T + tt;
-    };
     auto gload = [&](int tile) {
-        const int si = tile / tiles_per_img, kt = tile % tiles_per_img;
-        const float* base = p.qkv + src_img(si) * img_stride + (int64_t)(kt * ATT_KV) * row_stride + head * HD + st_c4;
+        int tt, kt;
+        locate(tile, tt, kt);
+        const float* base = p.qkv + (b * p.T + tt) * img_stride + (int64_t)(kt * ATT_KV) * row_stride + head * HD + st_c4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float* rp = base + (int64_t)(st_row + 16 * i) * row_stride;
@@ -113,8 +124,9 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
         if (tile + 1 < n_tiles) gload(tile + 1);
         }
 
-        const int kt = tile % tiles_per_img;
-        const int valid_in_tile = p.n_valid - kt * ATT_KV;  // >= 1
+        int tt_cur, kt;
+        locate(tile, tt_cur, kt);
+        const int valid_in_tile = p.nv[tt_cur] - kt * ATT_KV;  // >= 1
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             if (sub * 32 >= valid_in_tile) break;  // wave-uniform
@@ -179,14 +191,20 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
     }
 }
 
-int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* qkv,
+int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, int D, int H, const float* qkv,
                      int cross, float* out, hipStream_t s) {
+    int n_valid = 0;
+    for (int t = 0; t < T; ++t) {
+        if (nv[t] <= 0 || nv[t] > n_rows) return set_err(ctx, E2EMV_ESHAPE, "attention: image %d has %d keypoints (n_rows %d)", t, nv[t], n_rows);
+        n_valid = std::max(n_valid, nv[t]);
+    }
     if (D != H * HD) return set_err(ctx, E2EMV_ESHAPE, "attention: head dim must be 64 (D=%d H=%d)", D, H);
     if (n_rows % ATT_Q || n_valid <= 0 || n_valid > n_rows)
         return set_err(ctx, E2EMV_ESHAPE, "attention: n_rows=%d must be a multiple of %d and >= n_valid=%d", n_rows, ATT_Q, n_valid);
     if (cross && T < 2) return set_err(ctx, E2EMV_ESHAPE, "attention: cross layer needs T >= 2");
     AttnParams p;
-    p.qkv = qkv; p.out = out; p.B = B; p.T = T; p.n_rows = n_rows; p.n_valid = n_valid; p.D = D; p.H = H;
+    p.qkv = qkv; p.out = out; p.B = B; p.T = T; p.n_rows = n_rows; p.D = D; p.H = H;
+    for (int t = 0; t < E2EMV_MAX_TUPLE; ++t) p.nv[t] = t < T ? nv[t] : 0;
     p.cross = cross;
     p.nq = (n_valid + ATT_Q - 1) / ATT_Q;
     p.groups = B * T * H;
@@ -212,7 +230,10 @@ extern "C" int e2emv_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_v
                                int cross, float* d_out, void* stream) {
     if (!ctx || !d_qkv || !d_out) return E2EMV_EINVAL;
     e2emv::prof_begin(ctx, e2emv::PS_ATTN, (hipStream_t)stream);
-    int rc = e2emv::launch_attention(ctx, B, T, n_rows, n_valid, D, H, d_qkv, cross, d_out, (hipStream_t)stream);
+    if (T < 1 || T > E2EMV_MAX_TUPLE) return E2EMV_EINVAL;
+    int nv[E2EMV_MAX_TUPLE];
+    for (int t = 0; t < E2EMV_MAX_TUPLE; ++t) nv[t] = n_valid;
+    int rc = e2emv::launch_attention(ctx, B, T, n_rows, nv, D, H, d_qkv, cross, d_out, (hipStream_t)stream);
     e2emv::prof_end(ctx, (hipStream_t)stream);
     return rc;
 }

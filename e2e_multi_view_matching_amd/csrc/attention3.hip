@@ -11,6 +11,7 @@
 // registers 8u..8u+7 of a lane are exactly the 8 K-slots that lane must supply for the u-th
 // 16-key MFMA, provided the V^T tile is stored in LDS with the matching key order inside each
 // 16-key group (pos = (k&3) + 4*((k>>3)&1) + 8*((k>>2)&1)) - so P never leaves its lane.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -33,7 +34,8 @@ struct Attn3Params {
     const uint16_t* vt;   // [n_img][3][D][n_rows]
     uint16_t* out;        // S3 [n_img*n_rows][3][D] or null
     float* out32;         // fp32 [n_img*n_rows][D] or null
-    int B, T, n_rows, n_valid, D, H, cross;
+    int B, T, n_rows, D, H, cross;
+    int nv[E2EMV_MAX_TUPLE];  // valid keypoints (queries and keys) of image t of a tuple
     int nq, groups, gper;
 };
 
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Params p) {
     const int qt = idx % p.nq;
     const int img = g / p.H, head = g % p.H;
     const int b = img / p.T, t = img % p.T;
+    if (qt * A3_Q >= p.nv[t]) return;  // shorter image of a ragged tuple: no queries in this tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -79,20 +82,28 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Params p) {
     float m_run = -1e30f, l_run = 0.f;
 
     const int n_src = p.cross ? p.T - 1 : 1;
-    const int tiles_per_img = (p.n_valid + A3_KV - 1) / A3_KV;
-    const int n_tiles = n_src * tiles_per_img;
+    auto src_t = [&](int si) { return !p.cross ? t : (si < t ? si : si + 1); };
+    int n_tiles = 0;
+    for (int si = 0; si < n_src; ++si) n_tiles += (p.nv[src_t(si)] + A3_KV - 1) / A3_KV;
+    // linear key-tile index -> (source image of the tuple, tile inside it); sources may differ in length
+    auto locate = [&](int tile, int& tt, int& kt) {
+        int si = 0;
+        for (;; ++si) {
+            const int n = (p.nv[src_t(si)] + A3_KV - 1) / A3_KV;
+            if (tile < n || si + 1 == n_src) break;
+            tile -= n;
+        }
+        tt = src_t(si);
+        kt = tile;
+    };
 
     // staging: 6 x 16-byte chunks of K and of V^T per thread: chunk i -> plane i>>1, row tid/8 + 32*(i&1), chunk tid&7
     const int st_row = tid >> 3, st_ch = tid & 7;
     u32x4 rk[6], rv[6];
-    auto src_img = [&](int si) {
-        if (!p.cross) return img;
-        const int tt = si < t ? si : si + 1;
-        return b * p.T + tt;
-    };
     auto gload = [&](int tile) {
-        const int si = tile / tiles_per_img, kt = tile % tiles_per_img;
-        const int simg = src_img(si);
+        int tt, kt;
+        locate(tile, tt, kt);
+        const int simg = b * p.T + tt;
         const uint16_t* kbase = p.qk + ((int64_t)simg * p.n_rows + kt * A3_KV) * qk_row + p.D + head * A3_HD + st_ch * 8;
         const uint16_t* vbase = p.vt + ((int64_t)simg * 3 * p.D + head * A3_HD) * p.n_rows + kt * A3_KV + st_ch * 8;
 #pragma unroll
@@ -125,8 +136,9 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Params p) {
         __syncthreads();
         if (tile + 1 < n_tiles) gload(tile + 1);
 
-        const int kt = tile % tiles_per_img;
-        const int valid_in_tile = p.n_valid - kt * A3_KV;
+        int tt_cur, kt;
+        locate(tile, tt_cur, kt);
+        const int valid_in_tile = p.nv[tt_cur] - kt * A3_KV;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             if (sub * 32 >= valid_in_tile) break;
@@ -225,14 +237,20 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Params p) {
     }
 }
 
-int launch_attention3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const uint16_t* qk,
+int launch_attention3(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, int D, int H, const uint16_t* qk,
                       const uint16_t* vt, int cross, uint16_t* out3, float* out32, hipStream_t s) {
+    int n_valid = 0;
+    for (int t = 0; t < T; ++t) {
+        if (nv[t] <= 0 || nv[t] > n_rows) return set_err(ctx, E2EMV_ESHAPE, "attention3: image %d has %d keypoints (n_rows %d)", t, nv[t], n_rows);
+        n_valid = std::max(n_valid, nv[t]);
+    }
     if (D != H * A3_HD) return set_err(ctx, E2EMV_ESHAPE, "attention3: head dim must be 64 (D=%d H=%d)", D, H);
     if (n_rows % A3_Q || n_valid <= 0 || n_valid > n_rows)
         return set_err(ctx, E2EMV_ESHAPE, "attention3: n_rows=%d must be a multiple of %d and >= n_valid=%d", n_rows, A3_Q, n_valid);
     if (cross && T < 2) return set_err(ctx, E2EMV_ESHAPE, "attention3: cross layer needs T >= 2");
     Attn3Params p;
-    p.qk = qk; p.vt = vt; p.out = out3; p.out32 = out32; p.B = B; p.T = T; p.n_rows = n_rows; p.n_valid = n_valid; p.D = D; p.H = H;
+    p.qk = qk; p.vt = vt; p.out = out3; p.out32 = out32; p.B = B; p.T = T; p.n_rows = n_rows; p.D = D; p.H = H;
+    for (int t = 0; t < E2EMV_MAX_TUPLE; ++t) p.nv[t] = t < T ? nv[t] : 0;
     p.cross = cross;
     p.nq = (n_valid + A3_Q - 1) / A3_Q;
     p.groups = B * T * H;

@@ -148,7 +148,7 @@ struct GemmArgs {
 };
 int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s);
 
-int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* qkv,
+int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, const int* n_valid_img, int D, int H, const float* qkv,
                      int cross, float* out, hipStream_t s);
 
 // ---- bf16x3 split-operand path (gemm3.hip / attention3.hip): fp32-class accuracy on the bf16 pipe ----
@@ -177,7 +177,7 @@ struct Gemm3Args {
 int launch_gemm3(e2emv_ctx* ctx, const Gemm3Args& a, hipStream_t s);
 int launch_split3(e2emv_ctx* ctx, const float* src, int64_t rows, int C, int64_t ld_src, uint16_t* dst, int64_t ld,
                   hipStream_t s);
-int launch_attention3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const uint16_t* qk,
+int launch_attention3(e2emv_ctx* ctx, int B, int T, int n_rows, const int* n_valid_img, int D, int H, const uint16_t* qk,
                       const uint16_t* vt, int cross, uint16_t* out3, float* out32, hipStream_t s);
 
 // Sinkhorn on an internal score buffer S [n_groups * group_batch][M][ldS] (ldS % 4 == 0).  Batch

@@ -14,6 +14,8 @@
 // Rows >= N are zeroed at ingest and stay finite; attention masks them as keys.
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace e2emv {
@@ -25,7 +27,8 @@ struct IngestParams {
     const float* ksc[E2EMV_MAX_TUPLE];
     const void* desc[E2EMV_MAX_TUPLE];
     float img_w[E2EMV_MAX_TUPLE], img_h[E2EMV_MAX_TUPLE];
-    int B, T, N, n_rows, D, c0, f16;
+    int B, T, n_rows, D, c0, f16;
+    int Nimg[E2EMV_MAX_TUPLE];  // keypoints of image t
     const float* w0;
     const float* b0;
     float* x0;
@@ -41,8 +44,8 @@ __global__ __launch_bounds__(256) void ingest_transpose(IngestParams p) {
     const int n = n0 + tx;
     for (int dd = ty; dd < 64; dd += 4) {
         float v = 0.f;
-        if (n < p.N) {
-            const int64_t o = ((int64_t)b * p.D + d0 + dd) * p.N + n;
+        if (n < p.Nimg[t]) {
+            const int64_t o = ((int64_t)b * p.D + d0 + dd) * p.Nimg[t] + n;
             v = p.f16 ? __half2float(reinterpret_cast<const __half*>(p.desc[t])[o])
                       : reinterpret_cast<const float*>(p.desc[t])[o];
         }
@@ -59,15 +62,16 @@ __global__ __launch_bounds__(256) void ingest_kenc0(IngestParams p) {
     if (row >= p.n_rows) return;
     const int b = img / p.T, t = img % p.T;
     float* out = p.h0 + ((int64_t)img * p.n_rows + row) * p.c0;
-    if (row >= p.N) {
+    const int Nn = p.Nimg[t];
+    if (row >= Nn) {
         for (int c = 0; c < p.c0; c += 4) *reinterpret_cast<f32x4*>(out + c) = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
     }
     const float W = p.img_w[t], H = p.img_h[t];
     const float sc = fmaxf(W, H) * 0.7f;
-    const float kx = (p.kpts[t][((int64_t)b * p.N + row) * 2] - W / 2) / sc;
-    const float ky = (p.kpts[t][((int64_t)b * p.N + row) * 2 + 1] - H / 2) / sc;
-    const float ks = p.ksc[t][(int64_t)b * p.N + row];
+    const float kx = (p.kpts[t][((int64_t)b * Nn + row) * 2] - W / 2) / sc;
+    const float ky = (p.kpts[t][((int64_t)b * Nn + row) * 2 + 1] - H / 2) / sc;
+    const float ks = p.ksc[t][(int64_t)b * Nn + row];
     for (int c = 0; c < p.c0; c += 4) {
         f32x4 o;
 #pragma unroll
@@ -127,13 +131,22 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
                          const float* const* d_kscores, const void* const* d_desc, float* const* d_logZ,
                          int64_t* const* d_m0, int64_t* const* d_m1, float* const* d_ms0, float* const* d_ms1,
                          float* const* d_conf, hipStream_t s) {
-    const int B = fd->batch, T = fd->tuple_size, N = fd->n_kpts;
+    const int B = fd->batch, T = fd->tuple_size;
     const int D = ctx->model.desc_dim, H = ctx->model.num_heads;
+    // per-image keypoint counts (eval_pairs.py feeds images with different numbers of keypoints)
+    int Nt[E2EMV_MAX_TUPLE] = {0};
+    int N = 0;
+    bool uniform = true;
+    for (int t = 0; t < T; ++t) {
+        Nt[t] = fd->n_kpts_img[t] > 0 ? fd->n_kpts_img[t] : fd->n_kpts;
+        N = std::max(N, Nt[t]);
+        uniform = uniform && Nt[t] == Nt[0];
+    }
     const int n_rows = round_up(N, 128);
     const int n_img = B * T;
     const int64_t Mtot = (int64_t)n_img * n_rows;
     const int P = T * (T - 1) / 2;
-    const int ldS = round_up(N, 4);
+    const int ldS = round_up(N, 4);  // allocation stride; a pair (i, j) uses ld = round_up(N_j, 4)
     const bool full = (fd->flags & E2EMV_FLAG_FULL_OUTPUT) != 0;
 
     // ---- workspace ----
@@ -183,7 +196,8 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         ip.kpts[t] = d_kpts[t]; ip.ksc[t] = d_kscores[t]; ip.desc[t] = d_desc[t];
         ip.img_w[t] = fd->img_w[t]; ip.img_h[t] = fd->img_h[t];
     }
-    ip.B = B; ip.T = T; ip.N = N; ip.n_rows = n_rows; ip.D = D; ip.c0 = c0; ip.f16 = fd->desc_dtype == E2EMV_DESC_F16;
+    for (int t = 0; t < T; ++t) ip.Nimg[t] = Nt[t];
+    ip.B = B; ip.T = T; ip.n_rows = n_rows; ip.D = D; ip.c0 = c0; ip.f16 = fd->desc_dtype == E2EMV_DESC_F16;
     ip.w0 = ctx->kenc_w0; ip.b0 = ctx->kenc_b0; ip.x0 = x; ip.h0 = hid;
     prof_begin(ctx, PS_INGEST, s);
     hipLaunchKernelGGL(ingest_transpose, dim3(n_rows / 64, D / 64, n_img), dim3(256), 0, s, ip);
@@ -229,7 +243,7 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
             prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
             if (rc) return rc;
             prof_begin(ctx, PS_ATTN, s);
-            rc = launch_attention3(ctx, B, T, n_rows, N, D, H, qk3, vt3, L.type, nullptr, att, s);
+            rc = launch_attention3(ctx, B, T, n_rows, Nt, D, H, qk3, vt3, L.type, nullptr, att, s);
             prof_end(ctx, s);
             if (rc) return rc;
         } else {
@@ -240,7 +254,7 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
         if (rc) return rc;
         prof_begin(ctx, PS_ATTN, s);
-        rc = launch_attention(ctx, B, T, n_rows, N, D, H, qkv, L.type, att, s);
+        rc = launch_attention(ctx, B, T, n_rows, Nt, D, H, qkv, L.type, att, s);
         prof_end(ctx, s);
         if (rc) return rc;
         }
@@ -278,47 +292,69 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         if (rc) return rc;
     }
 
-    // ---- all pairs: scores -> ONE Sinkhorn over P*B problems -> matches; then the conf head per pair ----
+    // ---- all pairs: scores -> Sinkhorn -> matches; then the conf head per pair.  With equal keypoint counts all
+    // P*B problems go through ONE Sinkhorn batch; a ragged tuple runs one batch per pair (M = N_i, N = N_j).
     const int64_t tuple_stride = (int64_t)T * n_rows * D;
+    const int64_t pair_stride = (int64_t)B * N * ldS;
     SinkhornOut so;
     so.n_groups = P;
     so.group_batch = B;
     std::vector<bool> want_conf(P, false);
+    std::vector<int64_t*> pm0(P, nullptr);
+    std::vector<float*> pms0(P, nullptr);
     int pidx = 0;
     for (int j = 0; j < T; ++j)
         for (int i = 0; i < j; ++i, ++pidx) {
+            const int Ni = Nt[i], Nj = Nt[j], ldj = round_up(Nj, 4);
             GemmArgs g;
-            g.batch = B; g.M = N; g.N = N; g.K = D; g.K1 = D;
+            g.batch = B; g.M = Ni; g.N = Nj; g.K = D; g.K1 = D;
             g.A = mdesc + (int64_t)i * n_rows * D; g.lda = D; g.sA = tuple_stride;
             g.W = mdesc + (int64_t)j * n_rows * D; g.ldw = D; g.sW = tuple_stride;
-            g.C = S + (int64_t)pidx * B * N * ldS; g.ldc = ldS; g.sC = (int64_t)N * ldS;
+            g.C = S + pidx * pair_stride; g.ldc = ldj; g.sC = (int64_t)Ni * ldj;
             g.scale = 1.0f / sqrtf((float)D);
             prof_begin(ctx, PS_SCORE, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
             if (rc) return rc;
             want_conf[pidx] = full && d_conf && d_conf[pidx];
-            so.logZ[pidx] = d_logZ ? d_logZ[pidx] : nullptr;
+            SinkhornOut one;  // outputs of this pair
+            one.logZ[0] = d_logZ ? d_logZ[pidx] : nullptr;
             if (full) {
-                so.m0[pidx] = (d_m0 && d_m0[pidx]) ? d_m0[pidx] : (want_conf[pidx] ? tmp_m0[pidx] : nullptr);
-                so.m1[pidx] = d_m1 ? d_m1[pidx] : nullptr;
-                so.ms0[pidx] = (d_ms0 && d_ms0[pidx]) ? d_ms0[pidx] : (want_conf[pidx] ? tmp_ms0[pidx] : nullptr);
-                so.ms1[pidx] = d_ms1 ? d_ms1[pidx] : nullptr;
+                one.m0[0] = (d_m0 && d_m0[pidx]) ? d_m0[pidx] : (want_conf[pidx] ? tmp_m0[pidx] : nullptr);
+                one.m1[0] = d_m1 ? d_m1[pidx] : nullptr;
+                one.ms0[0] = (d_ms0 && d_ms0[pidx]) ? d_ms0[pidx] : (want_conf[pidx] ? tmp_ms0[pidx] : nullptr);
+                one.ms1[0] = d_ms1 ? d_ms1[pidx] : nullptr;
+            }
+            pm0[pidx] = one.m0[0];
+            pms0[pidx] = one.ms0[0];
+            so.logZ[pidx] = one.logZ[0]; so.m0[pidx] = one.m0[0]; so.m1[pidx] = one.m1[0];
+            so.ms0[pidx] = one.ms0[0]; so.ms1[pidx] = one.ms1[0];
+            if (!uniform) {
+                one.n_groups = 1;
+                one.group_batch = B;
+                prof_begin(ctx, PS_SINKHORN, s);
+                rc = launch_sinkhorn(ctx, B, Ni, Nj, S + pidx * pair_stride, ldj, ctx->bin_score, fd->sinkhorn_iters,
+                                     fd->match_threshold, one, skws, s);
+                prof_end(ctx, s);
+                if (rc) return rc;
             }
         }
-    prof_begin(ctx, PS_SINKHORN, s);
-    rc = launch_sinkhorn(ctx, P * B, N, N, S, ldS, ctx->bin_score, fd->sinkhorn_iters, fd->match_threshold, so, skws, s);
-    prof_end(ctx, s);
-    if (rc) return rc;
+    if (uniform) {
+        prof_begin(ctx, PS_SINKHORN, s);
+        rc = launch_sinkhorn(ctx, P * B, N, N, S, ldS, ctx->bin_score, fd->sinkhorn_iters, fd->match_threshold, so, skws, s);
+        prof_end(ctx, s);
+        if (rc) return rc;
+    }
     pidx = 0;
     for (int j = 0; j < T; ++j)
         for (int i = 0; i < j; ++i, ++pidx) {
             if (!want_conf[pidx]) continue;
+            const int Ni = Nt[i];
             const bool use_mlp = ctx->model.conf_mlp != 0;
             float* gathered = msg;          // [B][n_rows][D]
             float* chid = hid;              // [B][n_rows][D]
             if (use_mlp) {
                 prof_begin(ctx, PS_CONF, s);
-                hipLaunchKernelGGL(conf_gather_kernel, dim3((n_rows + 3) / 4, B), dim3(256), 0, s, N, n_rows, D,
-                                   mdesc + (int64_t)j * n_rows * D, tuple_stride, so.m0[pidx], gathered);
+                hipLaunchKernelGGL(conf_gather_kernel, dim3((n_rows + 3) / 4, B), dim3(256), 0, s, Ni, n_rows, D,
+                                   mdesc + (int64_t)j * n_rows * D, tuple_stride, pm0[pidx], gathered);
                 prof_end(ctx, s);
                 GemmArgs c;
                 c.batch = B; c.M = n_rows; c.N = D; c.K = 2 * D; c.K1 = D;
@@ -330,8 +366,8 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
                 if (rc) return rc;
             }
             prof_begin(ctx, PS_CONF, s);
-            hipLaunchKernelGGL(conf_final_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, N, n_rows, D, chid, ctx->w_conf1,
-                               ctx->b_conf1, so.m0[pidx], so.ms0[pidx], use_mlp ? 1 : 0, d_conf[pidx]);
+            hipLaunchKernelGGL(conf_final_kernel, dim3((Ni + 3) / 4, B), dim3(256), 0, s, Ni, n_rows, D, chid, ctx->w_conf1,
+                               ctx->b_conf1, pm0[pidx], pms0[pidx], use_mlp ? 1 : 0, d_conf[pidx]);
             prof_end(ctx, s);
             E2EMV_CHECK_LAUNCH(ctx, "conf kernels");
         }
@@ -344,9 +380,12 @@ extern "C" int e2emv_matcher_forward(e2emv_ctx* ctx, const e2emv_forward_desc* f
                                      float* const* d_mscores1, float* const* d_conf, void* stream) {
     if (!ctx || !fd || !d_kpts || !d_kscores || !d_desc) return E2EMV_EINVAL;
     if (!ctx->committed) return set_err(ctx, E2EMV_ESTATE, "matcher_forward: weights not committed");
-    const int B = fd->batch, T = fd->tuple_size, N = fd->n_kpts;
+    const int B = fd->batch, T = fd->tuple_size;
     if (B <= 0 || T < 2 || T > E2EMV_MAX_TUPLE) return set_err(ctx, E2EMV_ESHAPE, "matcher_forward: batch=%d tuple_size=%d", B, T);
-    if (N <= 0 || N > 2048) return set_err(ctx, E2EMV_ESHAPE, "matcher_forward: n_kpts=%d not in [1, 2048]", N);
+    for (int t = 0; t < T; ++t) {
+        const int n = fd->n_kpts_img[t] > 0 ? fd->n_kpts_img[t] : fd->n_kpts;
+        if (n <= 0 || n > 2048) return set_err(ctx, E2EMV_ESHAPE, "matcher_forward: image %d has n_kpts=%d, not in [1, 2048]", t, n);
+    }
     if (fd->desc_dtype != E2EMV_DESC_F32 && fd->desc_dtype != E2EMV_DESC_F16) return set_err(ctx, E2EMV_EINVAL, "bad desc_dtype");
     if (fd->sinkhorn_iters < 0) return set_err(ctx, E2EMV_EINVAL, "negative sinkhorn_iters");
     for (int t = 0; t < T; ++t)
@@ -363,6 +402,8 @@ extern "C" int e2emv_matcher_forward(e2emv_ctx* ctx, const e2emv_forward_desc* f
             f2.tuple_size = 2;
             f2.img_w[0] = fd->img_w[i]; f2.img_h[0] = fd->img_h[i];
             f2.img_w[1] = fd->img_w[j]; f2.img_h[1] = fd->img_h[j];
+            f2.n_kpts_img[0] = fd->n_kpts_img[i]; f2.n_kpts_img[1] = fd->n_kpts_img[j];
+            for (int t = 2; t < E2EMV_MAX_TUPLE; ++t) f2.n_kpts_img[t] = 0;
             const float* kp[2] = {d_kpts[i], d_kpts[j]};
             const float* ks[2] = {d_kscores[i], d_kscores[j]};
             const void* de[2] = {d_desc[i], d_desc[j]};

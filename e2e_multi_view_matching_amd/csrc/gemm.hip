@@ -27,6 +27,7 @@
 //  * XCD-aware tile ranges: the tiles in flight on one XCD are neighbours (shared A panels
 //    stay in that XCD's L2).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -69,7 +70,7 @@ struct GemmParams {
 // EXT = true adds the bf16x3-plane outputs (C3, V^T with swapped operand roles, q pre-scale) used by the
 // q|k|v GEMM of the split-operand attention path; it gets a 256-VGPR budget (2 workgroups/CU) so that the
 // plain kernel (EXT = false, every other GEMM) keeps its spill-free 168-VGPR / 3-workgroups-per-CU build.
-template <bool EXT>
+template <bool EXT, int DBG = 0>
 __global__ __launch_bounds__(256, EXT ? 2 : 3) void gemm_nt_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;               // [BM][LDK]  activations
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256, EXT ? 2 : 3) void gemm_nt_kernel(GemmParams p)
         constexpr bool SWAP = decltype(swap_tag)::value;
         const float* as = &As[(wr * 64 + l31) * LDK + lh * 4];
         const float* bs = &Bs[(wc * 64 + l31) * LDK + lh * 4];
+        if (DBG & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(as + c * 8);
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(256, EXT ? 2 : 3) void gemm_nt_kernel(GemmParams p)
                 }
             }
         }
+        if (DBG & 1) __builtin_amdgcn_s_setprio(0);
     };
     auto split4 = [&](const f32x4& v, bf16x4& h0, bf16x4& h1, bf16x4& h2) {
 #pragma unroll
@@ -330,7 +333,12 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
         const int slots2 = std::min(per_xcd, std::max(1, ctx->num_cus * 2 / 8));
         hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(8 * slots2), dim3(256), lds, s, p);
     } else {
-        hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3(8 * slots), dim3(256), lds, s, p);
+        static int dbg = -1, wg = -1;  // profiling knobs: E2EMV_GEMM_DEBUG (bit0: s_setprio around MFMAs), E2EMV_GEMM_WG_PER_CU
+        if (dbg < 0) { const char* e = getenv("E2EMV_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+        if (wg < 0) { const char* e = getenv("E2EMV_GEMM_WG_PER_CU"); wg = e ? atoi(e) : 3; }
+        const int sl = std::min(per_xcd, std::max(1, ctx->num_cus * wg / 8));
+        if (dbg & 1) hipLaunchKernelGGL((gemm_nt_kernel<false, 1>), dim3(8 * sl), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<false, 0>), dim3(8 * sl), dim3(256), lds, s, p);
     }
     E2EMV_CHECK_LAUNCH(ctx, "gemm_nt_kernel");
     return E2EMV_OK;

@@ -83,7 +83,10 @@ extern "C" int e2emv_attention_bf16x3(e2emv_ctx* ctx, int B, int T, int n_rows, 
     hipLaunchKernelGGL(split_qkv_kernel, dim3((unsigned)rows), dim3(256), 0, s, d_qkv, n_rows, D, 0.125f * 1.4426950408889634f, qk, vt);
     E2EMV_HIP(ctx, hipMemsetAsync(d_out, 0, (size_t)rows * D * sizeof(float), s));
     prof_begin(ctx, PS_ATTN, s);
-    rc = launch_attention3(ctx, B, T, n_rows, n_valid, D, H, qk, vt, cross, nullptr, d_out, s);
+    if (T < 1 || T > E2EMV_MAX_TUPLE) return E2EMV_EINVAL;
+    int nv[E2EMV_MAX_TUPLE];
+    for (int t = 0; t < E2EMV_MAX_TUPLE; ++t) nv[t] = n_valid;
+    rc = launch_attention3(ctx, B, T, n_rows, nv, D, H, qk, vt, cross, nullptr, d_out, s);
     prof_end(ctx, s);
     E2EMV_CHECK_LAUNCH(ctx, "bf16x3 helper kernels");
     return rc;

@@ -176,38 +176,42 @@ class MultiViewMatcher(nn.Module):
             else:
                 h, w = data[f"image_size{m}"]
             fd.img_w[m], fd.img_h[m] = float(w), float(h)
-        B, N = kpts[0].shape[:2]
+        B = kpts[0].shape[0]
+        Ns = [int(k.shape[1]) for k in kpts]  # per-image keypoint counts (eval_pairs.py: they differ between images)
+        N = max(Ns)
         D = cfg["descriptor_dim"]
         for m in range(T):
-            if kpts[m].shape != (B, N, 2) or scores[m].shape != (B, N) or descs[m].shape != (B, D, N):
+            if kpts[m].shape != (B, Ns[m], 2) or scores[m].shape != (B, Ns[m]) or descs[m].shape != (B, D, Ns[m]):
                 raise AssertionError(f"image {m}: keypoints {tuple(kpts[m].shape)} scores {tuple(scores[m].shape)} "
-                                     f"descriptors {tuple(descs[m].shape)} (all images of a call share B and N)")
+                                     f"descriptors {tuple(descs[m].shape)} (all images of a call share the batch size)")
         if len({d.dtype for d in descs}) != 1:
             raise AssertionError("mixed descriptor dtypes")
         out = {}
         pairs = [(i, j) for j in range(T) for i in range(j)]
-        if N == 0:  # upstream: no keypoints -> empty matches
+        if min(Ns) == 0:  # upstream: no keypoints -> empty matches
             for i, j in pairs:
-                out[f"scores_{i}_{j}"] = torch.full((B, 1, 1), 0.0, device=dev)
-                out[f"matches{i}_{i}_{j}"] = torch.empty((B, 0), dtype=torch.int64, device=dev)
-                out[f"matches{j}_{i}_{j}"] = torch.empty((B, 0), dtype=torch.int64, device=dev)
-                out[f"conf_scores_{i}_{j}"] = torch.empty((B, 0, 1), device=dev)
+                out[f"scores_{i}_{j}"] = torch.full((B, Ns[i] + 1, Ns[j] + 1), 0.0, device=dev)
+                out[f"matches{i}_{i}_{j}"] = torch.full((B, Ns[i]), -1, dtype=torch.int64, device=dev)
+                out[f"matches{j}_{i}_{j}"] = torch.full((B, Ns[j]), -1, dtype=torch.int64, device=dev)
+                out[f"conf_scores_{i}_{j}"] = torch.zeros((B, Ns[i], 1), device=dev)
             return out
         full = bool(cfg.get("full_output", False)) or not self.training
         fd.batch, fd.tuple_size, fd.n_kpts = B, T, N
+        for m in range(T):
+            fd.n_kpts_img[m] = Ns[m]
         fd.sinkhorn_iters = int(cfg["sinkhorn_iterations"])
         fd.match_threshold = float(cfg["match_threshold"])
         fd.desc_dtype = _lib.DESC_F16 if descs[0].dtype == torch.float16 else _lib.DESC_F32
         fd.flags = (_lib.FLAG_FULL_OUTPUT if full else 0) | (_lib.FLAG_MULTI_FRAME if cfg["multi_frame_matching"] else 0)
         P = len(pairs)
-        logZ = [torch.empty((B, N + 1, N + 1), dtype=torch.float32, device=dev) for _ in range(P)]
+        logZ = [torch.empty((B, Ns[i] + 1, Ns[j] + 1), dtype=torch.float32, device=dev) for i, j in pairs]
         none = [None] * P
         if full:
-            m0 = [torch.empty((B, N), dtype=torch.int64, device=dev) for _ in range(P)]
-            m1 = [torch.empty((B, N), dtype=torch.int64, device=dev) for _ in range(P)]
-            s0 = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(P)]
-            s1 = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(P)]
-            cf = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(P)]
+            m0 = [torch.empty((B, Ns[i]), dtype=torch.int64, device=dev) for i, j in pairs]
+            m1 = [torch.empty((B, Ns[j]), dtype=torch.int64, device=dev) for i, j in pairs]
+            s0 = [torch.empty((B, Ns[i]), dtype=torch.float32, device=dev) for i, j in pairs]
+            s1 = [torch.empty((B, Ns[j]), dtype=torch.float32, device=dev) for i, j in pairs]
+            cf = [torch.empty((B, Ns[i]), dtype=torch.float32, device=dev) for i, j in pairs]
         else:
             m0 = m1 = s0 = s1 = cf = none
         keep = []

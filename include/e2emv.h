@@ -100,18 +100,20 @@ typedef struct {
     int32_t desc_dtype;     /* E2EMV_DESC_F32 | E2EMV_DESC_F16                            */
     int32_t flags;
     float img_w[E2EMV_MAX_TUPLE], img_h[E2EMV_MAX_TUPLE]; /* data['image{m}'].shape[-1/-2] */
+    int32_t n_kpts_img[E2EMV_MAX_TUPLE]; /* per-image keypoint count N_m (0 = n_kpts): eval_pairs.py feeds images with
+                                            different numbers of SuperPoint keypoints; n_kpts must be the maximum   */
 } e2emv_forward_desc;
 
-/* d_kpts[m]   [B,N,2] f32 pixel xy      (data['keypoints{m}'])
- * d_kscores[m][B,N]   f32               (data['scores{m}'])
- * d_desc[m]   [B,D,N] f32|f16, N contiguous (data['descriptors{m}'])
- * outputs, one pointer per pair p (any may be NULL = not wanted):
- * d_logZ[p]     [B,N+1,N+1] f32  result['scores_{i}_{j}']
- * d_matches0[p] [B,N] int64      result['matches{i}_{i}_{j}'] (-1 = unmatched; int64 because
+/* d_kpts[m]   [B,N_m,2] f32 pixel xy      (data['keypoints{m}'])
+ * d_kscores[m][B,N_m]   f32               (data['scores{m}'])
+ * d_desc[m]   [B,D,N_m] f32|f16, N_m contiguous (data['descriptors{m}'])
+ * outputs, one pointer per pair p = (i, j) (any may be NULL = not wanted):
+ * d_logZ[p]     [B,N_i+1,N_j+1] f32  result['scores_{i}_{j}']
+ * d_matches0[p] [B,N_i] int64    result['matches{i}_{i}_{j}'] (-1 = unmatched; int64 because
  *                                the reference uses it as a fancy index, estimate_relative_pose.py:26-30)
- * d_matches1[p] [B,N] int64      result['matches{j}_{i}_{j}']
- * d_mscores0/1[p] [B,N] f32      matching scores
- * d_conf[p]     [B,N] f32        result['conf_scores_{i}_{j}'] (caller views it [B,N,1])  */
+ * d_matches1[p] [B,N_j] int64    result['matches{j}_{i}_{j}']
+ * d_mscores0/1[p] [B,N_i]/[B,N_j] f32  matching scores
+ * d_conf[p]     [B,N_i] f32      result['conf_scores_{i}_{j}'] (caller views it [B,N_i,1])  */
 int e2emv_matcher_forward(e2emv_ctx* ctx, const e2emv_forward_desc* fd,
                           const float* const* d_kpts, const float* const* d_kscores, const void* const* d_desc,
                           float* const* d_logZ, int64_t* const* d_matches0, int64_t* const* d_matches1,

@@ -124,3 +124,31 @@ def test_config_full_output_is_honoured_after_construction(gpu):
     assert set(model(data)) == {"scores_0_1"}
     model.config["full_output"] = True  # helpers.py:245
     assert "matches0_0_1" in model(data) and model(data)["conf_scores_0_1"].shape == (1, 64, 1)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_images_with_different_keypoint_counts(gpu, precision):
+    """eval_pairs.py (batch 1) feeds images whose SuperPoint keypoint counts differ: N0 != N1 (and a ragged 3-tuple)."""
+    from e2e_multi_view_matching_amd import MultiViewMatcher
+    from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
+    from oracle.matcher import matcher_forward
+    for T, counts, layers in ((2, (203, 150), ["self", "cross"] * 2), (3, (140, 96, 260), ["self", "cross"])):
+        torch.manual_seed(5)
+        cfg = {"GNN_layers": layers, "sinkhorn_iterations": 15, "conf_mlp": True, "multi_frame_matching": T > 2,
+               "tuple_size": T, "mfma_precision": precision}
+        model = identity_like_state(MultiViewMatcher(cfg).eval())
+        data = make_tuples(batch=2, tuple_size=T, n_kpts=max(counts), seed=17)
+        for m, n in enumerate(counts):  # truncate image m to its own keypoint count
+            data[f"keypoints{m}"] = data[f"keypoints{m}"][:, :n].contiguous()
+            data[f"scores{m}"] = data[f"scores{m}"][:, :n].contiguous()
+            data[f"descriptors{m}"] = data[f"descriptors{m}"][:, :, :n].contiguous()
+        ocfg = {k: v for k, v in model.config.items() if k != "mfma_precision"}
+        ocfg["full_output"] = True
+        ref = matcher_forward(data, {k: v.clone() for k, v in model.state_dict().items()}, ocfg)
+        model = model.to(gpu)
+        out = model({k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in data.items()})
+        pairs = [(i, j) for j in range(T) for i in range(j)]
+        for i, j in pairs:
+            assert out[f"scores_{i}_{j}"].shape == (2, counts[i] + 1, counts[j] + 1)
+            assert out[f"matches{i}_{i}_{j}"].shape == (2, counts[i]) and out[f"matches{j}_{i}_{j}"].shape == (2, counts[j])
+        _compare(out, ref, pairs)

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib_built):
 def test_struct_layouts_match_the_header():
     from e2e_multi_view_matching_amd import _lib
     assert ctypes.sizeof(_lib.ModelDesc) == 4 * (3 + 8 + 1 + 64 + 1)
-    assert ctypes.sizeof(_lib.ForwardDesc) == 4 * (7 + 8 + 8)
+    assert ctypes.sizeof(_lib.ForwardDesc) == 4 * (7 + 8 + 8 + 8)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
