@@ -37,7 +37,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
-constexpr int BM = 128, BN = 128, BK = 32, LDK = 36;
+constexpr int BM = 128, BN = 128;  // BK (K tile, 32 or 64) is a template parameter; LDS rows are BK + 4 floats
 
 struct GemmParams {
     const float* A;
@@ -70,11 +70,15 @@ struct GemmParams {
 // EXT = true adds the bf16x3-plane outputs (C3, V^T with swapped operand roles, q pre-scale) used by the
 // q|k|v GEMM of the split-operand attention path; it gets a 256-VGPR budget (2 workgroups/CU) so that the
 // plain kernel (EXT = false, every other GEMM) keeps its spill-free 168-VGPR / 3-workgroups-per-CU build.
-template <bool EXT, int DBG = 0>
-__global__ __launch_bounds__(256, EXT ? 2 : 3) void gemm_nt_kernel(GemmParams p) {
+template <bool EXT, int BK, int DBG = 0>
+__global__ __launch_bounds__(256, (EXT || BK == 64) ? 2 : 3) void gemm_nt_kernel(GemmParams p) {
+    constexpr int LDK = BK + 4;           // 36: 36*i mod 64, 68: 4*i mod 64 - both give 16 distinct 16-byte slots
+    constexpr int CPR = BK / 4;           // 16-byte chunks per tile row
+    constexpr int NCH = BM * CPR / 256;   // chunks per thread and operand (4 or 8)
+    constexpr int RSTEP = 256 / CPR;      // rows covered by one pass of the 256 threads (32 or 16)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;               // [BM][LDK]  activations
-    float* Bs = smem + BM * LDK;    // [BN][LDK]  weights
+    float* As = smem;                       // [BM][BK + 4]  activations
+    float* Bs = smem + BM * (BK + 4);       // [BN][BK + 4]  weights
 
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int per_xcd = (p.total + 7) / 8;
@@ -88,14 +92,14 @@ __global__ __launch_bounds__(256, EXT ? 2 : 3) void gemm_nt_kernel(GemmParams p)
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int ld_row = tid >> 3;        // 0..31 (+32*i)
-    const int ld_c4 = (tid & 7) * 4;    // float offset inside the K tile
+    const int ld_row = tid / CPR;           // (+RSTEP*i)
+    const int ld_c4 = (tid % CPR) * 4;      // float offset inside the K tile
     const int nk = p.K / BK;
 
     // operand pointers of the tile whose K tiles are being PREFETCHED
-    const float* a_ptr[4];
-    const float* a2_ptr[4];
-    const float* w_ptr[4];
+    const float* a_ptr[NCH];
+    const float* a2_ptr[NCH];
+    const float* w_ptr[NCH];
     auto setup = [&](int t) {
         const int z = t / tiles_mn, r = t - z * tiles_mn;
         const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
@@ -103,20 +107,20 @@ __global__ __launch_bounds__(256, EXT ? 2 : 3) void gemm_nt_kernel(GemmParams p)
         const float* A2 = p.A2 ? p.A2 + z * p.sA2 : nullptr;
         const float* W = p.W + z * p.sW;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ra = min(tm * BM + ld_row + 32 * i, p.M - 1);
-            const int rw = min(tn * BN + ld_row + 32 * i, p.N - 1);
+        for (int i = 0; i < NCH; ++i) {
+            const int ra = min(tm * BM + ld_row + RSTEP * i, p.M - 1);
+            const int rw = min(tn * BN + ld_row + RSTEP * i, p.N - 1);
             a_ptr[i] = A + (int64_t)ra * p.lda + ld_c4;
             a2_ptr[i] = A2 ? A2 + (int64_t)ra * p.lda2 + ld_c4 : nullptr;
             w_ptr[i] = W + (int64_t)rw * p.ldw + ld_c4;
         }
     };
 
-    f32x4 ra[4], rb[4];
+    f32x4 ra[NCH], rb[NCH];
     auto gload = [&](int kt) {
         const int k = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const float* src = (k < p.K1) ? a_ptr[i] + k : a2_ptr[i] + (k - p.K1);
             ra[i] = *reinterpret_cast<const f32x4*>(src);
             rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + k);
@@ -124,9 +128,9 @@ __global__ __launch_bounds__(256, EXT ? 2 : 3) void gemm_nt_kernel(GemmParams p)
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&As[(buf * BM + ld_row + 32 * i) * LDK + ld_c4]) = ra[i];
-            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + ld_row + 32 * i) * LDK + ld_c4]) = rb[i];
+        for (int i = 0; i < NCH; ++i) {
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + ld_row + RSTEP * i) * LDK + ld_c4]) = ra[i];
+            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + ld_row + RSTEP * i) * LDK + ld_c4]) = rb[i];
         }
     };
 
@@ -300,11 +304,8 @@ __global__ __launch_bounds__(256, EXT ? 2 : 3) void gemm_nt_kernel(GemmParams p)
 int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.batch <= 0) return set_err(ctx, E2EMV_ESHAPE, "gemm: empty problem");
     const int K1 = a.A2 ? a.K1 : a.K;
-    if (a.K % BK || K1 % BK || K1 > a.K || (K1 < a.K && !a.A2))
-        return set_err(ctx, E2EMV_ESHAPE, "gemm: K=%d K1=%d must be multiples of %d", a.K, K1, BK);
-    if ((a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4)) || ((uintptr_t)a.A % 16) || ((uintptr_t)a.W % 16) ||
-        (a.A2 && ((uintptr_t)a.A2 % 16)) || (a.sA % 4) || (a.sW % 4) || (a.sA2 % 4))
-        return set_err(ctx, E2EMV_ESHAPE, "gemm: operands must be 16-byte aligned with leading dims %% 4 == 0");
+    if (a.K % 32 || K1 % 32 || K1 > a.K || (K1 < a.K && !a.A2))
+        return set_err(ctx, E2EMV_ESHAPE, "gemm: K=%d K1=%d must be multiples of 32", a.K, K1);
     GemmParams p;
     p.A = a.A; p.A2 = a.A2; p.W = a.W; p.bias = a.bias; p.R = a.R; p.C = a.C;
     p.C3 = a.C3; p.ldc3 = a.ldc3;
@@ -327,18 +328,33 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
     if ((p.C3 || a.Vt) && (!p.vec_store || a.batch != 1 || (p.C3 && a.ldc3 % 4)))
         return set_err(ctx, E2EMV_ESHAPE, "gemm: the bf16x3 side output needs the vector epilogue and batch 1");
     const int per_xcd = (p.total + 7) / 8;
-    const int slots = std::min(per_xcd, std::max(1, ctx->num_cus * 3 / 8));
-    const size_t lds = sizeof(float) * (BM + BN) * LDK;
-    if (p.C3 || a.Vt || a.q_cols > 0) {
-        const int slots2 = std::min(per_xcd, std::max(1, ctx->num_cus * 2 / 8));
-        hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(8 * slots2), dim3(256), lds, s, p);
+    static int dbg = -1, wg = -1, bk_env = -1;  // profiling knobs: E2EMV_GEMM_DEBUG (bit0: s_setprio), _WG_PER_CU, _BK
+    if (dbg < 0) { const char* e = getenv("E2EMV_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (wg < 0) { const char* e = getenv("E2EMV_GEMM_WG_PER_CU"); wg = e ? atoi(e) : 0; }
+    if (bk_env < 0) { const char* e = getenv("E2EMV_GEMM_BK"); bk_env = e ? atoi(e) : 0; }
+    const bool ext = p.C3 || a.Vt || a.q_cols > 0;
+    // K tile: 32.  A 64-deep tile (half the barrier / staging episodes per MFMA, 2 workgroups per CU) was measured
+    // 1-5 % SLOWER at every shape; so were 1 or 2 workgroups per CU and s_setprio around the MFMA block: the main
+    // loop sits at ~125 TFLOP/s (MFMA pipe ~82 % busy at ~2.3 GHz) whatever the schedule.  E2EMV_GEMM_BK=64 keeps
+    // the variant reachable for profiling.
+    int bk = 32;
+    if (bk_env == 64 && a.K % 64 == 0 && K1 % 64 == 0 && !ext) bk = 64;
+    const int per_cu = wg > 0 ? wg : ((ext || bk == 64) ? 2 : 3);
+    const int sl = std::min(per_xcd, std::max(1, ctx->num_cus * per_cu / 8));
+    const size_t lds = sizeof(float) * (BM + BN) * (bk + 4);
+    if (bk == 64) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            E2EMV_HIP(ctx, hipFuncSetAttribute((const void*)gemm_nt_kernel<false, 64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_nt_kernel<false, 64, 0>), dim3(8 * sl), dim3(256), lds, s, p);
+    } else if (ext) {
+        hipLaunchKernelGGL((gemm_nt_kernel<true, 32, 0>), dim3(8 * sl), dim3(256), lds, s, p);
+    } else if (dbg & 1) {
+        hipLaunchKernelGGL((gemm_nt_kernel<false, 32, 1>), dim3(8 * sl), dim3(256), lds, s, p);
     } else {
-        static int dbg = -1, wg = -1;  // profiling knobs: E2EMV_GEMM_DEBUG (bit0: s_setprio around MFMAs), E2EMV_GEMM_WG_PER_CU
-        if (dbg < 0) { const char* e = getenv("E2EMV_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
-        if (wg < 0) { const char* e = getenv("E2EMV_GEMM_WG_PER_CU"); wg = e ? atoi(e) : 3; }
-        const int sl = std::min(per_xcd, std::max(1, ctx->num_cus * wg / 8));
-        if (dbg & 1) hipLaunchKernelGGL((gemm_nt_kernel<false, 1>), dim3(8 * sl), dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((gemm_nt_kernel<false, 0>), dim3(8 * sl), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((gemm_nt_kernel<false, 32, 0>), dim3(8 * sl), dim3(256), lds, s, p);
     }
     E2EMV_CHECK_LAUNCH(ctx, "gemm_nt_kernel");
     return E2EMV_OK;
