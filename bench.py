@@ -78,6 +78,7 @@ def main():
 
     import e2e_multi_view_matching_amd as E
     from e2e_multi_view_matching_amd import _lib
+    from e2e_multi_view_matching_amd.distributed import gather_pair_errors, reduce_max_seconds
     from e2e_multi_view_matching_amd.metrics import pair_errors_deg, pose_auc
     from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
 
@@ -130,10 +131,7 @@ def main():
     if not args.no_profile:
         prof = _lib.profile_read(ctx, reset=True)
         ctx.call("e2emv_profile", 0)
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = reduce_max_seconds(elapsed, device=dev)  # MAX over ranks
 
     # ---- optional second measurement: attention on the bf16 pipe with 3-way split operands (fp32-class accuracy,
     # e2emv_set_precision); reported separately, `value` above is always the all-fp32-MFMA path
@@ -152,10 +150,7 @@ def main():
         if dist is not None:
             dist.barrier()
         alt_elapsed = time.perf_counter() - a0
-        if dist is not None:
-            tt = torch.tensor([alt_elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            alt_elapsed = float(tt.item())
+        alt_elapsed = reduce_max_seconds(alt_elapsed, device=dev)
         ctx.call("e2emv_set_precision", _lib.PRECISION_F32)
         alt = {"ms_per_step": round(1000.0 * alt_elapsed / args.steps, 3),
                "value": round(B * len(pairs) * world * args.steps / alt_elapsed, 2), "unit": "pairs/s",
@@ -165,13 +160,7 @@ def main():
     # ---- AUC leg (not timed): identity-like weights give real matches; errors gathered over ranks
     _, errs = step(model_id)
     e_deg = np.concatenate([pair_errors_deg(r.cpu().numpy(), t.cpu().numpy()) for r, t in errs])
-    if dist is not None:
-        buf = torch.from_numpy(e_deg).to(dev)
-        gathered = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(gathered, buf)  # the path's only collective (RCCL over xGMI), B*P floats per rank
-        e_all = torch.cat(gathered).cpu().numpy()
-    else:
-        e_all = e_deg
+    e_all = gather_pair_errors(e_deg, device=dev)  # the path's only data collective (RCCL over xGMI), B*P floats per rank
     auc = [100.0 * a for a in pose_auc(e_all, [5, 10, 20])]
 
     if rank != 0:
