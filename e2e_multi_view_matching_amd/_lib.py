@@ -62,6 +62,9 @@ SIGNATURES = {
                            c_void_p]),
     "e2emv_pose_errors": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_ba_2view": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "e2emv_gt_matches": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "e2emv_match_loss": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_gemm_nt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                               c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                               c_int64, c_float, c_int, c_void_p]),

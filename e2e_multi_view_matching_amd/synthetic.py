@@ -107,3 +107,52 @@ def identity_like_state(module):
         sd["final_proj.bias"].zero_()
     module.load_state_dict(sd)
     return module
+
+
+def make_depth_pairs(batch, n_kpts=256, seed=0, height=IMG_H, width=IMG_W, noise_px=0.6, invalid_frac=0.05):
+    """Image pairs WITH depth maps for the ground-truth-match builder (``helpers.py:121-203``): a slanted plane seen by
+    two cameras (analytic depth in both views), keypoints of image 0 = random integer pixels, a fraction of them
+    re-observed in image 1 (+ noise), the rest of image 1 random; some depth pixels are invalidated (0) like real sensors.
+    Returns dict(keypoints0/1 [B,N,2], intr0/1, pose0/1 [B,4,4], depth0/1 [B,H,W], T_0to1)."""
+    rng = np.random.default_rng(seed)
+    B, N = batch, n_kpts
+    K = np.eye(4)
+    K[0, 0] = K[1, 1] = FOCAL
+    K[0, 2], K[1, 2] = width / 2, height / 2
+    Ki = np.linalg.inv(K)
+    uu, vv = np.meshgrid(np.arange(width), np.arange(height))
+    rays = np.stack([uu, vv, np.ones_like(uu)], -1).reshape(-1, 3) @ Ki[:3, :3].T  # z = 1 rays
+    out = {k: [] for k in ("keypoints0", "keypoints1", "depth0", "depth1", "pose1")}
+    for b in range(B):
+        nrm = _unit(np.array([rng.normal(0, 0.15), rng.normal(0, 0.15), 1.0]))
+        dist = rng.uniform(3.5, 5.5)  # plane n.X = dist in camera-0 coordinates
+        P = np.eye(4)
+        P[:3, :3] = _rand_rotation(rng, 0.25)
+        P[:3, 3] = rng.normal(0, 0.3, 3)
+        R, t = P[:3, :3], P[:3, 3]
+        depth0 = (dist / (rays @ nrm)).reshape(height, width)
+        # camera 1 ray: X0 = R^T (lam r - t);  n.X0 = dist  ->  lam = (dist + n.R^T t) / (n.R^T r)
+        Rn = R @ nrm
+        depth1 = ((dist + nrm @ (R.T @ t)) / (rays @ Rn)).reshape(height, width)
+        k0 = np.stack([rng.integers(8, width - 8, N), rng.integers(8, height - 8, N)], -1).astype(np.float64)
+        X0 = (np.concatenate([k0, np.ones((N, 1))], 1) @ Ki[:3, :3].T) * depth0[k0[:, 1].astype(int), k0[:, 0].astype(int)][:, None]
+        X1 = X0 @ R.T + t
+        proj = X1[:, :2] / X1[:, 2:3] * FOCAL + np.array([width / 2, height / 2]) + rng.normal(0, noise_px, (N, 2))
+        inside = (proj[:, 0] > 8) & (proj[:, 0] < width - 8) & (proj[:, 1] > 8) & (proj[:, 1] < height - 8)
+        keep = inside & (rng.uniform(size=N) < 0.7)
+        k1 = np.where(keep[:, None], proj, np.stack([rng.uniform(8, width - 8, N), rng.uniform(8, height - 8, N)], -1))
+        k1 = k1[rng.permutation(N)]
+        for dm in (depth0, depth1):
+            bad = rng.uniform(size=dm.shape) < invalid_frac
+            dm[bad] = 0.0
+        out["keypoints0"].append(k0 + rng.uniform(0, 0.9, (N, 2)))  # sub-pixel positions: the builder truncates them
+        out["keypoints1"].append(k1)
+        out["depth0"].append(depth0)
+        out["depth1"].append(depth1)
+        out["pose1"].append(P)
+    res = {k: torch.from_numpy(np.stack(v).astype(np.float32)) for k, v in out.items()}
+    res["pose0"] = torch.eye(4).unsqueeze(0).repeat(B, 1, 1)
+    res["intr0"] = torch.from_numpy(np.broadcast_to(K, (B, 4, 4)).astype(np.float32).copy())
+    res["intr1"] = res["intr0"].clone()
+    res["T_0to1"] = res["pose1"] @ torch.linalg.inv(res["pose0"])
+    return res

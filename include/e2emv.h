@@ -163,6 +163,19 @@ int e2emv_pose_errors(e2emv_ctx* ctx, int B, const float* d_T, const float* d_T_
 int e2emv_ba_2view(e2emv_ctx* ctx, int B, int N, const float* d_kpts0n, const float* d_kpts1n, const float* d_conf,
                    const float* d_T_init, int n_iterations, float* d_T_out, uint8_t* d_valid, void* stream);
 
+/* ---- validation targets and loss -----------------------------
+ * compute_gt_matches_of_image_pair (helpers.py:121-203): ground-truth matches of a pair from depth maps and the
+ * relative pose.  d_kpts0/1 [B,N,2] pixel xy (truncated to integers like the reference), d_K0/1 [B,4,4],
+ * d_T0to1 [B,4,4], d_depth0/1 [B,H,W].  Outputs d_indices [B,2,N+1] int64 (slot N = dustbin, -1 = no match) and
+ * d_weights [B,2,N+1] f32 - the tensors helpers.py:203 stacks ("gt_indices_i_j", "gt_weights_i_j").            */
+int e2emv_gt_matches(e2emv_ctx* ctx, int B, int N, const float* d_kpts0, const float* d_kpts1, const float* d_K0,
+                     const float* d_K1, const float* d_T0to1, const float* d_depth0, const float* d_depth1, int H, int W,
+                     float max_matched_reproj_err, float min_unmatched_reproj_err, int64_t* d_indices, float* d_weights,
+                     void* stream);
+/* compute_match_loss (helpers.py:228-241) on d_logZ [B,N+1,N+1] -> d_loss[0] (already divided by B). */
+int e2emv_match_loss(e2emv_ctx* ctx, int B, int N, const float* d_logZ, const int64_t* d_indices, const float* d_weights,
+                     float* d_loss, void* stream);
+
 /* ---- building blocks exported for per-kernel parity tests and micro-benchmarks ----- */
 /* C[z][m][n] = act(sum_k A[z][m][k] W[z][n][k] * scale + bias[n]) (+ R[z][m][n]); all f32;
  * A may be split in two K-segments (A: k < K1, A2: K1 <= k < K).  flags: bit0 relu.        */

@@ -154,6 +154,33 @@ def gen_ba():
     print("ba2view_reference.npz", {n: out[f"{n}/ref_fp32_noise"].tolist() for n in names})
 
 
+def gen_gt_matches():
+    """Ground-truth match targets + match loss from the reference's own helpers.py (imported unmodified; its
+    tensorboard / coloredlogs imports are satisfied by empty in-memory modules)."""
+    install_reference_shims()
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = object
+    sys.modules["torch.utils.tensorboard"] = tb
+    import warnings
+    warnings.filterwarnings("ignore")
+    import helpers as H
+    from e2e_multi_view_matching_amd.synthetic import make_depth_pairs
+    out, names = {}, []
+    for (B, N, seed, mm, mu) in [(3, 200, 1, 5.0, 15.0), (2, 400, 2, 5.0, 10.0), (2, 64, 3, 5.0, 15.0)]:
+        d = make_depth_pairs(B, N, seed=seed, height=240, width=320)
+        idx, w = H.compute_gt_matches_of_image_pair(d["keypoints0"], d["keypoints1"], d["intr0"], d["intr1"], d["T_0to1"],
+                                                    d["depth0"], d["depth1"], mm, mu)
+        lp = torch.log_softmax(torch.randn(B, N + 1, N + 1, generator=torch.Generator().manual_seed(seed)), -1)
+        name = f"B{B}_N{N}_s{seed}"
+        names.append(name)
+        out[f"{name}/args"] = np.array([B, N, seed, mm, mu])
+        out[f"{name}/indices"], out[f"{name}/weights"] = idx.numpy(), w.numpy()
+        out[f"{name}/loss"] = H.compute_match_loss(lp, idx, w).numpy()
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "gt_matches_reference.npz"), **out)
+    print("gt_matches_reference.npz", {n: int((out[f"{n}/indices"][:, 0] >= 0).sum()) for n in names})
+
+
 def gen_sinkhorn_hf():
     from transformers.models.superglue import modeling_superglue as HF
     out = {}
@@ -251,3 +278,4 @@ if __name__ == "__main__":
     gen_superglue_hf()
     gen_w8pt()
     gen_ba()
+    gen_gt_matches()
