@@ -65,6 +65,10 @@ SIGNATURES = {
     "e2emv_gt_matches": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "e2emv_match_loss": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e2emv_mv_init": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e2emv_mv_estimate_rotations": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "e2emv_mv_estimate_positions": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e2emv_mv_init_files": (c_int, [c_char_p, c_char_p]),
     "e2emv_gemm_nt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                               c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                               c_int64, c_float, c_int, c_void_p]),

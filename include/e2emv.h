@@ -176,6 +176,25 @@ int e2emv_gt_matches(e2emv_ctx* ctx, int B, int N, const float* d_kpts0, const f
 int e2emv_match_loss(e2emv_ctx* ctx, int B, int N, const float* d_logZ, const int64_t* d_indices, const float* d_weights,
                      float* d_loss, void* stream);
 
+/* ---- multi-view pose back-end --------------------------------
+ * HOST-side global initialisation = the reference's `ba_initializer` executable (bundle_adjustment/ba_init/src/
+ * ba_init.cpp:10-90): robust rotation averaging (Chatterjee & Govindu 2013; L1 steps then IRLS) followed by
+ * least-unsquared-deviation positions (Ozyesil & Singer 2015), both fp64 on the host like the reference (tiny
+ * problems: <= 64 views).  All pointers are HOST memory, no context needed.  Rotations are COLUMN-major 3x3
+ * (the CSV order), world -> camera; pair e = (id0, id1) carries R_021 and the position of camera id1 in the frame of
+ * camera id0 (ba_init.cpp:30-50).  View 0 is the gauge.  out_t = -R * position (ba_init.cpp:65).
+ * *status: bit 1 = rotation averaging failed, bit 2 = position estimation failed (results then = best so far).      */
+int e2emv_mv_init(int n_views, const double* init_R, int n_pairs, const int32_t* pair_ids, const double* pair_R,
+                  const double* pair_pos, double* out_R, double* out_t, int32_t* status);
+/* The two estimators on their own (angle-axis in/out), as the reference's gtests exercise them
+ * (ba_init/test/test_ba_init.cpp:95-268).  rot_aa [n_views,3] is the initial guess on input.                        */
+int e2emv_mv_estimate_rotations(int n_views, int n_pairs, const int32_t* pair_ids, const double* pair_rot_aa,
+                                double* rot_aa);
+int e2emv_mv_estimate_positions(int n_views, int n_pairs, const int32_t* pair_ids, const double* pair_pos,
+                                const double* rot_aa, double* out_pos);
+/* `ba_init_in.csv` -> `ba_init_out.csv` (ba_initializer.cpp:7-23; wire format ba_init.cpp:13-51, 58-75).           */
+int e2emv_mv_init_files(const char* in_csv, const char* out_csv);
+
 /* ---- building blocks exported for per-kernel parity tests and micro-benchmarks ----- */
 /* C[z][m][n] = act(sum_k A[z][m][k] W[z][n][k] * scale + bias[n]) (+ R[z][m][n]); all f32;
  * A may be split in two K-segments (A: k < K1, A2: K1 <= k < K).  flags: bit0 relu.        */
