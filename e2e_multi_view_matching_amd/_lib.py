@@ -69,6 +69,10 @@ SIGNATURES = {
     "e2emv_mv_estimate_rotations": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "e2emv_mv_estimate_positions": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_mv_init_files": (c_int, [c_char_p, c_char_p]),
+    "e2emv_mv_bundle_adjust": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "e2emv_mv_bundle_adjust_files": (c_int, [c_void_p, c_char_p, c_char_p, c_void_p]),
+    "e2emv_mv_triangulate": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_gemm_nt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                               c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                               c_int64, c_float, c_int, c_void_p]),

@@ -1,0 +1,706 @@
+// Multi-view weighted reprojection bundle adjustment on the device (SURVEY.md 8(f) "next" row 3).
+//
+// Replaces the reference's `bundle_adjuster` executable: pose_optimization/multi_view/bundle_adjustment/
+// problem/include/ba_problem.h:60-151 (the two reprojection functors), problem/src/ba_problem.cpp:8-88 (CSV parser),
+// :98-113 (WriteResult), :115-157 (Solve = Ceres, DENSE_SCHUR, squared loss, default options), bundle_adjuster.cpp:7-23.
+// Ceres 2.0 is absent here; the minimiser restates its documented Levenberg-Marquardt trust-region loop (see
+// oracle/mvba.py, which this kernel is tested against to ~1e-9, and the reference's gtest known answers).
+//
+// Where the reference hands the whole problem to a CPU solver (autodiff Jacobians, dense Schur on one thread), ONE
+// workgroup of 512 threads runs the entire optimisation without leaving the GPU:
+//   A  thread / observation : residual + analytic Jacobians (2x6 camera, 2x3 point), cost
+//   B  thread / point       : V_p = sum Jp^T Jp, g_p, damping, V_p^-1, Y_o = (Jc^T Jp) V_p^-1
+//   C  wave   / camera      : U_c = sum Jc^T Jc, g_c            (per-camera observation lists, shuffle reductions)
+//   E  wave   / camera pair : S_ab = [a==b](U_a + D_a) - sum_p Y_oa W_ob^T,  rhs_a = -g_a + sum_p Y_oa g_p
+//   F  wave 0               : Cholesky + two triangular solves of the reduced camera system (<= 48 x 48, LDS)
+//   G  thread / point       : dp = -V_p^-1 (g_p + sum_o W_o^T dc), candidate point
+//   H  thread / observation : model cost change -m.(r + m/2), m = J d;  cost at the candidate
+//   I  thread 0             : step acceptance, trust-region radius, termination tests
+// All arithmetic fp64; every reduction has a fixed order (no atomics), so results are run-to-run identical.
+// Quirk kept (ba_problem.cpp:129-137): observations of the fixed camera are predicted with the identity pose and that
+// camera's parameters are written back untouched.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+
+#include "common.h"
+#include "mv_host.h"
+
+namespace e2emv {
+
+constexpr int kMvThreads = 512;  // 8 waves = 2 per SIMD -> 256 VGPRs each (phase E keeps a 6x6 fp64 block per lane)
+constexpr int kMvWaves = kMvThreads / 64;
+constexpr int kMvMaxCams = E2EMV_MAX_TUPLE;
+constexpr int kMvN = 6 * kMvMaxCams;  // reduced system order bound (48)
+
+struct MvbaArgs {
+    int C, fixed, P, O, max_iters;
+    double fx, fy, cx, cy;
+    const int *cam_idx, *pt_idx, *pt_start, *pt_obs, *cam_start, *cam_obs;
+    const double *obs, *wts;
+    double *cams, *pts;
+    double *r, *Jc, *Jp, *Y, *Vinv, *gp, *dp, *scale_p, *cand;
+    double* summary;  // [0] initial cost [1] final cost [2] iterations [3] termination code
+};
+
+enum { kTermMaxIter = 0, kTermGradient = 1, kTermParameter = 2, kTermFunction = 3, kTermInvalid = 4, kTermRadius = 5 };
+
+__device__ __forceinline__ double mv_wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double mv_wmax(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// block-wide reduction of up to 4 values (sum for k < nsum, max for the rest); all threads get the result
+template <int NV, int NSUM>
+__device__ __forceinline__ void mv_block_reduce(double (&v)[NV], double* scratch /* [kMvWaves*NV] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = k < NSUM ? mv_wsum(v[k]) : mv_wmax(v[k]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) scratch[wave * NV + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double a = scratch[k];
+        for (int w = 1; w < kMvWaves; ++w) a = k < NSUM ? a + scratch[w * NV + k] : fmax(a, scratch[w * NV + k]);
+        v[k] = a;
+    }
+}
+
+// p = R(w) X + t and (optionally) R and dp/dw (ceres::AngleAxisRotatePoint under autodiff: Rodrigues for theta^2 > eps,
+// first-order X + w x X below).  identity: the fixed camera.
+__device__ __forceinline__ void mv_transform(const double* cam, bool identity, const double X[3], double p[3], double R[9] /*row-major*/,
+                                             double D[9] /* dp/dw row-major */, bool jac) {
+    if (identity) {
+        p[0] = X[0]; p[1] = X[1]; p[2] = X[2];
+        if (jac) {
+            R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) D[i] = 0;
+        }
+        return;
+    }
+    const double w0 = cam[0], w1 = cam[1], w2 = cam[2];
+    const double t2 = w0 * w0 + w1 * w1 + w2 * w2;
+    double Rl[9];
+    const bool big = t2 > 2.220446049250313e-16;
+    if (big) {
+        const double th = sqrt(t2), k0 = w0 / th, k1 = w1 / th, k2 = w2 / th;
+        const double s = sin(th), c = cos(th), v = 1.0 - c;
+        // R = I + s K + v K^2
+        Rl[0] = 1 - v * (k1 * k1 + k2 * k2); Rl[1] = -s * k2 + v * k0 * k1;       Rl[2] = s * k1 + v * k0 * k2;
+        Rl[3] = s * k2 + v * k0 * k1;        Rl[4] = 1 - v * (k0 * k0 + k2 * k2); Rl[5] = -s * k0 + v * k1 * k2;
+        Rl[6] = -s * k1 + v * k0 * k2;       Rl[7] = s * k0 + v * k1 * k2;        Rl[8] = 1 - v * (k0 * k0 + k1 * k1);
+    } else {
+        Rl[0] = 1; Rl[1] = -w2; Rl[2] = w1; Rl[3] = w2; Rl[4] = 1; Rl[5] = -w0; Rl[6] = -w1; Rl[7] = w0; Rl[8] = 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p[i] = Rl[3 * i] * X[0] + Rl[3 * i + 1] * X[1] + Rl[3 * i + 2] * X[2] + cam[3 + i];
+    if (!jac) return;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Rl[i];
+    // [X]x
+    const double Xh[9] = {0, -X[2], X[1], X[2], 0, -X[0], -X[1], X[0], 0};
+    if (!big) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) D[i] = -Xh[i];
+        return;
+    }
+    // G = (w w^T + (R^T - I) [w]x) / theta^2 ;  D = -R [X]x G
+    const double wh[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+    const double w[3] = {w0, w1, w2};
+    double G[9], T[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double a = w[i] * w[j];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a += (Rl[3 * k + i] - (k == i ? 1.0 : 0.0)) * wh[3 * k + j];
+            G[3 * i + j] = a / t2;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T[3 * i + j] = Xh[3 * i] * G[j] + Xh[3 * i + 1] * G[3 + j] + Xh[3 * i + 2] * G[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) D[3 * i + j] = -(Rl[3 * i] * T[j] + Rl[3 * i + 1] * T[3 + j] + Rl[3 * i + 2] * T[6 + j]);
+}
+
+__global__ __launch_bounds__(kMvThreads) void mvba_kernel(MvbaArgs a) {
+    __shared__ double s_cams[kMvN], s_cand[kMvN], s_scale[kMvN], s_lam[kMvN], s_gc[kMvN], s_dc[kMvN], s_rhs[kMvN];
+    __shared__ double s_U[kMvMaxCams * 36];
+    __shared__ double s_S[kMvN * kMvN];
+    __shared__ double s_red[kMvWaves * 4];
+    __shared__ double s_ctl[8];  // 0 radius 1 decrease 2 cost 3 - 4 - 5 solve ok
+    __shared__ int s_fidx[kMvMaxCams], s_free[kMvMaxCams], s_state[4];  // state: 0 stop flag, 1 iterations, 2 termination, 3 invalid count
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C, P = a.P, O = a.O;
+
+    if (tid < 6 * C) s_cams[tid] = a.cams[tid];
+    if (tid == 0) {
+        int F = 0;
+        for (int c = 0; c < C; ++c) {
+            s_fidx[c] = (c == a.fixed) ? -1 : F;
+            if (c != a.fixed) s_free[F++] = c;
+        }
+        s_state[0] = 0; s_state[1] = 0; s_state[2] = kTermMaxIter; s_state[3] = 0;
+        s_ctl[0] = 1e4; s_ctl[1] = 2.0;
+    }
+    __syncthreads();
+    int F = 0;
+    for (int c = 0; c < C; ++c) F += (c != a.fixed);
+    const int n = 6 * F;
+    bool first = true;
+
+    while (true) {
+        // ---- A: residuals, Jacobians, cost at the current iterate ------------------------------------------------
+        double red[4] = {0, 0, 0, 0};
+        for (int o = tid; o < O; o += kMvThreads) {
+            const int c = a.cam_idx[o], p = a.pt_idx[o];
+            const double X[3] = {a.pts[3 * p], a.pts[3 * p + 1], a.pts[3 * p + 2]};
+            double q[3], R[9], D[9];
+            const bool fixed = (c == a.fixed);
+            mv_transform(&s_cams[6 * c], fixed, X, q, R, D, true);
+            const double iz = 1.0 / q[2], wx = a.wts[2 * o], wy = a.wts[2 * o + 1];
+            const double rx = wx * (a.fx * q[0] * iz + a.cx - a.obs[2 * o]), ry = wy * (a.fy * q[1] * iz + a.cy - a.obs[2 * o + 1]);
+            a.r[2 * o] = rx; a.r[2 * o + 1] = ry;
+            red[0] += rx * rx + ry * ry;
+            // d(residual)/d(q): rows weighted
+            const double e00 = wx * a.fx * iz, e02 = -wx * a.fx * q[0] * iz * iz, e11 = wy * a.fy * iz, e12 = -wy * a.fy * q[1] * iz * iz;
+            double* jc = a.Jc + 12 * size_t(o);
+            double* jp = a.Jp + 6 * size_t(o);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                jc[k] = fixed ? 0.0 : e00 * D[k] + e02 * D[6 + k];
+                jc[6 + k] = fixed ? 0.0 : e11 * D[3 + k] + e12 * D[6 + k];
+                jp[k] = e00 * R[k] + e02 * R[6 + k];
+                jp[3 + k] = e11 * R[3 + k] + e12 * R[6 + k];
+            }
+            jc[3] = fixed ? 0.0 : e00; jc[4] = 0.0; jc[5] = fixed ? 0.0 : e02;
+            jc[9] = 0.0; jc[10] = fixed ? 0.0 : e11; jc[11] = fixed ? 0.0 : e12;
+        }
+        {
+            double v[1] = {red[0]};
+            mv_block_reduce<1, 1>(v, s_red);
+            if (tid == 0) {
+                s_ctl[2] = 0.5 * v[0];
+                if (first) a.summary[0] = 0.5 * v[0];
+            }
+        }
+        // ---- C: camera blocks U_c, g_c (a wave per free camera) -------------------------------------------------
+        __syncthreads();  // Jc / r of all observations are in memory
+        for (int f = wave; f < F; f += kMvWaves) {
+            const int c = s_free[f];
+            double u[21], g[6];
+#pragma unroll
+            for (int i = 0; i < 21; ++i) u[i] = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) g[i] = 0;
+            for (int k = a.cam_start[c] + lane; k < a.cam_start[c + 1]; k += 64) {
+                const int o = a.cam_obs[k];
+                const double* jc = a.Jc + 12 * size_t(o);
+                double j0[6], j1[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { j0[i] = jc[i]; j1[i] = jc[6 + i]; }
+                const double rx = a.r[2 * o], ry = a.r[2 * o + 1];
+                int t = 0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    g[i] += j0[i] * rx + j1[i] * ry;
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) u[t++] += j0[i] * j0[j] + j1[i] * j1[j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 21; ++i) u[i] = mv_wsum(u[i]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) g[i] = mv_wsum(g[i]);
+            if (lane == 0) {
+                int t = 0;
+                for (int i = 0; i < 6; ++i) {
+                    s_gc[6 * f + i] = g[i];
+                    for (int j = 0; j <= i; ++j) { s_U[36 * f + 6 * i + j] = u[t]; s_U[36 * f + 6 * j + i] = u[t]; ++t; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- D: camera scaling / damping, camera part of the gradient norm --------------------------------------
+        double gmax = 0.0;
+        if (tid < n) {
+            const double d = s_U[36 * (tid / 6) + 7 * (tid % 6)];
+            if (first) s_scale[tid] = 1.0 / (1.0 + sqrt(d));
+            const double sc = s_scale[tid];
+            s_lam[tid] = fmin(fmax(d * sc * sc, 1e-6), 1e32) / s_ctl[0] / (sc * sc);
+            gmax = fabs(s_gc[tid]);
+        }
+        // ---- B: point blocks ---------------------------------------------------------------------------------------
+        const double radius = s_ctl[0];
+        for (int p = tid; p < P; p += kMvThreads) {
+            double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};  // V: 00 10 11 20 21 22
+            for (int k = a.pt_start[p]; k < a.pt_start[p + 1]; ++k) {
+                const int o = a.pt_obs[k];
+                const double* jp = a.Jp + 6 * size_t(o);
+                const double rx = a.r[2 * o], ry = a.r[2 * o + 1];
+                V[0] += jp[0] * jp[0] + jp[3] * jp[3];
+                V[1] += jp[1] * jp[0] + jp[4] * jp[3];
+                V[2] += jp[1] * jp[1] + jp[4] * jp[4];
+                V[3] += jp[2] * jp[0] + jp[5] * jp[3];
+                V[4] += jp[2] * jp[1] + jp[5] * jp[4];
+                V[5] += jp[2] * jp[2] + jp[5] * jp[5];
+                g[0] += jp[0] * rx + jp[3] * ry;
+                g[1] += jp[1] * rx + jp[4] * ry;
+                g[2] += jp[2] * rx + jp[5] * ry;
+            }
+            const double d[3] = {V[0], V[2], V[5]};
+            double lam[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double sc;
+                if (first) { sc = 1.0 / (1.0 + sqrt(d[i])); a.scale_p[3 * p + i] = sc; }
+                else sc = a.scale_p[3 * p + i];
+                lam[i] = fmin(fmax(d[i] * sc * sc, 1e-6), 1e32) / radius / (sc * sc);
+                gmax = fmax(gmax, fabs(g[i]));
+                a.gp[3 * p + i] = g[i];
+            }
+            const double m00 = V[0] + lam[0], m10 = V[1], m11 = V[2] + lam[1], m20 = V[3], m21 = V[4], m22 = V[5] + lam[2];
+            // inverse of the symmetric 3x3 through its adjugate
+            const double c00 = m11 * m22 - m21 * m21, c10 = m20 * m21 - m10 * m22, c20 = m10 * m21 - m20 * m11;
+            const double det = m00 * c00 + m10 * c10 + m20 * c20, id = 1.0 / det;
+            const double i00 = c00 * id, i10 = c10 * id, i20 = c20 * id, i11 = (m00 * m22 - m20 * m20) * id, i21 = (m10 * m20 - m00 * m21) * id,
+                         i22 = (m00 * m11 - m10 * m10) * id;
+            double* vi = a.Vinv + 6 * size_t(p);
+            vi[0] = i00; vi[1] = i10; vi[2] = i11; vi[3] = i20; vi[4] = i21; vi[5] = i22;
+            for (int k = a.pt_start[p]; k < a.pt_start[p + 1]; ++k) {
+                const int o = a.pt_obs[k];
+                if (a.cam_idx[o] == a.fixed) continue;
+                const double* jc = a.Jc + 12 * size_t(o);
+                const double* jp = a.Jp + 6 * size_t(o);
+                double* y = a.Y + 18 * size_t(o);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double w0 = jc[i] * jp[0] + jc[6 + i] * jp[3], w1 = jc[i] * jp[1] + jc[6 + i] * jp[4], w2 = jc[i] * jp[2] + jc[6 + i] * jp[5];
+                    y[3 * i] = w0 * i00 + w1 * i10 + w2 * i20;
+                    y[3 * i + 1] = w0 * i10 + w1 * i11 + w2 * i21;
+                    y[3 * i + 2] = w0 * i20 + w1 * i21 + w2 * i22;
+                }
+            }
+        }
+        {
+            double v[1] = {gmax};
+            mv_block_reduce<1, 0>(v, s_red);  // also orders the Y / Vinv / gp writes before phase E
+            if (tid == 0) {
+                if (v[0] <= 1e-10) { s_state[0] = 1; s_state[2] = kTermGradient; }
+                else if (s_state[1] >= a.max_iters) { s_state[0] = 1; }
+                else s_state[1] += 1;
+            }
+        }
+        first = false;
+        __syncthreads();
+        if (s_state[0]) break;
+        // ---- E: reduced camera system (a wave per block of the upper triangle) ----------------------------------
+        const int nblk = F * (F + 1) / 2;
+        for (int blk = wave; blk < nblk; blk += kMvWaves) {
+            int fa = 0, rem = blk;
+            while (rem >= F - fa) { rem -= F - fa; ++fa; }
+            const int fb = fa + rem, ca = s_free[fa], cb = s_free[fb];
+            double acc[36], rh[6];
+#pragma unroll
+            for (int i = 0; i < 36; ++i) acc[i] = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) rh[i] = 0;
+            for (int k = a.cam_start[ca] + lane; k < a.cam_start[ca + 1]; k += 64) {
+                const int o = a.cam_obs[k], p = a.pt_idx[o];
+                double y[18];
+                const double* yo = a.Y + 18 * size_t(o);
+#pragma unroll
+                for (int i = 0; i < 18; ++i) y[i] = yo[i];
+                if (fa == fb) {
+                    const double g0 = a.gp[3 * p], g1 = a.gp[3 * p + 1], g2 = a.gp[3 * p + 2];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) rh[i] += y[3 * i] * g0 + y[3 * i + 1] * g1 + y[3 * i + 2] * g2;
+                }
+                for (int k2 = a.pt_start[p]; k2 < a.pt_start[p + 1]; ++k2) {
+                    const int o2 = a.pt_obs[k2];
+                    if (a.cam_idx[o2] != cb) continue;
+                    const double* jc = a.Jc + 12 * size_t(o2);
+                    const double* jp = a.Jp + 6 * size_t(o2);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const double w0 = jc[j] * jp[0] + jc[6 + j] * jp[3], w1 = jc[j] * jp[1] + jc[6 + j] * jp[4], w2 = jc[j] * jp[2] + jc[6 + j] * jp[5];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) acc[6 * i + j] += y[3 * i] * w0 + y[3 * i + 1] * w1 + y[3 * i + 2] * w2;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 36; ++i) acc[i] = mv_wsum(acc[i]);
+            if (fa == fb)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) rh[i] = mv_wsum(rh[i]);
+            if (lane == 0) {
+                for (int i = 0; i < 6; ++i) {
+                    for (int j = 0; j < 6; ++j) {
+                        double v = -acc[6 * i + j];
+                        if (fa == fb) v += s_U[36 * fa + 6 * i + j] + (i == j ? s_lam[6 * fa + i] : 0.0);
+                        s_S[(6 * fa + i) * kMvN + 6 * fb + j] = v;
+                        if (fa != fb) s_S[(6 * fb + j) * kMvN + 6 * fa + i] = v;
+                    }
+                    if (fa == fb) s_rhs[6 * fa + i] = -s_gc[6 * fa + i] + rh[i];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- F: Cholesky + solves by wave 0 (lane = row) -------------------------------------------------------
+        if (wave == 0) {
+            bool ok = true;
+            // a camera without observations has an all-zero row: keep it at zero step
+            for (int j = 0; j < n && ok; ++j) {
+                double s = 0.0;
+                if (lane >= j && lane < n) {
+                    s = s_S[lane * kMvN + j];
+                    for (int k = 0; k < j; ++k) s -= s_S[lane * kMvN + k] * s_S[j * kMvN + k];
+                }
+                const double d = __shfl(s, j);
+                if (!(d > 0.0)) { ok = false; break; }
+                const double sd = sqrt(d);
+                if (lane >= j && lane < n) s_S[lane * kMvN + j] = (lane == j) ? sd : s / sd;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (ok) {
+                double b = lane < n ? s_rhs[lane] : 0.0;
+                for (int j = 0; j < n; ++j) {  // L y = b
+                    const double yj = __shfl(b, j) / s_S[j * kMvN + j];
+                    if (lane == j) b = yj;
+                    else if (lane > j && lane < n) b -= s_S[lane * kMvN + j] * yj;
+                }
+                for (int j = n - 1; j >= 0; --j) {  // L^T x = y
+                    const double xj = __shfl(b, j) / s_S[j * kMvN + j];
+                    if (lane == j) b = xj;
+                    else if (lane < j) b -= s_S[j * kMvN + lane] * xj;
+                }
+                if (lane < n) s_dc[lane] = b;
+            }
+            if (lane == 0) s_ctl[5] = ok ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        const bool solved = s_ctl[5] != 0.0;
+        double r4[4] = {0, 0, 0, 0};  // step norm^2, x norm^2, model change, candidate cost*2
+        if (solved) {
+            if (tid < n) {
+                const int c = s_free[tid / 6];
+                s_cand[6 * c + tid % 6] = s_cams[6 * c + tid % 6] + s_dc[tid];
+                r4[0] += s_dc[tid] * s_dc[tid];
+                r4[1] += s_cams[6 * c + tid % 6] * s_cams[6 * c + tid % 6];
+            }
+            if (tid < 6 && a.fixed >= 0 && a.fixed < C) s_cand[6 * a.fixed + tid] = s_cams[6 * a.fixed + tid];
+            // ---- G: point steps ------------------------------------------------------------------------------------
+            for (int p = tid; p < P; p += kMvThreads) {
+                double g0 = a.gp[3 * p], g1 = a.gp[3 * p + 1], g2 = a.gp[3 * p + 2];
+                for (int k = a.pt_start[p]; k < a.pt_start[p + 1]; ++k) {
+                    const int o = a.pt_obs[k], f = s_fidx[a.cam_idx[o]];
+                    if (f < 0) continue;
+                    const double* jc = a.Jc + 12 * size_t(o);
+                    const double* jp = a.Jp + 6 * size_t(o);
+                    double q0 = 0, q1 = 0;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) { q0 += jc[i] * s_dc[6 * f + i]; q1 += jc[6 + i] * s_dc[6 * f + i]; }
+                    g0 += jp[0] * q0 + jp[3] * q1;
+                    g1 += jp[1] * q0 + jp[4] * q1;
+                    g2 += jp[2] * q0 + jp[5] * q1;
+                }
+                const double* vi = a.Vinv + 6 * size_t(p);
+                const double d0 = -(vi[0] * g0 + vi[1] * g1 + vi[3] * g2), d1 = -(vi[1] * g0 + vi[2] * g1 + vi[4] * g2),
+                             d2 = -(vi[3] * g0 + vi[4] * g1 + vi[5] * g2);
+                a.dp[3 * p] = d0; a.dp[3 * p + 1] = d1; a.dp[3 * p + 2] = d2;
+                const double x0 = a.pts[3 * p], x1 = a.pts[3 * p + 1], x2 = a.pts[3 * p + 2];
+                a.cand[3 * p] = x0 + d0; a.cand[3 * p + 1] = x1 + d1; a.cand[3 * p + 2] = x2 + d2;
+                r4[0] += d0 * d0 + d1 * d1 + d2 * d2;
+                r4[1] += x0 * x0 + x1 * x1 + x2 * x2;
+            }
+            __syncthreads();
+            // ---- H: model cost change and candidate cost ----------------------------------------------------------
+            for (int o = tid; o < O; o += kMvThreads) {
+                const int c = a.cam_idx[o], p = a.pt_idx[o], f = s_fidx[c];
+                const double* jc = a.Jc + 12 * size_t(o);
+                const double* jp = a.Jp + 6 * size_t(o);
+                const double d0 = a.dp[3 * p], d1 = a.dp[3 * p + 1], d2 = a.dp[3 * p + 2];
+                double m0 = jp[0] * d0 + jp[1] * d1 + jp[2] * d2, m1 = jp[3] * d0 + jp[4] * d1 + jp[5] * d2;
+                if (f >= 0)
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) { m0 += jc[i] * s_dc[6 * f + i]; m1 += jc[6 + i] * s_dc[6 * f + i]; }
+                r4[2] -= m0 * (a.r[2 * o] + 0.5 * m0) + m1 * (a.r[2 * o + 1] + 0.5 * m1);
+                const double X[3] = {a.cand[3 * p], a.cand[3 * p + 1], a.cand[3 * p + 2]};
+                double q[3];
+                mv_transform(&s_cand[6 * c], c == a.fixed, X, q, nullptr, nullptr, false);
+                const double iz = 1.0 / q[2];
+                const double rx = a.wts[2 * o] * (a.fx * q[0] * iz + a.cx - a.obs[2 * o]), ry = a.wts[2 * o + 1] * (a.fy * q[1] * iz + a.cy - a.obs[2 * o + 1]);
+                r4[3] += rx * rx + ry * ry;
+            }
+        }
+        mv_block_reduce<4, 4>(r4, s_red);
+        // ---- I: trust-region bookkeeping (thread 0) --------------------------------------------------------------
+        if (tid == 0) {
+            const double cost = s_ctl[2], model = r4[2], cand_cost = 0.5 * r4[3];
+            s_ctl[6] = 0.0;  // accept flag
+            if (!solved || !(model > 0.0)) {
+                s_state[3] += 1;
+                if (s_state[3] >= 5) { s_state[0] = 1; s_state[2] = kTermInvalid; }
+                s_ctl[0] /= s_ctl[1];
+                s_ctl[1] *= 2.0;
+            } else {
+                s_state[3] = 0;
+                if (sqrt(r4[0]) <= 1e-8 * (sqrt(r4[1]) + 1e-8)) {
+                    s_state[0] = 1; s_state[2] = kTermParameter;
+                } else {
+                    const double change = cost - cand_cost, rho = change / model;
+                    if (rho > 1e-3) {
+                        s_ctl[6] = 1.0;
+                        s_ctl[2] = cand_cost;
+                        s_ctl[0] = fmin(1e16, s_ctl[0] / fmax(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) * (2.0 * rho - 1.0) * (2.0 * rho - 1.0)));
+                        s_ctl[1] = 2.0;
+                    } else {
+                        s_ctl[0] /= s_ctl[1];
+                        s_ctl[1] *= 2.0;
+                    }
+                    if (fabs(change) <= 1e-6 * cost) { s_state[0] = 1; s_state[2] = kTermFunction; }
+                    else if (s_ctl[0] < 1e-32) { s_state[0] = 1; s_state[2] = kTermRadius; }
+                }
+            }
+        }
+        __syncthreads();
+        if (s_ctl[6] != 0.0) {
+            if (tid < 6 * C) s_cams[tid] = s_cand[tid];
+            for (int i = tid; i < 3 * P; i += kMvThreads) a.pts[i] = a.cand[i];
+        }
+        __syncthreads();
+        if (s_state[0]) break;
+    }
+    if (tid < 6 * C) a.cams[tid] = s_cams[tid];
+    if (tid == 0) {
+        a.summary[1] = s_ctl[2];
+        a.summary[2] = double(s_state[1]);
+        a.summary[3] = double(s_state[2]);
+    }
+}
+
+// one thread per point: homogeneous DLT of two views (cv2.triangulatePoints at bundle_adjust_io.py:226-227)
+__global__ void mv_triangulate_kernel(int n, const double* P0, const double* P1, const double* x0, const double* x1, double* xyz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double A[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        A[k] = x0[2 * i] * P0[8 + k] - P0[k];
+        A[4 + k] = x0[2 * i + 1] * P0[8 + k] - P0[4 + k];
+        A[8 + k] = x1[2 * i] * P1[8 + k] - P1[k];
+        A[12 + k] = x1[2 * i + 1] * P1[8 + k] - P1[4 + k];
+    }
+    // smallest eigenvector of A^T A by cyclic Jacobi (fp64)
+    double M[16], V[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            M[4 * r + c] = A[r] * A[c] + A[4 + r] * A[4 + c] + A[8 + r] * A[8 + c] + A[12 + r] * A[12 + c];
+            V[4 * r + c] = r == c ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 4; ++p)
+            for (int q = p + 1; q < 4; ++q) off += M[4 * p + q] * M[4 * p + q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 4; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                const double apq = M[4 * p + q];
+                if (apq == 0.0) continue;
+                const double theta = (M[4 * q + q] - M[4 * p + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 4; ++k) {
+                    const double mkp = M[4 * k + p], mkq = M[4 * k + q];
+                    M[4 * k + p] = c * mkp - s * mkq;
+                    M[4 * k + q] = s * mkp + c * mkq;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const double mpk = M[4 * p + k], mqk = M[4 * q + k];
+                    M[4 * p + k] = c * mpk - s * mqk;
+                    M[4 * q + k] = s * mpk + c * mqk;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const double vkp = V[4 * k + p], vkq = V[4 * k + q];
+                    V[4 * k + p] = c * vkp - s * vkq;
+                    V[4 * k + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int m = 0;
+    for (int k = 1; k < 4; ++k)
+        if (M[5 * k] < M[5 * m]) m = k;
+    const double w = V[12 + m];
+    xyz[3 * i] = V[m] / w;
+    xyz[3 * i + 1] = V[4 + m] / w;
+    xyz[3 * i + 2] = V[8 + m] / w;
+}
+
+}  // namespace e2emv
+
+using namespace e2emv;
+
+extern "C" int e2emv_mv_bundle_adjust(e2emv_ctx* ctx, int n_cams, int fixed_cam, int n_pts, int n_obs, const double* intr,
+                                      const int32_t* cam_idx, const int32_t* pt_idx, const double* obs_xy, const double* obs_w,
+                                      double* cams, double* pts, int max_iterations, double* summary, void* stream) {
+    if (!ctx) return E2EMV_EINVAL;
+    if (n_cams < 1 || n_cams > kMvMaxCams || n_pts < 0 || n_obs < 0 || !intr || !cams || (n_pts && !pts) ||
+        (n_obs && (!cam_idx || !pt_idx || !obs_xy || !obs_w)))
+        return set_err(ctx, E2EMV_EINVAL, "mv_bundle_adjust: bad argument (1 <= n_cams <= %d)", kMvMaxCams);
+    for (int o = 0; o < n_obs; ++o)
+        if (cam_idx[o] < 0 || cam_idx[o] >= n_cams || pt_idx[o] < 0 || pt_idx[o] >= n_pts)
+            return set_err(ctx, E2EMV_EINVAL, "mv_bundle_adjust: observation %d refers to camera %d / point %d", o, cam_idx[o], pt_idx[o]);
+    hipStream_t s = (hipStream_t)stream;
+    const int C = n_cams, P = n_pts, O = n_obs;
+    // observation lists per point and per camera (stable order -> deterministic sums)
+    std::vector<int> pstart(P + 1, 0), pobs(O), cstart(C + 1, 0), cobs(O);
+    for (int o = 0; o < O; ++o) { ++pstart[pt_idx[o] + 1]; ++cstart[cam_idx[o] + 1]; }
+    for (int p = 0; p < P; ++p) pstart[p + 1] += pstart[p];
+    for (int c = 0; c < C; ++c) cstart[c + 1] += cstart[c];
+    {
+        std::vector<int> pf(pstart.begin(), pstart.end() - 1), cf(cstart.begin(), cstart.end() - 1);
+        for (int o = 0; o < O; ++o) { pobs[pf[pt_idx[o]]++] = o; cobs[cf[cam_idx[o]]++] = o; }
+    }
+    auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+    const size_t nd = size_t(6) * C + size_t(3) * P * 5 + size_t(6) * P + size_t(O) * (2 + 2 + 2 + 12 + 6 + 18) + 8;
+    const size_t ni = size_t(O) * 4 + P + 1 + C + 1;
+    const size_t bytes = al(nd * 8) + al(ni * 4) + 4096;
+    int rc = ws_reserve(ctx, bytes);
+    if (rc) return rc;
+    double* d = reinterpret_cast<double*>(ctx->d_ws);
+    MvbaArgs a{};
+    a.C = C; a.fixed = fixed_cam; a.P = P; a.O = O; a.max_iters = max_iterations;
+    a.fx = intr[0]; a.fy = intr[1]; a.cx = intr[2]; a.cy = intr[3];
+    double* cur = d;
+    auto take = [&](size_t n) { double* q = cur; cur += n; return q; };
+    a.cams = take(6 * C); a.pts = take(3 * size_t(P)); a.gp = take(3 * size_t(P)); a.dp = take(3 * size_t(P));
+    a.scale_p = take(3 * size_t(P)); a.cand = take(3 * size_t(P)); a.Vinv = take(6 * size_t(P));
+    double* d_obs = take(2 * size_t(O)); double* d_w = take(2 * size_t(O));
+    a.r = take(2 * size_t(O)); a.Jc = take(12 * size_t(O)); a.Jp = take(6 * size_t(O)); a.Y = take(18 * size_t(O));
+    a.summary = take(8);
+    int* di = reinterpret_cast<int*>(ctx->d_ws + al(nd * 8));
+    int* d_ci = di; int* d_pi = di + O; int* d_pobs = di + 2 * size_t(O); int* d_cobs = di + 3 * size_t(O);
+    int* d_ps = di + 4 * size_t(O); int* d_cs = d_ps + P + 1;
+    a.obs = d_obs; a.wts = d_w; a.cam_idx = d_ci; a.pt_idx = d_pi; a.pt_obs = d_pobs; a.cam_obs = d_cobs; a.pt_start = d_ps; a.cam_start = d_cs;
+    E2EMV_HIP(ctx, hipMemcpyAsync(a.cams, cams, sizeof(double) * 6 * C, hipMemcpyHostToDevice, s));
+    if (P) E2EMV_HIP(ctx, hipMemcpyAsync(a.pts, pts, sizeof(double) * 3 * P, hipMemcpyHostToDevice, s));
+    if (O) {
+        E2EMV_HIP(ctx, hipMemcpyAsync(d_obs, obs_xy, sizeof(double) * 2 * O, hipMemcpyHostToDevice, s));
+        E2EMV_HIP(ctx, hipMemcpyAsync(d_w, obs_w, sizeof(double) * 2 * O, hipMemcpyHostToDevice, s));
+        E2EMV_HIP(ctx, hipMemcpyAsync(d_ci, cam_idx, sizeof(int) * O, hipMemcpyHostToDevice, s));
+        E2EMV_HIP(ctx, hipMemcpyAsync(d_pi, pt_idx, sizeof(int) * O, hipMemcpyHostToDevice, s));
+        E2EMV_HIP(ctx, hipMemcpyAsync(d_pobs, pobs.data(), sizeof(int) * O, hipMemcpyHostToDevice, s));
+        E2EMV_HIP(ctx, hipMemcpyAsync(d_cobs, cobs.data(), sizeof(int) * O, hipMemcpyHostToDevice, s));
+    }
+    E2EMV_HIP(ctx, hipMemcpyAsync(d_ps, pstart.data(), sizeof(int) * (P + 1), hipMemcpyHostToDevice, s));
+    E2EMV_HIP(ctx, hipMemcpyAsync(d_cs, cstart.data(), sizeof(int) * (C + 1), hipMemcpyHostToDevice, s));
+    E2EMV_HIP(ctx, hipStreamSynchronize(s));  // the host staging vectors die at return
+    prof_begin(ctx, PS_W8PT, s);
+    hipLaunchKernelGGL(mvba_kernel, dim3(1), dim3(kMvThreads), 0, s, a);
+    E2EMV_CHECK_LAUNCH(ctx, "mvba_kernel");
+    prof_end(ctx, s);
+    double sm[4];
+    E2EMV_HIP(ctx, hipMemcpyAsync(cams, a.cams, sizeof(double) * 6 * C, hipMemcpyDeviceToHost, s));
+    if (P) E2EMV_HIP(ctx, hipMemcpyAsync(pts, a.pts, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, s));
+    E2EMV_HIP(ctx, hipMemcpyAsync(sm, a.summary, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
+    E2EMV_HIP(ctx, hipStreamSynchronize(s));
+    if (summary) std::memcpy(summary, sm, sizeof(sm));
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_mv_bundle_adjust_files(e2emv_ctx* ctx, const char* in_csv, const char* out_csv, void* stream) {
+    if (!ctx) return E2EMV_EINVAL;
+    if (!in_csv || !out_csv) return set_err(ctx, E2EMV_EINVAL, "mv_bundle_adjust_files: NULL path");
+    std::ifstream file(in_csv);
+    if (!file) return set_err(ctx, E2EMV_EINVAL, "mv_bundle_adjust_files: cannot open %s", in_csv);
+    int n_cams = -1, fixed = 0, n_pts = 0, n_obs = 0;
+    double intr[4] = {1, 1, 0, 0};
+    std::vector<int> ci, pi;
+    std::vector<double> obs, wts, cams, pts;
+    std::string line;
+    try {
+        while (std::getline(file, line)) {  // rows are classified by their field count (ba_problem.cpp:15-87)
+            const auto el = mv::split_by_char(line, ',');
+            const size_t k = el.size();
+            if (k == 8) {
+                n_cams = std::stoi(el[0]); fixed = std::stoi(el[1]); n_pts = std::stoi(el[2]); n_obs = std::stoi(el[3]);
+                for (int i = 0; i < 4; ++i) intr[i] = std::stod(el[4 + i]);
+            } else if (k == 3) {
+                for (int i = 0; i < 3; ++i) pts.push_back(std::stod(el[i]));
+            } else if (k >= 4 && k <= 6) {
+                ci.push_back(std::stoi(el[0])); pi.push_back(std::stoi(el[1]));
+                obs.push_back(std::stod(el[2])); obs.push_back(std::stod(el[3]));
+                double wx = 1.0, wy = 1.0;
+                if (k == 5) wx = wy = std::stod(el[4]);
+                if (k == 6) { wx = std::stod(el[4]); wy = std::stod(el[5]); }
+                wts.push_back(wx); wts.push_back(wy);
+            } else if (k == 12) {
+                double R[9], aa[3];
+                for (int i = 0; i < 9; ++i) R[i] = std::stod(el[i]);
+                mv::R_to_aa(R, aa);
+                cams.insert(cams.end(), aa, aa + 3);
+                for (int i = 9; i < 12; ++i) cams.push_back(std::stod(el[i]));
+            }
+        }
+    } catch (...) {
+        return set_err(ctx, E2EMV_EINVAL, "mv_bundle_adjust_files: malformed number in %s", in_csv);
+    }
+    if (n_cams < 1 || int(cams.size()) != 6 * n_cams || int(pts.size()) != 3 * n_pts || int(ci.size()) != n_obs)
+        return set_err(ctx, E2EMV_ESHAPE, "mv_bundle_adjust_files: header says %d cameras / %d points / %d observations, file holds %zu / %zu / %zu",
+                       n_cams, n_pts, n_obs, cams.size() / 6, pts.size() / 3, ci.size());
+    double summary[4];
+    const int rc = e2emv_mv_bundle_adjust(ctx, n_cams, fixed, n_pts, n_obs, intr, ci.data(), pi.data(), obs.data(), wts.data(), cams.data(),
+                                          pts.data(), 50, summary, stream);
+    if (rc) return rc;
+    std::ofstream out(out_csv);
+    if (!out) return set_err(ctx, E2EMV_EINVAL, "mv_bundle_adjust_files: cannot write %s", out_csv);
+    for (int c = 0; c < n_cams; ++c) {  // WriteResult (ba_problem.cpp:98-113): R column-major then t
+        double R[9];
+        mv::aa_to_R(&cams[6 * c], R);
+        for (int i = 0; i < 9; ++i) out << std::setprecision(12) << R[i] << ",";
+        out << cams[6 * c + 3] << "," << cams[6 * c + 4] << "," << cams[6 * c + 5] << "\n";
+    }
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_mv_triangulate(e2emv_ctx* ctx, int n, const double* P0, const double* P1, const double* x0, const double* x1,
+                                    double* xyz, void* stream) {
+    if (!ctx) return E2EMV_EINVAL;
+    if (n < 0 || !P0 || !P1 || (n && (!x0 || !x1 || !xyz))) return set_err(ctx, E2EMV_EINVAL, "mv_triangulate: bad argument");
+    if (n == 0) return E2EMV_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nd = 24 + size_t(n) * 7;
+    int rc = ws_reserve(ctx, nd * 8 + 256);
+    if (rc) return rc;
+    double* d = reinterpret_cast<double*>(ctx->d_ws);
+    E2EMV_HIP(ctx, hipMemcpyAsync(d, P0, 96, hipMemcpyHostToDevice, s));
+    E2EMV_HIP(ctx, hipMemcpyAsync(d + 12, P1, 96, hipMemcpyHostToDevice, s));
+    E2EMV_HIP(ctx, hipMemcpyAsync(d + 24, x0, 16 * size_t(n), hipMemcpyHostToDevice, s));
+    E2EMV_HIP(ctx, hipMemcpyAsync(d + 24 + 2 * size_t(n), x1, 16 * size_t(n), hipMemcpyHostToDevice, s));
+    double* dx = d + 24 + 4 * size_t(n);
+    hipLaunchKernelGGL(mv_triangulate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d, d + 12, d + 24, d + 24 + 2 * size_t(n), dx);
+    E2EMV_CHECK_LAUNCH(ctx, "mv_triangulate_kernel");
+    E2EMV_HIP(ctx, hipMemcpyAsync(xyz, dx, 24 * size_t(n), hipMemcpyDeviceToHost, s));
+    E2EMV_HIP(ctx, hipStreamSynchronize(s));
+    return E2EMV_OK;
+}

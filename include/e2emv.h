@@ -195,6 +195,25 @@ int e2emv_mv_estimate_positions(int n_views, int n_pairs, const int32_t* pair_id
 /* `ba_init_in.csv` -> `ba_init_out.csv` (ba_initializer.cpp:7-23; wire format ba_init.cpp:13-51, 58-75).           */
 int e2emv_mv_init_files(const char* in_csv, const char* out_csv);
 
+/* Weighted reprojection bundle adjustment of <= E2EMV_MAX_TUPLE cameras on the DEVICE = the reference's
+ * `bundle_adjuster` executable (problem/include/ba_problem.h:60-151, problem/src/ba_problem.cpp:115-157: Ceres
+ * DENSE_SCHUR, squared loss, default options, restated as a Levenberg-Marquardt trust-region loop with an analytic
+ * Schur complement; one workgroup runs the whole optimisation).  All pointers are HOST memory (the wire format is
+ * CSV / numpy): intr = {fx, fy, cx, cy}; observation o = (cam_idx, pt_idx, obs_xy[2], obs_w[2] = residual weights);
+ * cams [n_cams,6] = angle-axis + translation, world -> camera, in/out; pts [n_pts,3] in/out.  The fixed camera is
+ * predicted with the IDENTITY pose and its row is returned untouched (ba_problem.cpp:129-137).  summary[4] =
+ * {initial cost, final cost, iterations, termination: 0 max-iterations 1 gradient 2 parameter 3 function tolerance,
+ * 4 five invalid steps, 5 radius underflow}.  Synchronous.                                                           */
+int e2emv_mv_bundle_adjust(e2emv_ctx* ctx, int n_cams, int fixed_cam, int n_pts, int n_obs, const double* intr,
+                           const int32_t* cam_idx, const int32_t* pt_idx, const double* obs_xy, const double* obs_w,
+                           double* cams, double* pts, int max_iterations, double* summary, void* stream);
+/* `ba_in.csv` -> `ba_out.csv` (bundle_adjuster.cpp:7-23; parser ba_problem.cpp:8-88, writer :98-113), 50 iterations. */
+int e2emv_mv_bundle_adjust_files(e2emv_ctx* ctx, const char* in_csv, const char* out_csv, void* stream);
+/* cv2.triangulatePoints as used by write_bundle_adjust_problem (bundle_adjust_io.py:226-227): homogeneous DLT of
+ * two views, one thread per point, fp64.  HOST pointers: P0, P1 [3,4] row-major, x0, x1 [n,2], xyz [n,3].           */
+int e2emv_mv_triangulate(e2emv_ctx* ctx, int n, const double* P0, const double* P1, const double* x0, const double* x1,
+                         double* xyz, void* stream);
+
 /* ---- building blocks exported for per-kernel parity tests and micro-benchmarks ----- */
 /* C[z][m][n] = act(sum_k A[z][m][k] W[z][n][k] * scale + bias[n]) (+ R[z][m][n]); all f32;
  * A may be split in two K-segments (A: k < K1, A2: K1 <= k < K).  flags: bit0 relu.        */

@@ -272,8 +272,80 @@ def gen_superglue_hf():
     print("superglue_hf_small.npz", "matched:", int((matches[:, 0] >= 0).sum()))
 
 
+def gen_multi_view():
+    """Multi-view back-end host logic: the reference's own bundle_adjust_io.py (imported unmodified) turns a 4-image
+    tuple's matches into ``ba_init_in.csv`` and ``ba_in.csv``.  Absent third-party names it imports are provided in
+    memory: kornia / pytorch3d as above, ``cv2.triangulatePoints`` by the homogeneous-DLT restatement in
+    oracle/mvba.py, ``models.models.utils.estimate_pose`` (RANSAC, unused by the default ``w8pt_ba`` method) by a stub;
+    ``Tensor.cuda()`` is the identity here (no GPU in the build container).  scipy's spanning tree is the real one."""
+    install_reference_shims()
+    import tempfile
+    from oracle import mvba
+    cv2 = types.ModuleType("cv2")
+
+    def triangulatePoints(P0, P1, x0, x1):
+        xyz = mvba.triangulate_dlt(np.asarray(P0, np.float64), np.asarray(P1, np.float64), np.asarray(x0, np.float64).T,
+                                   np.asarray(x1, np.float64).T)
+        return np.concatenate([xyz, np.ones((len(xyz), 1))], 1).T
+    cv2.triangulatePoints = triangulatePoints
+    models = types.ModuleType("models")
+    models.models = types.ModuleType("models.models")
+    utils = types.ModuleType("models.models.utils")
+
+    def estimate_pose(*a, **k):
+        raise RuntimeError("RANSAC is outside the golden fixture")
+    utils.estimate_pose = estimate_pose
+    models.models.utils = utils
+    sys.modules.update({"cv2": cv2, "models": models, "models.models": models.models, "models.models.utils": utils})
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import warnings
+    warnings.filterwarnings("ignore")
+    from pose_optimization.multi_view import bundle_adjust_io as IO
+    from e2e_multi_view_matching_amd.synthetic import make_tuples
+    T, N = 4, 160
+    d = make_tuples(batch=1, tuple_size=T, n_kpts=N, seed=11, rho=0.6, noise_px=0.7, max_angle=0.3, transl_sigma=0.5)
+    g = torch.Generator().manual_seed(3)
+    data = {k: v for k, v in d.items() if k.startswith(("keypoints", "intr"))}
+    result, out = {}, {}
+    for j in range(T):
+        for i in range(j):
+            m = d[f"gt_matches{i}_{i}_{j}"].clone()
+            if (i, j) == (1, 3):  # a weak pair: below min_inliers unless it lies on the spanning tree
+                keep = torch.nonzero(m[0] >= 0)[:14, 0]
+                mm = torch.full_like(m, -1)
+                mm[0, keep] = m[0, keep]
+                m = mm
+            drop = torch.rand(m.shape, generator=g) < 0.1
+            m[drop] = -1
+            wrong = torch.rand(m.shape, generator=g) < 0.05  # a few wrong matches with low confidence
+            m[wrong & (m >= 0)] = torch.randint(0, N, (int((wrong & (m >= 0)).sum()),), generator=g)
+            conf = torch.rand(1, N, 1, generator=g) * 0.8 + 0.2
+            conf[wrong.unsqueeze(-1)] *= 0.05
+            result[f"matches{i}_{i}_{j}"] = m
+            result[f"conf_scores_{i}_{j}"] = conf
+            out[f"matches{i}_{i}_{j}"], out[f"conf_scores_{i}_{j}"] = m.numpy(), conf.numpy()
+    for k, v in data.items():
+        out[k] = v.numpy()
+    tmp = tempfile.mkdtemp()
+    pw = IO.initialize_bundle_adjust(T, data, result, os.path.join(tmp, "ba_init_in.csv"))
+    extr = np.stack([d[f"pose{m}"][0].numpy().astype(np.float64) for m in range(T)])
+    extr[1:, :3, 3] += 0.01  # any consistent-ish start: the writer only triangulates with it
+    IO.write_bundle_adjust_problem(T, pw, extr, os.path.join(tmp, "ba_in.csv"))
+    for name in ("ba_init_in", "ba_in"):
+        rows = [[float(x) for x in line.split(",")] for line in open(os.path.join(tmp, name + ".csv"))]
+        out[name + "_len"] = np.array([len(r) for r in rows])
+        out[name + "_flat"] = np.array([x for r in rows for x in r])
+    out["extrinsics"] = extr
+    out["inlier_counts"] = np.array([pw[f"inlier_count{i}_{j}"] for j in range(T) for i in range(j)])
+    np.savez_compressed(os.path.join(HERE, "multi_view_io_reference.npz"), **out)
+    print("multi_view_io_reference.npz rows:", len(out["ba_init_in_len"]), len(out["ba_in_len"]), "inliers", out["inlier_counts"])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if "--multi-view" in sys.argv:
+        gen_multi_view()
+        sys.exit(0)
     gen_sinkhorn_hf()
     gen_superglue_hf()
     gen_w8pt()
