@@ -341,8 +341,47 @@ def gen_multi_view():
     print("multi_view_io_reference.npz rows:", len(out["ba_init_in_len"]), len(out["ba_in_len"]), "inliers", out["inlier_counts"])
 
 
+def gen_superpoint_hf():
+    """SuperPoint front-end: the HuggingFace port of upstream magicleap SuperPoint (transformers
+    models/superpoint/modeling_superpoint.py) with seeded random weights (oracle.superpoint.seeded_state re-creates them
+    in the tests, so the fixture stores only images and outputs)."""
+    from transformers import SuperPointConfig, SuperPointForKeypointDetection
+    from oracle import superpoint as OS
+    sd = OS.seeded_state(0)
+    names = {"conv1a": "encoder.conv_blocks.0.conv_a", "conv1b": "encoder.conv_blocks.0.conv_b", "conv2a": "encoder.conv_blocks.1.conv_a",
+             "conv2b": "encoder.conv_blocks.1.conv_b", "conv3a": "encoder.conv_blocks.2.conv_a", "conv3b": "encoder.conv_blocks.2.conv_b",
+             "conv4a": "encoder.conv_blocks.3.conv_a", "conv4b": "encoder.conv_blocks.3.conv_b", "convPa": "keypoint_decoder.conv_score_a",
+             "convPb": "keypoint_decoder.conv_score_b", "convDa": "descriptor_decoder.conv_descriptor_a",
+             "convDb": "descriptor_decoder.conv_descriptor_b"}
+    g = torch.Generator().manual_seed(42)
+    H, W, B = 96, 128, 2
+    img = torch.rand(B, 1, H, W, generator=g)
+    img = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(img, (2, 2, 2, 2), mode="reflect"), 5, 1)  # smooth-ish texture
+    img = (img - img.amin()) / (img.amax() - img.amin())
+    out = {"image": img.numpy()}
+    for tag, maxk in (("all", -1), ("top", 48)):
+        # border_removal_distance = 0: the HF port passes the FULL-resolution height/width times 8 to its border filter
+        # (modeling_superpoint.py `_extract_keypoints`), so only the low borders are removed there; upstream passes the
+        # coarse h*8, w*8.  The oracle follows upstream; the border rule is covered by a property test instead.
+        cfg = SuperPointConfig(keypoint_threshold=0.005, max_keypoints=maxk, nms_radius=3 if tag == "top" else 4, border_removal_distance=0)
+        model = SuperPointForKeypointDetection(cfg).eval()
+        model.load_state_dict({names[k.rsplit(".", 1)[0]] + "." + k.rsplit(".", 1)[1]: v for k, v in sd.items()})
+        with torch.no_grad():
+            r = model(img.expand(B, 3, H, W))
+        n = r.mask.sum(1)
+        out[f"{tag}/count"] = n.numpy()
+        out[f"{tag}/keypoints"] = torch.round(r.keypoints * torch.tensor([W, H])).numpy()  # HF returns relative coordinates
+        out[f"{tag}/scores"] = r.scores.numpy()
+        out[f"{tag}/descriptors"] = r.descriptors[:, :64].numpy()  # [B, first 64 keypoints, 256] (keeps the fixture small)
+        print("superpoint_hf", tag, "keypoints per image:", n.tolist())
+    np.savez_compressed(os.path.join(HERE, "superpoint_hf.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if "--superpoint" in sys.argv:
+        gen_superpoint_hf()
+        sys.exit(0)
     if "--multi-view" in sys.argv:
         gen_multi_view()
         sys.exit(0)
@@ -351,3 +390,5 @@ if __name__ == "__main__":
     gen_w8pt()
     gen_ba()
     gen_gt_matches()
+    gen_superpoint_hf()
+    gen_multi_view()
