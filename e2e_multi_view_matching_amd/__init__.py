@@ -12,9 +12,10 @@ from .ops import (attention, attention_bf16x3, extract_matches, gemm_bf16x3, gem
 from .pose import (compute_rotation_error, compute_translation_error_as_angle, estimate_relative_pose_w8pt,  # noqa: F401
                    get_kpts, normalize, pose_errors, run_bundle_adjust_2_view, run_weighted_8_point)
 
+from .superpoint import SuperPoint  # noqa: F401,E402
 from .targets import (compute_gt_matches, compute_gt_matches_of_image_pair, compute_match_loss,  # noqa: F401,E402
                       run_matcher)
 
-__all__ = ["compute_gt_matches", "compute_gt_matches_of_image_pair", "compute_match_loss", "run_matcher", "MultiViewMatcher", "SuperGlue", "estimate_relative_pose_w8pt", "run_weighted_8_point", "get_kpts",
+__all__ = ["SuperPoint", "compute_gt_matches", "compute_gt_matches_of_image_pair", "compute_match_loss", "run_matcher", "MultiViewMatcher", "SuperGlue", "estimate_relative_pose_w8pt", "run_weighted_8_point", "get_kpts",
            "run_bundle_adjust_2_view", "normalize", "compute_rotation_error", "compute_translation_error_as_angle", "pose_errors", "pose_auc",
            "compute_pose_error", "log_optimal_transport", "extract_matches", "gemm_nt", "attention"]

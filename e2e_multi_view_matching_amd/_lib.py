@@ -36,6 +36,12 @@ class ForwardDesc(ctypes.Structure):
                 ("n_kpts_img", ctypes.c_int32 * MAX_TUPLE)]
 
 
+class SuperPointDesc(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32), ("nms_radius", ctypes.c_int32),
+                ("max_keypoints", ctypes.c_int32), ("remove_borders", ctypes.c_int32), ("fill_random", ctypes.c_int32),
+                ("keypoint_threshold", ctypes.c_float), ("seed", ctypes.c_uint32)]
+
+
 # every symbol include/e2emv.h declares: name -> (restype, argtypes)
 _PP = ctypes.POINTER(c_void_p)
 SIGNATURES = {
@@ -73,6 +79,9 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "e2emv_mv_bundle_adjust_files": (c_int, [c_void_p, c_char_p, c_char_p, c_void_p]),
     "e2emv_mv_triangulate": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e2emv_superpoint_commit": (c_int, [c_void_p]),
+    "e2emv_superpoint_forward": (c_int, [c_void_p, ctypes.POINTER(SuperPointDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p]),
     "e2emv_gemm_nt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                               c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                               c_int64, c_float, c_int, c_void_p]),

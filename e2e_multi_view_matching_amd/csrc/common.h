@@ -85,6 +85,11 @@ struct e2emv_ctx {
     float* b_conf0 = nullptr;
     float* w_conf1 = nullptr;  // [D]
     float b_conf1 = 0.f;
+    // SuperPoint front-end (superpoint.hip): packed conv weights [Cout][ky][kx][Cin] + biases
+    bool sp_committed = false;
+    float* d_sparena = nullptr;
+    float* sp_w[12] = {nullptr};
+    float* sp_b[12] = {nullptr};
     // workspace arena
     char* d_ws = nullptr;
     size_t ws_bytes = 0;
@@ -145,6 +150,8 @@ struct GemmArgs {
     float q_scale = 1.f;
     float scale = 1.f;
     bool relu = false;
+    // implicit-GEMM 3x3 convolution (pad 1, stride 1) over NHWC activations: A = input [imgs*H*W][conv_c], K = 9*conv_c
+    int conv_h = 0, conv_w = 0, conv_c = 0;
 };
 int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s);
 

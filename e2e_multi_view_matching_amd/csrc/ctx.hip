@@ -105,6 +105,7 @@ void e2emv_destroy(e2emv_ctx* ctx) {
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_warena) (void)hipFree(ctx->d_warena);
     if (ctx->d_w3arena) (void)hipFree(ctx->d_w3arena);
+    if (ctx->d_sparena) (void)hipFree(ctx->d_sparena);
     for (auto& pe : ctx->prof_events) {
         (void)hipEventDestroy(pe.a);
         (void)hipEventDestroy(pe.b);
@@ -161,8 +162,9 @@ int e2emv_set_weight(e2emv_ctx* ctx, const char* key, const float* data, const i
         n *= shape[i];
     }
     t.data.assign(data, data + n);
+    const bool sp = k.rfind("superpoint.", 0) == 0;  // front-end weights (superpoint.hip) live beside the matcher's
     ctx->raw[k] = std::move(t);
-    ctx->committed = false;
+    if (sp) ctx->sp_committed = false; else ctx->committed = false;
     return E2EMV_OK;
 }
 

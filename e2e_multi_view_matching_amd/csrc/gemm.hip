@@ -59,6 +59,9 @@ struct GemmParams {
     float scale;
     int relu;
     int vec_store;  // 1: N % 4 == 0 and C/R rows 16-byte aligned -> dwordx4 epilogue
+    // CONV (implicit GEMM of a 3x3 / pad 1 / stride 1 convolution over NHWC activations): row m = pixel (img, y, x),
+    // K = 9 * conv_c ordered (ky, kx, cin); A = the NHWC input, taps outside the image read as zero
+    int conv_h, conv_w, conv_c;
 };
 
 // Persistent kernel: gridDim.x = 8 * slots workgroups (2 per CU); workgroup (xcd = id & 7,
@@ -70,7 +73,7 @@ struct GemmParams {
 // EXT = true adds the bf16x3-plane outputs (C3, V^T with swapped operand roles, q pre-scale) used by the
 // q|k|v GEMM of the split-operand attention path; it gets a 256-VGPR budget (2 workgroups/CU) so that the
 // plain kernel (EXT = false, every other GEMM) keeps its spill-free 168-VGPR / 3-workgroups-per-CU build.
-template <bool EXT, int BK, int DBG = 0>
+template <bool EXT, int BK, int DBG = 0, bool CONV = false>
 __global__ __launch_bounds__(256, (EXT || BK == 64) ? 2 : 3) void gemm_nt_kernel(GemmParams p) {
     constexpr int LDK = BK + 4;           // 36: 36*i mod 64, 68: 4*i mod 64 - both give 16 distinct 16-byte slots
     constexpr int CPR = BK / 4;           // 16-byte chunks per tile row
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(256, (EXT || BK == 64) ? 2 : 3) void gemm_nt_kernel
     const float* a_ptr[NCH];
     const float* a2_ptr[NCH];
     const float* w_ptr[NCH];
+    int cy[CONV ? NCH : 1], cx[CONV ? NCH : 1];  // CONV: pixel coordinates of this thread's A rows
     auto setup = [&](int t) {
         const int z = t / tiles_mn, r = t - z * tiles_mn;
         const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
@@ -111,6 +115,11 @@ __global__ __launch_bounds__(256, (EXT || BK == 64) ? 2 : 3) void gemm_nt_kernel
             const int ra = min(tm * BM + ld_row + RSTEP * i, p.M - 1);
             const int rw = min(tn * BN + ld_row + RSTEP * i, p.N - 1);
             a_ptr[i] = A + (int64_t)ra * p.lda + ld_c4;
+            if (CONV) {
+                const int rem = ra % (p.conv_h * p.conv_w);
+                cy[i] = rem / p.conv_w;
+                cx[i] = rem - cy[i] * p.conv_w;
+            }
             a2_ptr[i] = A2 ? A2 + (int64_t)ra * p.lda2 + ld_c4 : nullptr;
             w_ptr[i] = W + (int64_t)rw * p.ldw + ld_c4;
         }
@@ -119,6 +128,20 @@ __global__ __launch_bounds__(256, (EXT || BK == 64) ? 2 : 3) void gemm_nt_kernel
     f32x4 ra[NCH], rb[NCH];
     auto gload = [&](int kt) {
         const int k = kt * BK;
+        if (CONV) {
+            const int tap = k / p.conv_c, ci = k - tap * p.conv_c;  // a K tile never straddles two taps (conv_c % BK == 0)
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const int off = (dy * p.conv_w + dx) * p.conv_c + ci;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const bool ok = (unsigned)(cy[i] + dy) < (unsigned)p.conv_h && (unsigned)(cx[i] + dx) < (unsigned)p.conv_w;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + off);
+                ra[i] = v;
+                rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + k);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const float* src = (k < p.K1) ? a_ptr[i] + k : a2_ptr[i] + (k - p.K1);
@@ -317,6 +340,11 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
     p.lda = a.lda; p.lda2 = a.lda2; p.ldw = a.ldw; p.ldr = a.ldr; p.ldc = a.ldc;
     p.sA = a.sA; p.sA2 = a.sA2; p.sW = a.sW; p.sR = a.sR; p.sC = a.sC;
     p.M = a.M; p.N = a.N; p.K = a.K; p.K1 = K1;
+    p.conv_h = a.conv_h; p.conv_w = a.conv_w; p.conv_c = a.conv_c;
+    const bool conv = a.conv_c > 0;
+    if (conv && (a.conv_c % 32 || a.K != 9 * a.conv_c || a.A2 || a.batch != 1 || a.conv_h <= 0 || a.conv_w <= 0 ||
+                 a.M % (a.conv_h * a.conv_w) || a.lda != a.conv_c || a.C3 || a.Vt || a.q_cols > 0))
+        return set_err(ctx, E2EMV_ESHAPE, "gemm: conv mode needs NHWC input with C %% 32 == 0, K = 9 C, whole images, batch 1");
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + BN - 1) / BN;
     p.total = p.tiles_m * p.tiles_n * a.batch;
@@ -338,11 +366,13 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
     // loop sits at ~125 TFLOP/s (MFMA pipe ~82 % busy at ~2.3 GHz) whatever the schedule.  E2EMV_GEMM_BK=64 keeps
     // the variant reachable for profiling.
     int bk = 32;
-    if (bk_env == 64 && a.K % 64 == 0 && K1 % 64 == 0 && !ext) bk = 64;
+    if (bk_env == 64 && a.K % 64 == 0 && K1 % 64 == 0 && !ext && !conv) bk = 64;
     const int per_cu = wg > 0 ? wg : ((ext || bk == 64) ? 2 : 3);
     const int sl = std::min(per_xcd, std::max(1, ctx->num_cus * per_cu / 8));
     const size_t lds = sizeof(float) * (BM + BN) * (bk + 4);
-    if (bk == 64) {
+    if (conv) {
+        hipLaunchKernelGGL((gemm_nt_kernel<false, 32, 0, true>), dim3(8 * sl), dim3(256), lds, s, p);
+    } else if (bk == 64) {
         static bool attr_set = false;
         if (!attr_set) {
             E2EMV_HIP(ctx, hipFuncSetAttribute((const void*)gemm_nt_kernel<false, 64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

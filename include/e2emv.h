@@ -214,6 +214,31 @@ int e2emv_mv_bundle_adjust_files(e2emv_ctx* ctx, const char* in_csv, const char*
 int e2emv_mv_triangulate(e2emv_ctx* ctx, int n, const double* P0, const double* P1, const double* x0, const double* x1,
                          double* xyz, void* stream);
 
+/* ---- SuperPoint front-end --------------------------------------
+ * Replaces models.models.superpoint.SuperPoint (absent submodule; call sites helpers.py:73-96, configs train.py:335-341,
+ * eval_pairs.py:197-202, eval_multi_view.py:135-140) = upstream magicleap SuperPoint.  Weights go in through
+ * e2emv_set_weight with the upstream parameter names prefixed by "superpoint." (superpoint.conv1a.weight [64,1,3,3] ...
+ * superpoint.convDb.bias [256]; layers conv1a conv1b conv2a conv2b conv3a conv3b conv4a conv4b convPa convPb convDa
+ * convDb), then e2emv_superpoint_commit repacks them for NHWC implicit-GEMM convolutions.                          */
+typedef struct {
+    int32_t batch;             /* images in this call (a merged tuple batch, helpers.py:73-81)                      */
+    int32_t height, width;     /* multiples of 8                                                                      */
+    int32_t nms_radius;        /* config "nms_radius"                                                                 */
+    int32_t max_keypoints;     /* K: capacity of the outputs, 1..4096 (config "max_keypoints"; -1 is mapped by the
+                                  Python layer to the capacity)                                                       */
+    int32_t remove_borders;    /* config "remove_borders"                                                             */
+    int32_t fill_random;       /* fork option "fill_with_random_keypoints": pad to K with pseudo-random pixels        */
+    float keypoint_threshold;  /* config "keypoint_threshold"                                                         */
+    uint32_t seed;             /* for fill_random                                                                     */
+} e2emv_superpoint_desc;
+int e2emv_superpoint_commit(e2emv_ctx* ctx);
+/* d_images [B,H,W] fp32 grey in [0,1].  Outputs: d_kpts [B,K,2] pixel (x, y), d_scores [B,K], d_desc [B,256,K]
+ * (descriptor-major, what the matcher's descriptors{m} input wants), d_count [B] valid entries per image (the rest is
+ * zero).  Order: row-major when an image has <= K candidates, else score-descending (ties: lower pixel index).
+ * d_score_map (optional) [B,H,W] receives the NMS-ed score map.                                                        */
+int e2emv_superpoint_forward(e2emv_ctx* ctx, const e2emv_superpoint_desc* desc, const float* d_images, float* d_kpts,
+                             float* d_scores, float* d_desc, int32_t* d_count, float* d_score_map, void* stream);
+
 /* ---- building blocks exported for per-kernel parity tests and micro-benchmarks ----- */
 /* C[z][m][n] = act(sum_k A[z][m][k] W[z][n][k] * scale + bias[n]) (+ R[z][m][n]); all f32;
  * A may be split in two K-segments (A: k < K1, A2: K1 <= k < K).  flags: bit0 relu.        */
