@@ -152,6 +152,7 @@ struct GemmArgs {
     bool relu = false;
     // implicit-GEMM 3x3 convolution (pad 1, stride 1) over NHWC activations: A = input [imgs*H*W][conv_c], K = 9*conv_c
     int conv_h = 0, conv_w = 0, conv_c = 0;
+    bool conv_pool = false;  // fuse the following 2x2 / stride-2 max-pool (output [imgs*(H/2)*(W/2)][N])
 };
 int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s);
 

@@ -62,6 +62,9 @@ struct GemmParams {
     // CONV (implicit GEMM of a 3x3 / pad 1 / stride 1 convolution over NHWC activations): row m = pixel (img, y, x),
     // K = 9 * conv_c ordered (ky, kx, cin); A = the NHWC input, taps outside the image read as zero
     int conv_h, conv_w, conv_c;
+    // conv_pool: rows are enumerated quad-major (4 consecutive rows = one 2x2 block of pixels) and the epilogue writes
+    // their maximum: the 2x2 / stride-2 max-pool that follows conv1b / conv2b / conv3b never touches memory
+    int conv_pool;
 };
 
 // Persistent kernel: gridDim.x = 8 * slots workgroups (2 per CU); workgroup (xcd = id & 7,
@@ -73,11 +76,15 @@ struct GemmParams {
 // EXT = true adds the bf16x3-plane outputs (C3, V^T with swapped operand roles, q pre-scale) used by the
 // q|k|v GEMM of the split-operand attention path; it gets a 256-VGPR budget (2 workgroups/CU) so that the
 // plain kernel (EXT = false, every other GEMM) keeps its spill-free 168-VGPR / 3-workgroups-per-CU build.
-template <bool EXT, int BK, int DBG = 0, bool CONV = false>
-__global__ __launch_bounds__(256, (EXT || BK == 64) ? 2 : 3) void gemm_nt_kernel(GemmParams p) {
+// TN = 2: 128 x 128 output tile, waves 2 x 2 (the default).  TN = 1: 256 x 64 tile, waves 4 x 1 - for outputs only 64
+// channels wide (SuperPoint's conv1b / conv2a / conv2b), where half of a 128-wide tile would multiply padding.
+template <bool EXT, int BK, int DBG = 0, bool CONV = false, int TN = 2>
+__global__ __launch_bounds__(256, (EXT || BK == 64 || TN == 1) ? 2 : 3) void gemm_nt_kernel(GemmParams p) {
+    constexpr int BM = TN == 2 ? 128 : 256, BN = TN == 2 ? 128 : 64;  // shadow the namespace-scope defaults
     constexpr int LDK = BK + 4;           // 36: 36*i mod 64, 68: 4*i mod 64 - both give 16 distinct 16-byte slots
     constexpr int CPR = BK / 4;           // 16-byte chunks per tile row
-    constexpr int NCH = BM * CPR / 256;   // chunks per thread and operand (4 or 8)
+    constexpr int NCH = BM * CPR / 256;   // chunks per thread of the activation tile (4 or 8)
+    constexpr int NCHB = BN * CPR / 256;  // chunks per thread of the weight tile
     constexpr int RSTEP = 256 / CPR;      // rows covered by one pass of the 256 threads (32 or 16)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [BM][BK + 4]  activations
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(256, (EXT || BK == 64) ? 2 : 3) void gemm_nt_kernel
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = TN == 2 ? wave >> 1 : wave, wc = TN == 2 ? (wave & 1) : 0;
     const int l31 = lane & 31, lh = lane >> 5;
     const int ld_row = tid / CPR;           // (+RSTEP*i)
     const int ld_c4 = (tid % CPR) * 4;      // float offset inside the K tile
@@ -102,8 +109,8 @@ __global__ __launch_bounds__(256, (EXT || BK == 64) ? 2 : 3) void gemm_nt_kernel
     // operand pointers of the tile whose K tiles are being PREFETCHED
     const float* a_ptr[NCH];
     const float* a2_ptr[NCH];
-    const float* w_ptr[NCH];
-    int cy[CONV ? NCH : 1], cx[CONV ? NCH : 1];  // CONV: pixel coordinates of this thread's A rows
+    const float* w_ptr[NCHB];
+    int cyx[CONV ? NCH : 1];  // CONV: pixel coordinates (y << 16 | x) of this thread's A rows
     auto setup = [&](int t) {
         const int z = t / tiles_mn, r = t - z * tiles_mn;
         const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
@@ -111,21 +118,32 @@ __global__ __launch_bounds__(256, (EXT || BK == 64) ? 2 : 3) void gemm_nt_kernel
         const float* A2 = p.A2 ? p.A2 + z * p.sA2 : nullptr;
         const float* W = p.W + z * p.sW;
 #pragma unroll
+        for (int i = 0; i < NCHB; ++i) {
+            const int rw = min(tn * BN + ld_row + RSTEP * i, p.N - 1);
+            w_ptr[i] = W + (int64_t)rw * p.ldw + ld_c4;
+        }
+#pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ra = min(tm * BM + ld_row + RSTEP * i, p.M - 1);
-            const int rw = min(tn * BN + ld_row + RSTEP * i, p.N - 1);
             a_ptr[i] = A + (int64_t)ra * p.lda + ld_c4;
             if (CONV) {
-                const int rem = ra % (p.conv_h * p.conv_w);
-                cy[i] = rem / p.conv_w;
-                cx[i] = rem - cy[i] * p.conv_w;
+                if (p.conv_pool) {
+                    const int q = ra >> 2, sub = ra & 3, wq = p.conv_w >> 1, quads = (p.conv_h >> 1) * wq;
+                    const int img = q / quads, rem = q - img * quads, qy = rem / wq;
+                    const int yy = 2 * qy + (sub >> 1), xx = 2 * (rem - qy * wq) + (sub & 1);
+                    cyx[i] = (yy << 16) | xx;
+                    a_ptr[i] = A + ((int64_t)(img * p.conv_h + yy) * p.conv_w + xx) * p.lda + ld_c4;
+                } else {
+                    const int rem = ra % (p.conv_h * p.conv_w);
+                    const int yy = rem / p.conv_w;
+                    cyx[i] = (yy << 16) | (rem - yy * p.conv_w);
+                }
             }
             a2_ptr[i] = A2 ? A2 + (int64_t)ra * p.lda2 + ld_c4 : nullptr;
-            w_ptr[i] = W + (int64_t)rw * p.ldw + ld_c4;
         }
     };
 
-    f32x4 ra[NCH], rb[NCH];
+    f32x4 ra[NCH], rb[NCHB];
     auto gload = [&](int kt) {
         const int k = kt * BK;
         if (CONV) {
@@ -134,27 +152,26 @@ __global__ __launch_bounds__(256, (EXT || BK == 64) ? 2 : 3) void gemm_nt_kernel
             const int off = (dy * p.conv_w + dx) * p.conv_c + ci;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
-                const bool ok = (unsigned)(cy[i] + dy) < (unsigned)p.conv_h && (unsigned)(cx[i] + dx) < (unsigned)p.conv_w;
+                const bool ok = (unsigned)((cyx[i] >> 16) + dy) < (unsigned)p.conv_h && (unsigned)((cyx[i] & 0xFFFF) + dx) < (unsigned)p.conv_w;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (ok) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + off);
                 ra[i] = v;
-                rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + k);
             }
-            return;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const float* src = (k < p.K1) ? a_ptr[i] + k : a2_ptr[i] + (k - p.K1);
+                ra[i] = *reinterpret_cast<const f32x4*>(src);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const float* src = (k < p.K1) ? a_ptr[i] + k : a2_ptr[i] + (k - p.K1);
-            ra[i] = *reinterpret_cast<const f32x4*>(src);
-            rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + k);
-        }
+        for (int i = 0; i < NCHB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + k);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            *reinterpret_cast<f32x4*>(&As[(buf * BM + ld_row + RSTEP * i) * LDK + ld_c4]) = ra[i];
-            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + ld_row + RSTEP * i) * LDK + ld_c4]) = rb[i];
-        }
+        for (int i = 0; i < NCH; ++i) *reinterpret_cast<f32x4*>(&As[(buf * BM + ld_row + RSTEP * i) * LDK + ld_c4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NCHB; ++i) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + ld_row + RSTEP * i) * LDK + ld_c4]) = rb[i];
     };
 
     // acc[j][i]: weights tile j (MFMA A operand, rows -> registers) x activation tile i (B operand,
@@ -262,6 +279,15 @@ __global__ __launch_bounds__(256, (EXT || BK == 64) ? 2 : 3) void gemm_nt_kernel
                         }
                         if (R) v += *reinterpret_cast<const f32x4*>(R + (int64_t)m * p.ldr + n);
                         if (EXT && n < p.q_cols) v *= p.q_scale;
+                        if (CONV && p.conv_pool) {  // lanes 4q..4q+3 hold the 2x2 block of pooled pixel m/4
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[e] = fmaxf(v[e], __shfl_xor(v[e], 1));
+                                v[e] = fmaxf(v[e], __shfl_xor(v[e], 2));
+                            }
+                            if ((lane & 3) == 0) *reinterpret_cast<f32x4*>(C + (int64_t)(m >> 2) * p.ldc + n) = v;
+                            continue;
+                        }
                         if (!EXT || p.C) *reinterpret_cast<f32x4*>(C + (int64_t)m * p.ldc + n) = v;
                         if (EXT && p.C3) {  // bf16x3 planes for the split-operand attention (attention3.hip)
                             bf16x4 h0, h1, h2;
@@ -340,13 +366,18 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
     p.lda = a.lda; p.lda2 = a.lda2; p.ldw = a.ldw; p.ldr = a.ldr; p.ldc = a.ldc;
     p.sA = a.sA; p.sA2 = a.sA2; p.sW = a.sW; p.sR = a.sR; p.sC = a.sC;
     p.M = a.M; p.N = a.N; p.K = a.K; p.K1 = K1;
-    p.conv_h = a.conv_h; p.conv_w = a.conv_w; p.conv_c = a.conv_c;
+    p.conv_h = a.conv_h; p.conv_w = a.conv_w; p.conv_c = a.conv_c; p.conv_pool = a.conv_pool ? 1 : 0;
     const bool conv = a.conv_c > 0;
-    if (conv && (a.conv_c % 32 || a.K != 9 * a.conv_c || a.A2 || a.batch != 1 || a.conv_h <= 0 || a.conv_w <= 0 ||
+    if (conv && (a.conv_h > 32767 || a.conv_w > 32767 || a.conv_c % 32 || a.K != 9 * a.conv_c || a.A2 || a.batch != 1 || a.conv_h <= 0 || a.conv_w <= 0 ||
                  a.M % (a.conv_h * a.conv_w) || a.lda != a.conv_c || a.C3 || a.Vt || a.q_cols > 0))
         return set_err(ctx, E2EMV_ESHAPE, "gemm: conv mode needs NHWC input with C %% 32 == 0, K = 9 C, whole images, batch 1");
-    p.tiles_m = (a.M + BM - 1) / BM;
-    p.tiles_n = (a.N + BN - 1) / BN;
+    if (a.conv_pool && (!conv || a.conv_h % 2 || a.conv_w % 2 || a.N % 4 || a.R))
+        return set_err(ctx, E2EMV_ESHAPE, "gemm: fused 2x2 max-pool needs conv mode, even image sides and N %% 4 == 0");
+    // 64-channel-wide outputs: the 256 x 64 tile variant (conv mode only - the matcher never has N <= 64 at scale)
+    const bool narrow = a.conv_c > 0 && a.N <= 64;
+    const int bm = narrow ? 256 : BM, bn = narrow ? 64 : BN;
+    p.tiles_m = (a.M + bm - 1) / bm;
+    p.tiles_n = (a.N + bn - 1) / bn;
     p.total = p.tiles_m * p.tiles_n * a.batch;
     p.scale = a.scale;
     p.relu = a.relu ? 1 : 0;
@@ -367,10 +398,12 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
     // the variant reachable for profiling.
     int bk = 32;
     if (bk_env == 64 && a.K % 64 == 0 && K1 % 64 == 0 && !ext && !conv) bk = 64;
-    const int per_cu = wg > 0 ? wg : ((ext || bk == 64) ? 2 : 3);
+    const int per_cu = wg > 0 ? wg : ((ext || bk == 64 || narrow) ? 2 : 3);
     const int sl = std::min(per_xcd, std::max(1, ctx->num_cus * per_cu / 8));
-    const size_t lds = sizeof(float) * (BM + BN) * (bk + 4);
-    if (conv) {
+    const size_t lds = sizeof(float) * (bm + bn) * (bk + 4);
+    if (conv && narrow) {
+        hipLaunchKernelGGL((gemm_nt_kernel<false, 32, 0, true, 1>), dim3(8 * sl), dim3(256), lds, s, p);
+    } else if (conv) {
         hipLaunchKernelGGL((gemm_nt_kernel<false, 32, 0, true>), dim3(8 * sl), dim3(256), lds, s, p);
     } else if (bk == 64) {
         static bool attr_set = false;

@@ -10,7 +10,8 @@
 // matrix cores through the CONV mode of gemm_nt_kernel (gemm.hip): M = pixels, N = Cout, K = 9*Cin ordered (ky, kx, cin),
 // zero padding resolved in the operand fetch, bias + ReLU fused in the epilogue; the 1x1 heads are plain GEMMs.
 //   conv1a (Cin = 1)            direct kernel, 16 lanes x 4 channels per pixel (HBM-bound: 256 B written per pixel)
-//   2x2 max-pool                 one thread per (output pixel, 4 channels)
+//   2x2 max-pool                 fused into the epilogue of conv1b / conv2b / conv3b (quad-major row order, 2 lane
+//                                shuffles): the full-resolution conv_b outputs never reach memory
 //   detector head                convPa (conv GEMM) -> convPb (GEMM, N = 65) -> softmax over 65 + 8x8 depth-to-space
 //   simple_nms                   5 max-pools of radius r: tile kernel, row-max then column-max through LDS, -inf padding
 //   threshold / borders / top-k  one workgroup per image: ordered compaction, 4-pass radix select of the k-th score,
@@ -58,25 +59,6 @@ __global__ __launch_bounds__(256) void sp_conv1a_kernel(const float* __restrict_
         o[e] = fmaxf(acc + sw[576 + c0 + e], 0.f);
     }
     *reinterpret_cast<sp_f4*>(out + pix * 64 + c0) = o;
-}
-
-// ---- 2x2 / stride 2 max-pool, NHWC -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sp_pool_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int64_t total /* out pixels * C/4 */) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int c4 = C / 4;
-    const int q = (int)(i % c4);
-    const int64_t op = i / c4;
-    const int Ho = H / 2, Wo = W / 2;
-    const int64_t im = op / ((int64_t)Ho * Wo);
-    const int rem = (int)(op - im * Ho * Wo), y = rem / Wo, x = rem - y * Wo;
-    const float* src = in + ((im * H + 2 * y) * (int64_t)W + 2 * x) * C + 4 * q;
-    const sp_f4 a = *reinterpret_cast<const sp_f4*>(src), b = *reinterpret_cast<const sp_f4*>(src + C);
-    const sp_f4 c = *reinterpret_cast<const sp_f4*>(src + (int64_t)W * C), d = *reinterpret_cast<const sp_f4*>(src + (int64_t)W * C + C);
-    sp_f4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
-    *reinterpret_cast<sp_f4*>(out + op * C + 4 * q) = o;
 }
 
 // ---- softmax over the 65 detector channels, drop the dustbin, 8x8 depth-to-space --------------------------------------
@@ -401,7 +383,7 @@ extern "C" int e2emv_superpoint_commit(e2emv_ctx* ctx) {
 
 namespace {
 
-int sp_conv3x3(e2emv_ctx* ctx, int layer, const float* in, float* out, int imgs, int H, int W, hipStream_t s) {
+int sp_conv3x3(e2emv_ctx* ctx, int layer, const float* in, float* out, int imgs, int H, int W, hipStream_t s, bool pool = false) {
     GemmArgs g;
     g.M = imgs * H * W; g.N = kSpCout[layer]; g.K = 9 * kSpCin[layer];
     g.A = in; g.lda = kSpCin[layer];
@@ -410,6 +392,7 @@ int sp_conv3x3(e2emv_ctx* ctx, int layer, const float* in, float* out, int imgs,
     g.C = out; g.ldc = g.N;
     g.relu = true;
     g.conv_h = H; g.conv_w = W; g.conv_c = kSpCin[layer];
+    g.conv_pool = pool;
     prof_begin(ctx, PS_GEMM, s);
     const int rc = launch_gemm_nt(ctx, g, s);
     prof_end(ctx, s);
@@ -466,24 +449,14 @@ extern "C" int e2emv_superpoint_forward(e2emv_ctx* ctx, const e2emv_superpoint_d
     hipLaunchKernelGGL(sp_conv1a_kernel, dim3((unsigned)((npix + 15) / 16)), dim3(256), 0, s, d_images, ctx->sp_w[0], ctx->sp_b[0], A, H, W, npix);
     E2EMV_CHECK_LAUNCH(ctx, "sp_conv1a_kernel");
     prof_end(ctx, s);
-    auto pool = [&](const float* in, float* out, int h, int w, int c) -> int {
-        const int64_t total = (int64_t)B * (h / 2) * (w / 2) * (c / 4);
-        prof_begin(ctx, PS_MISC, s);
-        hipLaunchKernelGGL(sp_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, h, w, c, total);
-        E2EMV_CHECK_LAUNCH(ctx, "sp_pool_kernel");
-        prof_end(ctx, s);
-        return E2EMV_OK;
-    };
-    if ((rc = sp_conv3x3(ctx, 1, A, Bf, B, H, W, s))) return rc;
-    if ((rc = pool(Bf, A, H, W, 64))) return rc;
-    if ((rc = sp_conv3x3(ctx, 2, A, Bf, B, H / 2, W / 2, s))) return rc;
-    if ((rc = sp_conv3x3(ctx, 3, Bf, A, B, H / 2, W / 2, s))) return rc;
-    if ((rc = pool(A, Bf, H / 2, W / 2, 64))) return rc;
+    // conv_b of blocks 1-3 write their 2x2 max-pooled output directly (fused epilogue)
+    if ((rc = sp_conv3x3(ctx, 1, A, Bf, B, H, W, s, true))) return rc;
+    if ((rc = sp_conv3x3(ctx, 2, Bf, A, B, H / 2, W / 2, s))) return rc;
+    if ((rc = sp_conv3x3(ctx, 3, A, Bf, B, H / 2, W / 2, s, true))) return rc;
     if ((rc = sp_conv3x3(ctx, 4, Bf, A, B, H / 4, W / 4, s))) return rc;
-    if ((rc = sp_conv3x3(ctx, 5, A, Bf, B, H / 4, W / 4, s))) return rc;
-    if ((rc = pool(Bf, A, H / 4, W / 4, 128))) return rc;
-    if ((rc = sp_conv3x3(ctx, 6, A, Bf, B, Hc, Wc, s))) return rc;
-    if ((rc = sp_conv3x3(ctx, 7, Bf, X, B, Hc, Wc, s))) return rc;
+    if ((rc = sp_conv3x3(ctx, 5, A, Bf, B, H / 4, W / 4, s, true))) return rc;
+    if ((rc = sp_conv3x3(ctx, 6, Bf, A, B, Hc, Wc, s))) return rc;
+    if ((rc = sp_conv3x3(ctx, 7, A, X, B, Hc, Wc, s))) return rc;
     // ---- detector head ----
     if ((rc = sp_conv3x3(ctx, 8, X, P1, B, Hc, Wc, s))) return rc;
     if ((rc = sp_conv1x1(ctx, 9, P1, S65, cells, s))) return rc;
