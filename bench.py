@@ -69,12 +69,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", init_method="env://")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        # one process per GPU over RCCL ("nccl" on ROCm); binding the group to this rank's device up front keeps
+        # barrier()/collectives from guessing it
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
 
     import e2e_multi_view_matching_amd as E
     from e2e_multi_view_matching_amd import _lib
