@@ -72,7 +72,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("E2EMV_BENCH_FORCE_DIST"):  # the env knob exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
         # one process per GPU over RCCL ("nccl" on ROCm); binding the group to this rank's device up front keeps
         # barrier()/collectives from guessing it
