@@ -152,3 +152,27 @@ def test_images_with_different_keypoint_counts(gpu, precision):
             assert out[f"scores_{i}_{j}"].shape == (2, counts[i] + 1, counts[j] + 1)
             assert out[f"matches{i}_{i}_{j}"].shape == (2, counts[i]) and out[f"matches{j}_{i}_{j}"].shape == (2, counts[j])
         _compare(out, ref, pairs)
+
+
+def test_maximum_size_2048_keypoints_fp16_multi_frame(gpu):
+    """BASELINE configs[4] shape at the library's maximum keypoint count: T = 3 joint matching, 2048 keypoints per image,
+    fp16 descriptors, (self, cross, cross) schedule, both arithmetic modes - against the oracle fed the same fp16-rounded
+    descriptors; identity-like weights so the assignment is a real (non-degenerate) matching."""
+    from e2e_multi_view_matching_amd import MultiViewMatcher
+    from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
+    from oracle.matcher import matcher_forward
+    torch.manual_seed(3)
+    cfg = {"GNN_layers": ["self", "cross", "cross"], "sinkhorn_iterations": 20, "multi_frame_matching": True, "tuple_size": 3, "conf_mlp": True}
+    model = identity_like_state(MultiViewMatcher(cfg).eval())
+    _randomize_bn(model, 3)
+    data = make_tuples(batch=1, tuple_size=3, n_kpts=2048, seed=31, desc_dtype=torch.float16)
+    rounded = {k: (v.float() if torch.is_tensor(v) and v.dtype == torch.float16 else v) for k, v in data.items()}
+    ref = matcher_forward(rounded, model.state_dict(), {**model.config, "full_output": True})
+    model = model.to(gpu)
+    dev = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in data.items()}
+    for precision in PRECISIONS:
+        model.config["mfma_precision"] = precision
+        with torch.no_grad():
+            out = model(dev)
+        _compare(out, ref, [(0, 1), (0, 2), (1, 2)])
+        assert float((out["matches0_0_1"] >= 0).float().mean()) > 0.5
