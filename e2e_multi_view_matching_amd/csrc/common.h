@@ -183,6 +183,8 @@ struct Gemm3Args {
     bool relu = false;
 };
 int launch_gemm3(e2emv_ctx* ctx, const Gemm3Args& a, hipStream_t s);
+// gemm_x3.hip: fp32 activations (a.A / a.A2, a.bias, a.R, a.C, a.relu as for launch_gemm_nt) x pre-split weights W3 (S3 [N][3][ldw3])
+int launch_gemm_x3(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* W3, int64_t ldw3, hipStream_t s);
 int launch_split3(e2emv_ctx* ctx, const float* src, int64_t rows, int C, int64_t ld_src, uint16_t* dst, int64_t ld,
                   hipStream_t s);
 int launch_attention3(e2emv_ctx* ctx, int B, int T, int n_rows, const int* n_valid_img, int D, int H, const uint16_t* qk,

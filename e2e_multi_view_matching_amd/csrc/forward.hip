@@ -272,13 +272,18 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         g = GemmArgs();
         g.M = (int)Mtot; g.N = 2 * D; g.K = 2 * D; g.K1 = D; g.A = x; g.lda = D; g.A2 = second; g.lda2 = D;
         g.W = L.w_mlp0; g.ldw = 2 * D; g.bias = L.b_mlp0; g.relu = true; g.C = hid; g.ldc = 2 * D;
-        prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
+        // bf16x3 mode: the two MLP GEMMs (2/3 of the layer's GEMM flops) run on the bf16 pipe with split operands
+        prof_begin(ctx, PS_GEMM, s);
+        rc = b3 ? launch_gemm_x3(ctx, g, L.w3_mlp0, 2 * D, s) : launch_gemm_nt(ctx, g, s);
+        prof_end(ctx, s);
         if (rc) return rc;
         // x += W1 hidden + b1
         g = GemmArgs();
         g.M = (int)Mtot; g.N = D; g.K = 2 * D; g.K1 = 2 * D; g.A = hid; g.lda = 2 * D; g.W = L.w_mlp1; g.ldw = 2 * D;
         g.bias = L.b_mlp1; g.R = x; g.ldr = D; g.C = x; g.ldc = D;
-        prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
+        prof_begin(ctx, PS_GEMM, s);
+        rc = b3 ? launch_gemm_x3(ctx, g, L.w3_mlp1, 2 * D, s) : launch_gemm_nt(ctx, g, s);
+        prof_end(ctx, s);
         if (rc) return rc;
     }
 

@@ -198,6 +198,11 @@ __global__ __launch_bounds__(256, (EXT || BK == 64 || TN == 1) ? 2 : 3) void gem
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(as + 32 * LDK + c * 8);
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(bs + c * 8);
             const f32x4 w1 = *reinterpret_cast<const f32x4*>(bs + 32 * LDK + c * 8);
+            if (DBG & 2) {  // profiling: operand pipeline only (global -> LDS -> registers), no matrix-core work
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0][0][e] += x0[e] + x1[e] + w0[e] + w1[e];
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (SWAP) {
@@ -414,6 +419,8 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((gemm_nt_kernel<false, 64, 0>), dim3(8 * sl), dim3(256), lds, s, p);
     } else if (ext) {
         hipLaunchKernelGGL((gemm_nt_kernel<true, 32, 0>), dim3(8 * sl), dim3(256), lds, s, p);
+    } else if (dbg & 2) {
+        hipLaunchKernelGGL((gemm_nt_kernel<false, 32, 2>), dim3(8 * sl), dim3(256), lds, s, p);
     } else if (dbg & 1) {
         hipLaunchKernelGGL((gemm_nt_kernel<false, 32, 1>), dim3(8 * sl), dim3(256), lds, s, p);
     } else {

@@ -57,8 +57,16 @@ extern "C" int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const f
     if (rc) return rc;
     uint16_t* A3 = (uint16_t*)ctx->d_ws;
     uint16_t* W3 = (uint16_t*)(ctx->d_ws + szA);
-    if ((rc = launch_split3(ctx, d_A, M, K, K, A3, K, s))) return rc;
     if ((rc = launch_split3(ctx, d_W, Nout, K, K, W3, K, s))) return rc;
+    if (!(flags & 2)) {  // second-generation kernel: activations stay fp32, split on the way into LDS (gemm_x3.hip)
+        GemmArgs g;
+        g.M = M; g.N = Nout; g.K = K; g.K1 = K; g.A = d_A; g.lda = K; g.bias = d_bias; g.C = d_C; g.ldc = Nout; g.relu = (flags & 1) != 0;
+        prof_begin(ctx, PS_GEMM, s);
+        rc = launch_gemm_x3(ctx, g, W3, K, s);
+        prof_end(ctx, s);
+        return rc;
+    }
+    if ((rc = launch_split3(ctx, d_A, M, K, K, A3, K, s))) return rc;
     Gemm3Args g;
     g.M = M; g.N = Nout; g.K = K; g.K1 = K; g.A = A3; g.lda = K; g.W = W3; g.ldw = K; g.bias = d_bias;
     g.C32 = d_C; g.ldc32 = Nout; g.relu = (flags & 1) != 0;

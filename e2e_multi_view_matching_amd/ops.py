@@ -72,8 +72,9 @@ def attention(qkv, B, T, n_valid, H, cross):
     return out
 
 
-def gemm_bf16x3(A, W, bias=None, relu=False):
-    """bf16x3 split-operand GEMM building block on fp32 tensors: act(A W^T + bias)."""
+def gemm_bf16x3(A, W, bias=None, relu=False, all_planes=False):
+    """bf16x3 split-operand GEMM building block on fp32 tensors: act(A W^T + bias).  Default: gemm_x3.hip (activations
+    split on the way into LDS); ``all_planes=True``: the first-generation kernel that reads pre-split planes (gemm3.hip)."""
     ctx = _ctx(A)
     A_, W_ = A.contiguous().float(), W.contiguous().float()
     M, K = A_.shape
@@ -81,7 +82,7 @@ def gemm_bf16x3(A, W, bias=None, relu=False):
     C = torch.empty((M, N), dtype=torch.float32, device=A.device)
     b = bias.contiguous().float() if bias is not None else None
     with torch.cuda.device(A.device):
-        ctx.call("e2emv_gemm_bf16x3", M, N, K, _lib.ptr(A_), _lib.ptr(W_), _lib.ptr(b), _lib.ptr(C), 1 if relu else 0,
+        ctx.call("e2emv_gemm_bf16x3", M, N, K, _lib.ptr(A_), _lib.ptr(W_), _lib.ptr(b), _lib.ptr(C), (1 if relu else 0) | (2 if all_planes else 0),
                  _lib.stream_ptr(A.device))
     return C
 

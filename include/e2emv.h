@@ -264,7 +264,8 @@ int e2emv_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D
 #define E2EMV_PRECISION_BF16X3 1
 int e2emv_set_precision(e2emv_ctx* ctx, int precision);
 /* building blocks of the bf16x3 path on fp32 buffers (split / merge done internally; for tests):
- * C = act(A W^T + bias), A [M,K], W [N,K], C [M,N]; flags bit0 relu. */
+ * C = act(A W^T + bias), A [M,K], W [N,K], C [M,N]; flags bit0 relu, bit1 = first-generation kernel reading pre-split
+ * activation planes (gemm3.hip) instead of the default gemm_x3.hip (fp32 activations split on the way into LDS). */
 int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const float* d_A, const float* d_W, const float* d_bias,
                       float* d_C, int flags, void* stream);
 /* same contract as e2emv_attention. */

@@ -51,16 +51,17 @@ def main():
         for (M, N, K) in [(65536, 256, 256), (65536, 256, 512), (65536, 512, 512), (65536, 768, 256), (65536, 256, 2048)]:
             A = torch.randn(M, K, device=dev)
             W = torch.randn(N, K, device=dev)
-            for _ in range(2):
-                E.gemm_bf16x3(A, W)
-            ctx.call("e2emv_profile", 1)
-            _lib.profile_read(ctx, reset=True)
-            for _ in range(10):
-                E.gemm_bf16x3(A, W)
-            pr = _lib.profile_read(ctx, reset=True)["gemm"]
-            ctx.call("e2emv_profile", 0)
-            ms = pr["ms"] / pr["launches"]
-            print(f"  {M:7d} {N:5d} {K:5d}  {ms * 1e3:9.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF")
+            for v1 in ((False,) if os.environ.get('E2EMV_X3_DEBUG') else (False, True)):
+                for _ in range(2):
+                    E.gemm_bf16x3(A, W, all_planes=v1)
+                ctx.call("e2emv_profile", 1)
+                _lib.profile_read(ctx, reset=True)
+                for _ in range(10):
+                    E.gemm_bf16x3(A, W, all_planes=v1)
+                pr = _lib.profile_read(ctx, reset=True)["gemm"]
+                ctx.call("e2emv_profile", 0)
+                ms = pr["ms"] / pr["launches"]
+                print(f"  {M:7d} {N:5d} {K:5d}  {ms * 1e3:9.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF  ({'gemm3 all-planes' if v1 else 'gemm_x3'})")
     if "a3" in args.what:
         print("== attention_bf16x3 kernel alone (B pairs, N) -> us, TFLOP/s fp32-equivalent")
         from e2e_multi_view_matching_amd import _lib
