@@ -191,9 +191,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmX3Params p) {
     gload(0);
     for (;;) {
         for (int kt = 0; kt + 1 < nk; ++kt) {
-            __syncthreads();
-            lstore();
-            __syncthreads();
+            if (!(DBG & 4) || kt == 0) {  // (DBG & 4: profiling - LDS filled once, no barriers / LDS stores in the loop)
+                __syncthreads();
+                lstore();
+                __syncthreads();
+            }
             gload(kt + 1);
             compute();
         }
@@ -236,6 +238,7 @@ int launch_gemm_x3(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* W3, int64_
     if (dbg < 0) { const char* e = getenv("E2EMV_X3_DEBUG"); dbg = e ? atoi(e) : 0; }
     if (dbg == 1) hipLaunchKernelGGL(gemm_x3_kernel<1>, dim3(8 * sl), dim3(256), lds, s, p);
     else if (dbg == 2) hipLaunchKernelGGL(gemm_x3_kernel<2>, dim3(8 * sl), dim3(256), lds, s, p);
+    else if (dbg == 6) hipLaunchKernelGGL(gemm_x3_kernel<6>, dim3(8 * sl), dim3(256), lds, s, p);
     else hipLaunchKernelGGL(gemm_x3_kernel<0>, dim3(8 * sl), dim3(256), lds, s, p);
     E2EMV_CHECK_LAUNCH(ctx, "gemm_x3_kernel");
     return E2EMV_OK;
