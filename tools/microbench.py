@@ -89,11 +89,12 @@ def main():
                 print(f"  B={B:3d} N={N:5d} cross={cross}  {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.1f} TF")
     if "sinkhorn" in args.what:
         print("== sinkhorn 100 iters (B, N) -> ms, algorithmic GB/s")
-        for (B, N) in [(32, 1024), (8, 1024), (8, 2048), (64, 512)]:
+        for (B, N) in [(32, 1024), (16, 1024), (8, 1024), (4, 1024), (2, 1024), (8, 2048), (64, 512)]:
             s = torch.randn(B, N, N, device=dev)
             ms = timeit(lambda: E.log_optimal_transport(s, 1.0, 100), iters=5, warm=1)
             by = B * 202 * (N + 1) ** 2 * 4
-            print(f"  B={B:3d} N={N:5d}  {ms:8.3f} ms  {by / ms / 1e6:8.1f} GB/s")
+            print(f"  B={B:3d} N={N:5d}  {ms:8.3f} ms  {by / ms / 1e6:8.1f} GB/s   S = {B * N * N * 4 / 2**20:.0f} MiB, one pass per iteration: "
+                  f"{B * 100 * (N + 1) ** 2 * 4 / ms / 1e6:8.1f} GB/s")
 
 
 if __name__ == "__main__":
