@@ -13,8 +13,8 @@
 //   * a workgroup owns 16 full rows (4 waves x 4 rows, 64 floats per lane in registers):
 //     it computes u for its rows (row LSE = wave shuffles only) and, FROM THE SAME REGISTERS,
 //     the per-column partial (max, sum-exp) of S + u over its 16 rows (cross-wave through
-//     LDS).  `sinkhorn_combine` (one workgroup per pair) folds the M/16 partials into v and
-//     the two dustbin scalars.
+//     LDS).  `sinkhorn_combine` (64 columns x 4 chunk ranges per workgroup) folds the M/16 partials into
+//     v and the two dustbin scalars.
 // Row loads are 16 B per lane, 1 KiB contiguous per wave instruction.
 // The final sweep writes logZ = couplings + u + v + log(M+N) densely ([M+1][N+1], the API
 // layout) and fuses the row/column arg-max needed by the match block, so Z is never re-read.
