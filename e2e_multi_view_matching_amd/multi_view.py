@@ -52,115 +52,113 @@ def estimate_relative_pose_w8pt_ba(intr0, intr1, mkpts0, mkpts1, conf):
     return True, pred_T021[0, :3, :3].cpu().numpy(), pred_T021[0, :3, 3].cpu().numpy(), info["inliers"].squeeze(0).cpu().numpy()
 
 
+def _pairs(n_images):
+    """Image pairs in the reference's enumeration order (second index outer): (0,1), (0,2), (1,2), (0,3), ..."""
+    return [(i, j) for j in range(n_images) for i in range(j)]
+
+
+def _key(kind, *ids):
+    return kind + "_".join(str(i) for i in ids)
+
+
+def _csv(values):
+    return ",".join(str(v) for v in values) + "\n"  # str(x) is what "{}".format(x) writes in the reference
+
+
+def _colmajor(R):
+    return [R[r, c] for c in range(3) for r in range(3)]
+
+
 def normalize_confidences(obs_xyc):
-    """bundle_adjust_io.py:56-60."""
-    conf = obs_xyc[:, 2:]
-    sum_conf = conf.sum(axis=0, keepdims=True) + 1e-3
-    obs_xyc[:, 2:] = conf / (0.5 * sum_conf)  # 0.5 because each match leads to 2 observations
+    """bundle_adjust_io.py:56-60: weights rescaled so that they sum to 2 over all observations (each match is seen twice)."""
+    total = obs_xyc[:, 2:].sum(axis=0, keepdims=True) + 1e-3
+    obs_xyc[:, 2:] = obs_xyc[:, 2:] / (0.5 * total)
     return obs_xyc
 
 
+def _collect_matches(n_images, data, result, conf_thresh):
+    """First stage of bundle_adjust_io.py:62-96: matched keypoints / confidences / intrinsics of batch element 0."""
+    pw = {}
+    for i, j in _pairs(n_images):
+        mkey = _key("matches", str(i), i, j)
+        if mkey not in result:
+            continue
+        if "keypoints" + str(i) in data:
+            k0, k1 = data["keypoints" + str(i)], data["keypoints" + str(j)]
+        else:
+            k0, k1 = data[_key("keypoints", str(i), i, j)], data[_key("keypoints", str(j), i, j)]
+        k0, k1 = k0[0].cpu().numpy(), k1[0].cpu().numpy()
+        m = result[mkey][0].cpu().numpy()
+        c = result[_key("conf_scores_", i, j)][0].cpu().numpy()
+        keep = (m >= 0) & np.all(c > conf_thresh, -1)
+        pw[_key("mkpts", str(i), i, j)] = k0[keep]
+        pw[_key("mkpts", str(j), i, j)] = k1[m[keep]]
+        pw[_key("conf", str(i), i, j)] = pw[_key("conf", str(j), i, j)] = c[keep]
+        pw["intr" + str(i)] = data["intr" + str(i)][0].cpu().numpy()
+        pw["intr" + str(j)] = data["intr" + str(j)][0].cpu().numpy()
+    return pw
+
+
+def _chain_along_tree(n_images, edges, rel_pose):
+    """Absolute camera-to-world poses by walking the spanning tree outwards from image 0 (bundle_adjust_io.py:141-161):
+    across edge (a, b), a < b:  pose_b = pose_a @ inv(T_a->b)  and  pose_a = pose_b @ T_a->b."""
+    pose = {0: np.eye(4)}
+    frontier = [0]
+    while frontier:
+        cur = frontier.pop()
+        for a, b in edges:
+            if cur == a and b not in pose:
+                pose[b] = pose[a] @ np.linalg.inv(rel_pose[(a, b)])
+                frontier.append(b)
+            elif cur == b and a not in pose:
+                pose[a] = pose[b] @ rel_pose[(a, b)]
+                frontier.append(a)
+    return pose
+
+
 def initialize_bundle_adjust(n_images, data, result, file_path, conf_thresh=0., rel_pose_method="w8pt_ba"):
-    """``initialize_bundle_adjust`` (bundle_adjust_io.py:62-191): collects the matches of batch element 0, estimates all
-    pairwise poses, chains them along the maximum spanning tree of the inlier-count graph and writes ``ba_init_in.csv``."""
+    """``initialize_bundle_adjust`` (bundle_adjust_io.py:62-191): matches of batch element 0 -> pairwise poses (w8pt + two-view
+    BA on the device) -> maximum spanning tree of the inlier-count graph -> chained absolute poses -> ``ba_init_in.csv``.
+    Returns the reference's ``pair_wise_data`` dictionary (same keys)."""
     if rel_pose_method != "w8pt_ba":
         # the "ransac" / "ransac_ba" variants call OpenCV's findEssentialMat (absent submodule + absent cv2): out of scope
         raise NotImplementedError("relative pose method {} needs OpenCV RANSAC, which is outside this back-end".format(rel_pose_method))
     min_inliers = 20
-    pair_wise_data = dict()
-    match_graph = np.zeros((n_images, n_images), dtype=int)
-    for id1 in range(n_images):
-        for id0 in range(id1):
-            matches_key = "matches{}_{}_{}".format(id0, id0, id1)
-            if matches_key not in result:
-                continue
-            if "keypoints" + str(id0) in data:
-                kpts0, kpts1 = data["keypoints" + str(id0)][0].cpu().numpy(), data["keypoints" + str(id1)][0].cpu().numpy()
-            else:
-                kpts0 = data["keypoints{}_{}_{}".format(id0, id0, id1)][0].cpu().numpy()
-                kpts1 = data["keypoints{}_{}_{}".format(id1, id0, id1)][0].cpu().numpy()
-            matches = result[matches_key][0].cpu().numpy()
-            intr0, intr1 = data["intr" + str(id0)][0].cpu().numpy(), data["intr" + str(id1)][0].cpu().numpy()
-            confidence = result["conf_scores_{}_{}".format(id0, id1)][0].cpu().numpy()
-            valid = (matches >= 0) & np.all(confidence > conf_thresh, -1)
-            pair_wise_data["mkpts{}_{}_{}".format(id0, id0, id1)] = kpts0[valid]
-            pair_wise_data["mkpts{}_{}_{}".format(id1, id0, id1)] = kpts1[matches[valid]]
-            confidence = confidence[valid]
-            pair_wise_data["conf{}_{}_{}".format(id0, id0, id1)] = confidence
-            pair_wise_data["conf{}_{}_{}".format(id1, id0, id1)] = confidence
-            pair_wise_data["intr{}".format(id0)] = intr0
-            pair_wise_data["intr{}".format(id1)] = intr1
+    pw = _collect_matches(n_images, data, result, conf_thresh)
+    graph = np.zeros((n_images, n_images), dtype=int)
+    rel = {}
+    for i, j in _pairs(n_images):
+        k0, k1 = _key("mkpts", str(i), i, j), _key("mkpts", str(j), i, j)
+        if k0 not in pw:
+            continue
+        ok, R, t, inl = estimate_relative_pose_w8pt_ba(pw["intr" + str(i)], pw["intr" + str(j)], pw[k0], pw[k1], pw[_key("conf", str(i), i, j)])
+        # every match is kept for the bundle adjustment; the inlier count only weights the match graph (:111-113, :133)
+        pw[_key("inlier_count", i, j)] = inl.sum() if ok else 0
+        if ok:
+            T = np.eye(4)
+            T[:3, :3], T[:3, 3] = R, t
+            pw[_key("rel_pose", i, j)] = rel[(i, j)] = T
+            graph[i, j] = len(pw[k0])
 
-    for id1 in range(n_images):
-        for id0 in range(id1):
-            k0, k1 = "mkpts{}_{}_{}".format(id0, id0, id1), "mkpts{}_{}_{}".format(id1, id0, id1)
-            c0, c1 = "conf{}_{}_{}".format(id0, id0, id1), "conf{}_{}_{}".format(id1, id0, id1)
-            if k0 not in pair_wise_data:
-                continue
-            mkpts0, mkpts1 = pair_wise_data[k0], pair_wise_data[k1]
-            success, R, t, inliers = estimate_relative_pose_w8pt_ba(pair_wise_data["intr{}".format(id0)], pair_wise_data["intr{}".format(id1)],
-                                                                    mkpts0, mkpts1, pair_wise_data[c0])
-            if success:
-                inlier_count = inliers.sum()
-                inliers = np.full_like(inliers, True)  # every match is kept; the count only weights the graph (:111-113)
-            else:
-                inlier_count = 0
-            pair_wise_data["inlier_count{}_{}".format(id0, id1)] = inlier_count
-            if success:
-                pair_wise_data[k0], pair_wise_data[k1] = mkpts0[inliers], mkpts1[inliers]
-                pair_wise_data[c0], pair_wise_data[c1] = pair_wise_data[c0][inliers], pair_wise_data[c1][inliers]
-                rel_pose = np.eye(4)
-                rel_pose[:3, :3] = R
-                rel_pose[:3, 3] = t
-                pair_wise_data["rel_pose{}_{}".format(id0, id1)] = rel_pose
-                match_graph[id0, id1] = inliers.sum()
+    # maximum spanning tree = minimum spanning tree of (max - w + 1) on the existing edges (:135-138)
+    has_edge = graph != 0
+    graph[has_edge] = np.amax(graph) - graph[has_edge] + 1
+    tree = minimum_spanning_tree(graph).toarray().astype(int)
+    tree_edges = [(min(r, c), max(r, c)) for r, c in zip(*np.nonzero(tree))]
+    pw["abs_init_pose0"] = np.eye(4)
+    for node, P in _chain_along_tree(n_images, tree_edges, rel).items():
+        pw["abs_init_pose" + str(node)] = P
+    world_to_cam = [np.linalg.inv(pw["abs_init_pose" + str(v)]) if "abs_init_pose" + str(v) in pw else np.eye(4) for v in range(n_images)]
 
-    # absolute poses along the maximum spanning tree (inlier counts as edge weights), bundle_adjust_io.py:134-170
-    max_inliers = np.amax(match_graph)
-    non_zero_mask = match_graph != 0
-    match_graph[non_zero_mask] = max_inliers - match_graph[non_zero_mask] + 1
-    min_spanning_tree = minimum_spanning_tree(match_graph).toarray().astype(int)
-    pair_wise_data["abs_init_pose0"] = np.eye(4)
-    n_abs_poses = 1
-    row, col = np.nonzero(min_spanning_tree)
-    pairs_on_spanning_tree = []
-    for _ in range(n_images):
-        for r, c in zip(row, col):
-            id0, id1 = (r, c) if r < c else (c, r)
-            pairs_on_spanning_tree.append((id0, id1))
-            a0, a1 = "abs_init_pose{}".format(id0), "abs_init_pose{}".format(id1)
-            if a1 not in pair_wise_data and a0 in pair_wise_data:
-                pair_wise_data[a1] = pair_wise_data[a0] @ np.linalg.inv(pair_wise_data["rel_pose{}_{}".format(id0, id1)])
-                n_abs_poses += 1
-            elif a0 not in pair_wise_data and a1 in pair_wise_data:
-                pair_wise_data[a0] = pair_wise_data[a1] @ pair_wise_data["rel_pose{}_{}".format(id0, id1)]
-                n_abs_poses += 1
-        if n_abs_poses == n_images:
-            break
-    extr = [np.eye(4)]
-    for id in range(1, n_images):
-        key = "abs_init_pose{}".format(id)
-        extr.append(np.linalg.inv(pair_wise_data[key]) if key in pair_wise_data else np.eye(4))
-    extr = np.array(extr)
-
-    with open(file_path, 'w') as f:  # wire format read by ba_init.cpp:13-51
-        for id in range(n_images):
-            R = extr[id, :3, :3]
-            f.write("{},{},{},{},{},{},{},{},{},{}\n".format(id, R[0, 0], R[1, 0], R[2, 0], R[0, 1], R[1, 1], R[2, 1], R[0, 2], R[1, 2],
-                                                             R[2, 2]))
-        for id1 in range(n_images):
-            for id0 in range(id1):
-                rel_pose_key = "rel_pose{}_{}".format(id0, id1)
-                if rel_pose_key in pair_wise_data:
-                    n_inliers = pair_wise_data["inlier_count{}_{}".format(id0, id1)]
-                    if n_inliers >= min_inliers or (id0, id1) in pairs_on_spanning_tree:
-                        T_021 = pair_wise_data[rel_pose_key]
-                        R_021 = T_021[:3, :3]
-                        t_021 = -R_021.transpose() @ T_021[:3, 3]
-                        f.write("{},{},{},{},{},{},{},{},{},{},{},{},{},{}\n".format(
-                            id0, id1, R_021[0, 0], R_021[1, 0], R_021[2, 0], R_021[0, 1], R_021[1, 1], R_021[2, 1], R_021[0, 2],
-                            R_021[1, 2], R_021[2, 2], t_021[0], t_021[1], t_021[2]))
-    return pair_wise_data
+    lines = [_csv([v] + _colmajor(world_to_cam[v][:3, :3])) for v in range(n_images)]  # 10 fields, ba_init.cpp:18-30
+    for i, j in _pairs(n_images):
+        if (i, j) in rel and (pw[_key("inlier_count", i, j)] >= min_inliers or (i, j) in tree_edges):
+            R = rel[(i, j)][:3, :3]
+            position = -R.transpose() @ rel[(i, j)][:3, 3]  # camera j in the frame of camera i
+            lines.append(_csv([i, j] + _colmajor(R) + list(position)))  # 14 fields, ba_init.cpp:31-50
+    with open(file_path, "w") as f:
+        f.writelines(lines)
+    return pw
 
 
 def triangulate_points(P0, P1, x0, x1):
@@ -179,68 +177,46 @@ def write_bundle_adjust_problem(n_images, pair_wise_data, extrinsics, file_path)
     observations each, confidences normalised to sum 2, intrinsics folded into the observations (header says f=1, c=0)."""
     if extrinsics.ndim != 3:
         extrinsics = np.array([np.eye(4) for _ in range(n_images)])
-    min_inliers = 0
-    n_3d_pts = 0
-    observations_img_id, observations_pt_id, observations_xyc, points_in_3d = [], [], [], []
-    for id1 in range(n_images):
-        for id0 in range(id1):
-            mkpts0_key = "mkpts{}_{}_{}".format(id0, id0, id1)
-            if mkpts0_key in pair_wise_data:
-                n_inliers = pair_wise_data["inlier_count{}_{}".format(id0, id1)]
-                if n_inliers >= min_inliers:
-                    mkpts0 = pair_wise_data[mkpts0_key]
-                    mkpts1 = pair_wise_data["mkpts{}_{}_{}".format(id1, id0, id1)]
-                    conf0 = pair_wise_data["conf{}_{}_{}".format(id0, id0, id1)]
-                    conf1 = pair_wise_data["conf{}_{}_{}".format(id1, id0, id1)]
-                    intr0 = pair_wise_data["intr{}".format(id0)]
-                    intr1 = pair_wise_data["intr{}".format(id1)]
-                    mkpts0 = (mkpts0 - intr0[[0, 1], [2, 2]][None]) / intr0[[0, 1], [0, 1]][None]
-                    mkpts1 = (mkpts1 - intr1[[0, 1], [2, 2]][None]) / intr1[[0, 1], [0, 1]][None]
-                    if mkpts0.shape[0] != 0:
-                        pts_3d = triangulate_points(extrinsics[id0, :3, :], extrinsics[id1, :3, :], mkpts0, mkpts1)
-                    else:
-                        pts_3d = np.zeros((0, 3))
-                    for id, mkpts, conf in zip((id0, id1), (mkpts0, mkpts1), (conf0, conf1)):
-                        observations_img_id.append(np.full(mkpts.shape[0], id, dtype=int))
-                        observations_pt_id.append(np.arange(n_3d_pts, n_3d_pts + pts_3d.shape[0], dtype=int))
-                        observations_xyc.append(np.concatenate((mkpts, conf), -1))
-                    n_3d_pts += pts_3d.shape[0]
-                    points_in_3d.append(pts_3d)
-    observations_img_id = np.concatenate(observations_img_id, 0)
-    observations_pt_id = np.concatenate(observations_pt_id, 0)
-    observations_xyc = normalize_confidences(np.concatenate(observations_xyc, 0))
-    points_in_3d = np.concatenate(points_in_3d, 0)
-    with open(file_path, 'w') as f:  # wire format read by ba_problem.cpp:15-87
-        ref_cam = 0
-        f.write("{},{},{},{},{},{},{},{}\n".format(n_images, ref_cam, n_3d_pts, 2 * n_3d_pts, 1., 1., 0., 0.))
-        for id, pt_id, kpt in zip(observations_img_id, observations_pt_id, observations_xyc):
-            if kpt.shape[0] == 3:
-                f.write("{},{},{},{},{}\n".format(id, pt_id, kpt[0], kpt[1], kpt[2]))
-            elif kpt.shape[0] == 4:
-                f.write("{},{},{},{},{},{}\n".format(id, pt_id, kpt[0], kpt[1], kpt[2], kpt[3]))
-            else:
-                logging.error("Unexpected number of confidence values")
-        for id in range(n_images):
-            R, t = extrinsics[id, :3, :3], extrinsics[id, :3, 3]
-            f.write("{},{},{},{},{},{},{},{},{},{},{},{}\n".format(R[0, 0], R[1, 0], R[2, 0], R[0, 1], R[1, 1], R[2, 1], R[0, 2], R[1, 2],
-                                                                   R[2, 2], t[0], t[1], t[2]))
-        for pt_3d in points_in_3d:
-            f.write("{},{},{}\n".format(pt_3d[0], pt_3d[1], pt_3d[2]))
+    pw = pair_wise_data
+    cam_ids, pt_ids, obs, points = [], [], [], []
+    n_pts = 0
+    for i, j in _pairs(n_images):
+        k0 = _key("mkpts", str(i), i, j)
+        if k0 not in pw or pw[_key("inlier_count", i, j)] < 0:
+            continue
+        xy = []
+        for v in (i, j):  # pixel -> normalised camera coordinates (in the keypoints' dtype, like the reference)
+            K = pw["intr" + str(v)]
+            xy.append((pw[_key("mkpts", str(v), i, j)] - K[[0, 1], [2, 2]][None]) / K[[0, 1], [0, 1]][None])
+        m = xy[0].shape[0]
+        X = triangulate_points(extrinsics[i, :3, :], extrinsics[j, :3, :], xy[0], xy[1]) if m else np.zeros((0, 3))
+        for v, x in zip((i, j), xy):
+            cam_ids.append(np.full(m, v, dtype=int))
+            pt_ids.append(np.arange(n_pts, n_pts + m, dtype=int))
+            obs.append(np.concatenate((x, pw[_key("conf", str(v), i, j)]), -1))
+        n_pts += m
+        points.append(X)
+    cam_ids, pt_ids = np.concatenate(cam_ids, 0), np.concatenate(pt_ids, 0)
+    obs = normalize_confidences(np.concatenate(obs, 0))
+    if obs.shape[1] not in (3, 4):
+        logging.error("Unexpected number of confidence values")
+    lines = [_csv([n_images, 0, n_pts, 2 * n_pts, 1., 1., 0., 0.])]  # header: cameras, fixed camera, points, observations, f, c
+    lines += [_csv([c, q] + list(o)) for c, q, o in zip(cam_ids, pt_ids, obs)]  # 5 / 6 fields, ba_problem.cpp:42-69
+    lines += [_csv(_colmajor(extrinsics[v][:3, :3]) + list(extrinsics[v][:3, 3])) for v in range(n_images)]  # 12 fields
+    lines += [_csv(X) for X in np.concatenate(points, 0)]  # 3 fields
+    with open(file_path, "w") as f:
+        f.writelines(lines)
 
 
 def read_bundle_adjust_result(file_path):
-    """``read_bundle_adjust_result`` (bundle_adjust_io.py:261-273): rows of column-major R + t -> list of 4x4."""
-    extrinsics = []
-    with open(file_path, "r") as f:
-        for line in f:
-            w = line.split(',')
-            R = np.array([[float(w[0]), float(w[3]), float(w[6])], [float(w[1]), float(w[4]), float(w[7])],
-                          [float(w[2]), float(w[5]), float(w[8])]])
-            T = np.eye(4)
-            T[:3, :3] = R
-            T[:3, 3] = [float(w[9]), float(w[10]), float(w[11])]
-            extrinsics.append(T)
-    return extrinsics
+    """``read_bundle_adjust_result`` (bundle_adjust_io.py:261-273): rows of column-major R + t -> list of 4x4 world-to-camera."""
+    out = []
+    for row in np.loadtxt(file_path, delimiter=",", ndmin=2):
+        T = np.eye(4)
+        T[:3, :3] = row[:9].reshape(3, 3).T
+        T[:3, 3] = row[9:12]
+        out.append(T)
+    return out
 
 
 def run_ba_initializer(directory):
