@@ -30,6 +30,55 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float seed) 
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// One k-step of the split-operand GEMM inner loop: READS ds_read_b128 fragments (conflict-free 80-byte row stride) feeding
+// 24 bf16 MFMAs on 4 accumulator tiles; READS = 12 is gemm_x3.hip today (both operands from LDS), 6 = one operand from
+// registers / straight from L2.
+template <int READS>
+__global__ __launch_bounds__(256, 2) void probe_lds(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    for (int i = threadIdx.x; i < 6 * 128 * 40; i += 256) lds[i] = (unsigned short)(0x3f80 + (i & 7));
+    __syncthreads();
+    f32x16 acc[4];
+    for (int a = 0; a < 4; ++a)
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned short* base = lds + ((wave >> 1) * 64 + (lane & 31)) * 40 + (lane >> 5) * 8;
+    bf16x8 f[12];
+    for (int q = 0; q < 12; ++q) f[q] = *reinterpret_cast<const bf16x8*>(base + (q % 6) * 128 * 40 + (q / 6) * 32 * 40);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < READS; ++q)
+            f[q] = *reinterpret_cast<const bf16x8*>(base + (q % 6) * 128 * 40 + (q / 6) * 32 * 40 + (it & 1) * 16);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[(q + a) % 6], f[6 + (q + 2 * a) % 6], acc[a], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int a = 0; a < 4; ++a)
+        for (int r = 0; r < 16; ++r) s += acc[a][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int READS>
+void run_lds(float* d) {
+    const int iters = 20000, cus = 256, wg_per_cu = 2;
+    const size_t lds = 6 * 128 * 40 * 2;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    probe_lds<READS><<<cus * wg_per_cu, 256, lds>>>(d, 100);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    probe_lds<READS><<<cus * wg_per_cu, 256, lds>>>(d, iters);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    const double flop = 32768.0 * 24 * iters * 4.0 * cus * wg_per_cu;
+    printf("bf16 k-step, %2d ds_read_b128 per 24 MFMAs, 2 waves/SIMD : %8.1f TFLOP/s = %.1f fp32-equivalent (6 products)\n", READS,
+           flop / ms / 1e9, flop / ms / 1e9 / 6);
+}
+
 template <int NACC, bool BF16>
 void run(int wg_per_cu, float* d) {
     const int iters = 20000, cus = 256;
@@ -53,5 +102,6 @@ int main() {
     hipMalloc(&d, sizeof(float) * 256 * 256 * 8);
     for (int w = 1; w <= 4; w *= 2) { run<1, false>(w, d); run<4, false>(w, d); }
     for (int w = 1; w <= 4; w *= 2) { run<1, true>(w, d); run<2, true>(w, d); run<4, true>(w, d); }
+    run_lds<0>(d); run_lds<6>(d); run_lds<12>(d);
     return 0;
 }

@@ -48,7 +48,7 @@ def main():
         print("== gemm_bf16x3 kernel alone (HIP events inside the library) (M, N, K) -> us, TFLOP/s fp32-equivalent")
         from e2e_multi_view_matching_amd import _lib
         ctx = _lib.context(dev)
-        for (M, N, K) in [(65536, 256, 256), (65536, 256, 512), (65536, 512, 512), (65536, 768, 256), (65536, 256, 2048)]:
+        for (M, N, K) in [(65536, 256, 256), (65536, 256, 512), (65536, 512, 512), (65536, 768, 256), (65536, 256, 2048), (32768, 256, 8192)]:
             A = torch.randn(M, K, device=dev)
             W = torch.randn(N, K, device=dev)
             for v1 in ((False,) if os.environ.get('E2EMV_X3_DEBUG') else (False, True)):
