@@ -110,3 +110,22 @@ def test_errors(gpu):
         SuperPoint({"max_keypoints": 100000})
     out = sp({"image": [torch.zeros(1, 1, 96, 96, device=gpu)]})  # constant image: still well defined
     assert out["keypoints"][0].shape[1] == 2
+
+
+def test_fill_with_random_keypoints_pads_to_a_fixed_count(gpu):
+    """Fork option used for training batches (train.py:335-341): every image returns exactly max_keypoints entries so that
+    helpers.run_super_point can torch.stack them; the detected keypoints come first and are unchanged, the padding lies
+    inside the border band with score 0, the call is deterministic."""
+    img = _image(2, 96, 128, 9).to(gpu)
+    base = _model(gpu, max_keypoints=400, remove_borders=8, keypoint_threshold=0.02)({"image": [img]})
+    sp = _model(gpu, max_keypoints=400, remove_borders=8, keypoint_threshold=0.02, fill_with_random_keypoints=True, seed=5)
+    a, b = sp({"image": [img]}), sp({"image": [img]})
+    for i in range(2):
+        n = len(base["keypoints"][i])
+        assert 0 < n < 400 and a["keypoints"][i].shape == (400, 2) and a["descriptors"][i].shape == (256, 400)
+        assert torch.equal(a["keypoints"][i][:n], base["keypoints"][i]) and torch.equal(a["scores"][i][:n], base["scores"][i])
+        pad = a["keypoints"][i][n:]
+        assert float(a["scores"][i][n:].abs().max()) == 0.0
+        assert pad[:, 0].min() >= 8 and pad[:, 0].max() < 128 - 8 and pad[:, 1].min() >= 8 and pad[:, 1].max() < 96 - 8
+        assert torch.equal(a["keypoints"][i], b["keypoints"][i])
+        assert (a["descriptors"][i].norm(dim=0) - 1).abs().max() < 1e-4  # padded positions get sampled descriptors too
