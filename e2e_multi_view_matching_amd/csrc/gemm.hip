@@ -79,8 +79,12 @@ struct GemmParams {
 // TN = 2: 128 x 128 output tile, waves 2 x 2 (the default).  TN = 1: 256 x 64 tile, waves 4 x 1 - for outputs only 64
 // channels wide (SuperPoint's conv1b / conv2a / conv2b), where half of a 128-wide tile would multiply padding.
 template <bool EXT, int BK, int DBG = 0, bool CONV = false, int TN = 2>
+// TN = 0: 64 x 64 tile, waves 2 x 2 of ONE 32 x 32 MFMA tile each - the latency shape for small problems (batch 1-4 of the
+// reference's eval loop): a tile's K loop is 4x shorter and a 2048-row GEMM fills 256 workgroups instead of 64.
 __global__ __launch_bounds__(256, (EXT || BK == 64 || TN == 1) ? 2 : 3) void gemm_nt_kernel(GemmParams p) {
-    constexpr int BM = TN == 2 ? 128 : 256, BN = TN == 2 ? 128 : 64;  // shadow the namespace-scope defaults
+    constexpr int BM = TN == 2 ? 128 : (TN == 1 ? 256 : 64), BN = TN == 2 ? 128 : 64;  // shadow the namespace-scope defaults
+    constexpr int WT = TN == 0 ? 1 : 2;   // 32 x 32 MFMA tiles per wave and dimension
+    constexpr int WS = 32 * WT;           // rows / columns of the output tile one wave owns
     constexpr int LDK = BK + 4;           // 36: 36*i mod 64, 68: 4*i mod 64 - both give 16 distinct 16-byte slots
     constexpr int CPR = BK / 4;           // 16-byte chunks per tile row
     constexpr int NCH = BM * CPR / 256;   // chunks per thread of the activation tile (4 or 8)
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256, (EXT || BK == 64 || TN == 1) ? 2 : 3) void gem
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wr = TN == 2 ? wave >> 1 : wave, wc = TN == 2 ? (wave & 1) : 0;
+    const int wr = TN == 1 ? wave : wave >> 1, wc = TN == 1 ? 0 : (wave & 1);
     const int l31 = lane & 31, lh = lane >> 5;
     const int ld_row = tid / CPR;           // (+RSTEP*i)
     const int ld_c4 = (tid % CPR) * 4;      // float offset inside the K tile
@@ -176,12 +180,12 @@ __global__ __launch_bounds__(256, (EXT || BK == 64 || TN == 1) ? 2 : 3) void gem
 
     // acc[j][i]: weights tile j (MFMA A operand, rows -> registers) x activation tile i (B operand,
     // rows -> lanes).  C/D layout: lane = activation row m, registers = 4-runs of output channels n.
-    f32x16 acc[2][2];
+    f32x16 acc[WT][WT];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WT; ++j)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < WT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
     };
@@ -189,14 +193,20 @@ __global__ __launch_bounds__(256, (EXT || BK == 64 || TN == 1) ? 2 : 3) void gem
     // SWAP = true : roles exchanged (lane = output channel, registers = runs of 4 rows) for V^T tiles
     auto compute = [&](auto swap_tag) {
         constexpr bool SWAP = decltype(swap_tag)::value;
-        const float* as = &As[(wr * 64 + l31) * LDK + lh * 4];
-        const float* bs = &Bs[(wc * 64 + l31) * LDK + lh * 4];
+        const float* as = &As[(wr * WS + l31) * LDK + lh * 4];
+        const float* bs = &Bs[(wc * WS + l31) * LDK + lh * 4];
         if (DBG & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(as + c * 8);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(as + 32 * LDK + c * 8);
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(bs + c * 8);
+            if constexpr (WT == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[0][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], w0[e], acc[0][0], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], x0[e], acc[0][0], 0, 0, 0);
+            } else {
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(as + 32 * LDK + c * 8);
             const f32x4 w1 = *reinterpret_cast<const f32x4*>(bs + 32 * LDK + c * 8);
             if (DBG & 2) {  // profiling: operand pipeline only (global -> LDS -> registers), no matrix-core work
 #pragma unroll
@@ -207,15 +217,16 @@ __global__ __launch_bounds__(256, (EXT || BK == 64 || TN == 1) ? 2 : 3) void gem
             for (int e = 0; e < 4; ++e) {
                 if (SWAP) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], w0[e], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], w0[e], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], w1[e], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], w1[e], acc[1][1], 0, 0, 0);
+                    acc[0][WT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], w0[e], acc[0][WT - 1], 0, 0, 0);
+                    acc[WT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], w1[e], acc[WT - 1][0], 0, 0, 0);
+                    acc[WT - 1][WT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], w1[e], acc[WT - 1][WT - 1], 0, 0, 0);
                 } else {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], x0[e], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], x1[e], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], x0[e], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], x1[e], acc[1][1], 0, 0, 0);
+                    acc[0][WT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], x1[e], acc[0][WT - 1], 0, 0, 0);
+                    acc[WT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], x0[e], acc[WT - 1][0], 0, 0, 0);
+                    acc[WT - 1][WT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], x1[e], acc[WT - 1][WT - 1], 0, 0, 0);
                 }
+            }
             }
         }
         if (DBG & 1) __builtin_amdgcn_s_setprio(0);
@@ -235,15 +246,15 @@ __global__ __launch_bounds__(256, (EXT || BK == 64 || TN == 1) ? 2 : 3) void gem
         const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
         const int nv = p.N - p.vt_n0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = tn * BN + wc * 64 + j * 32 + l31;
+        for (int j = 0; j < WT; ++j) {
+            const int n = tn * BN + wc * WS + j * 32 + l31;
             if (n >= p.N) continue;
             const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < WT; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int m = tm * BM + wr * 64 + i * 32 + 8 * g + 4 * lh;
+                    const int m = tm * BM + wr * WS + i * 32 + 8 * g + 4 * lh;
                     if (m >= p.M) continue;
                     const int img = m / p.n_rows, ml = m - img * p.n_rows;
                     f32x4 v;
@@ -264,14 +275,14 @@ __global__ __launch_bounds__(256, (EXT || BK == 64 || TN == 1) ? 2 : 3) void gem
         float* C = p.C ? p.C + z * p.sC : nullptr;
         const float* R = p.R ? p.R + z * p.sR : nullptr;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = tm * BM + wr * 64 + i * 32 + l31;
+        for (int i = 0; i < WT; ++i) {
+            const int m = tm * BM + wr * WS + i * 32 + l31;
             if (m >= p.M) continue;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < WT; ++j) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = tn * BN + wc * 64 + j * 32 + 8 * g + 4 * lh;
+                    const int n = tn * BN + wc * WS + j * 32 + 8 * g + 4 * lh;
                     if (n >= p.N) continue;
                     f32x4 v;
 #pragma unroll
@@ -380,7 +391,14 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
         return set_err(ctx, E2EMV_ESHAPE, "gemm: fused 2x2 max-pool needs conv mode, even image sides and N %% 4 == 0");
     // 64-channel-wide outputs: the 256 x 64 tile variant (conv mode only - the matcher never has N <= 64 at scale)
     const bool narrow = a.conv_c > 0 && a.N <= 64;
-    const int bm = narrow ? 256 : BM, bn = narrow ? 64 : BN;
+    // latency shape: when 128 x 128 tiles would leave most CUs idle (batch 1-4 of the reference's eval loop), 64 x 64 tiles
+    // make 4x more, 4x shorter work items (E2EMV_GEMM_SMALL=0 disables)
+    static int small_env = -1;
+    if (small_env < 0) { const char* e = getenv("E2EMV_GEMM_SMALL"); small_env = e ? atoi(e) : 1; }
+    const bool plain = a.conv_c == 0 && !a.C3 && !a.Vt && a.q_cols == 0;
+    const int64_t tiles128 = (int64_t)a.batch * ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const bool small = small_env && plain && tiles128 * 2 <= ctx->num_cus;
+    const int bm = narrow ? 256 : (small ? 64 : BM), bn = (narrow || small) ? 64 : BN;
     p.tiles_m = (a.M + bm - 1) / bm;
     p.tiles_n = (a.N + bn - 1) / bn;
     p.total = p.tiles_m * p.tiles_n * a.batch;
@@ -406,7 +424,9 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
     const int per_cu = wg > 0 ? wg : ((ext || bk == 64 || narrow) ? 2 : 3);
     const int sl = std::min(per_xcd, std::max(1, ctx->num_cus * per_cu / 8));
     const size_t lds = sizeof(float) * (bm + bn) * (bk + 4);
-    if (conv && narrow) {
+    if (small) {
+        hipLaunchKernelGGL((gemm_nt_kernel<false, 32, 0, false, 0>), dim3(8 * sl), dim3(256), lds, s, p);
+    } else if (conv && narrow) {
         hipLaunchKernelGGL((gemm_nt_kernel<false, 32, 0, true, 1>), dim3(8 * sl), dim3(256), lds, s, p);
     } else if (conv) {
         hipLaunchKernelGGL((gemm_nt_kernel<false, 32, 0, true>), dim3(8 * sl), dim3(256), lds, s, p);
