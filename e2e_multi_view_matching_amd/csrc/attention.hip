@@ -39,16 +39,23 @@ struct AttnParams {
     int B, T, n_rows, D, H, cross;
     int nv[E2EMV_MAX_TUPLE];  // valid keypoints (queries and keys) of image t of a tuple
     int nq, groups, gper;
+    // key-split mode (small problems): split sp of ksplit handles a slice of the key tiles and writes UNNORMALISED partial
+    // outputs + (running max, sum) per query; attention_merge_kernel folds them
+    int ksplit;
+    float* part_o;   // [n_img][H][n_rows][ksplit][64]
+    float* part_ml;  // [n_img][H][n_rows][ksplit][2]
 };
 
-template <int DBG>
+template <int DBG, bool SPLIT = false>
 __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) float Ks[ATT_KV * KLD];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_KV * HD];
 
     // XCD-aware mapping: all query tiles of one (image, head) share an XCD (K/V stay in its L2)
     const int lin = blockIdx.x;
-    const int xcd = lin & 7, idx = lin >> 3;
+    const int xcd = lin & 7;
+    const int sp = SPLIT ? (lin >> 3) % p.ksplit : 0;
+    const int idx = SPLIT ? (lin >> 3) / p.ksplit : lin >> 3;
     const int g = xcd * p.gper + idx / p.nq;
     if (g >= p.groups) return;
     const int qt = idx % p.nq;
@@ -111,9 +118,11 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
         }
     };
 
-    gload(0);
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        if (!(DBG & 4) || tile == 0) {
+    const int tile_lo = SPLIT ? (int)((int64_t)n_tiles * sp / p.ksplit) : 0;
+    const int tile_hi = SPLIT ? (int)((int64_t)n_tiles * (sp + 1) / p.ksplit) : n_tiles;
+    if (tile_lo < tile_hi) gload(tile_lo);
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+        if (!(DBG & 4) || tile == tile_lo) {
         __syncthreads();  // everyone is done reading the previous tile
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
             *reinterpret_cast<f32x4*>(&Vs[(st_row + 16 * i) * HD + st_c4]) = rv[i];
         }
         __syncthreads();
-        if (tile + 1 < n_tiles) gload(tile + 1);
+        if (tile + 1 < tile_hi) gload(tile + 1);
         }
 
         int tt_cur, kt;
@@ -179,6 +188,20 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if (SPLIT) {
+        const int64_t slot = (((int64_t)img * p.H + head) * p.n_rows + q_row) * p.ksplit + sp;
+        float* po = p.part_o + slot * HD + 4 * lh;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            f32x4 a, c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = O0[gq * 4 + e]; c[e] = O1[gq * 4 + e]; }
+            *reinterpret_cast<f32x4*>(po + 8 * gq) = a;
+            *reinterpret_cast<f32x4*>(po + 32 + 8 * gq) = c;
+        }
+        if (lh == 0) { p.part_ml[slot * 2] = m_run; p.part_ml[slot * 2 + 1] = l_tot; }
+        return;
+    }
     const float inv = 1.f / l_tot;
     float* op = p.out + ((int64_t)img * p.n_rows + q_row) * p.D + head * HD + 4 * lh;
 #pragma unroll
@@ -189,6 +212,28 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(AttnParams p) {
         *reinterpret_cast<f32x4*>(op + 8 * gq) = a;
         *reinterpret_cast<f32x4*>(op + 32 + 8 * gq) = c;
     }
+}
+
+// folds the key-split partials: out[q][:] = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M)
+__global__ __launch_bounds__(256) void attention_merge_kernel(AttnParams p) {
+    // one thread per (image, head, query, 4 channels)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = (int)(i & 15);
+    const int64_t rowi = i >> 4;  // (img * H + head) * n_rows + q
+    if (rowi >= (int64_t)p.groups * p.n_rows) return;
+    const int q = (int)(rowi % p.n_rows);
+    const int gh = (int)(rowi / p.n_rows), img = gh / p.H, head = gh % p.H;
+    if (q >= p.nv[img % p.T]) return;
+    float M = -1e30f;
+    for (int s2 = 0; s2 < p.ksplit; ++s2) M = fmaxf(M, p.part_ml[(rowi * p.ksplit + s2) * 2]);
+    float L = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < p.ksplit; ++s2) {
+        const float w = __builtin_amdgcn_exp2f(p.part_ml[(rowi * p.ksplit + s2) * 2] - M);
+        L += p.part_ml[(rowi * p.ksplit + s2) * 2 + 1] * w;
+        acc += *reinterpret_cast<const f32x4*>(p.part_o + (rowi * p.ksplit + s2) * HD + 4 * c4) * w;
+    }
+    *reinterpret_cast<f32x4*>(p.out + ((int64_t)img * p.n_rows + q) * p.D + head * HD + 4 * c4) = acc * (1.f / L);
 }
 
 int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, int D, int H, const float* qkv,
@@ -212,6 +257,42 @@ int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, in
     dim3 grid(8 * p.gper * p.nq);
     static int dbg = -1;  // E2EMV_ATTN_DEBUG: ablation variants for profiling only (results are wrong when != 0)
     if (dbg < 0) { const char* e = getenv("E2EMV_ATTN_DEBUG"); dbg = e ? atoi(e) : 0; }
+    // Small problems (batch 1-2 of the reference's eval loop): one workgroup per (image, head, 128 queries) leaves most CUs
+    // idle while each workgroup walks all key tiles serially.  Split the key tiles over up to 8 workgroups + a merge pass.
+    static int split_env = -1;  // E2EMV_ATTN_SPLIT: 0 off, n > 1 forces n
+    if (split_env < 0) { const char* e = getenv("E2EMV_ATTN_SPLIT"); split_env = e ? atoi(e) : -1; }
+    p.ksplit = 1; p.part_o = nullptr; p.part_ml = nullptr;
+    {
+        int min_tiles = 1 << 30;  // key tiles a query walks (smallest over the images)
+        for (int t = 0; t < T; ++t) {
+            int n = 0;
+            for (int u = 0; u < T; ++u)
+                if (cross ? u != t : u == t) n += (nv[u] + ATT_KV - 1) / ATT_KV;
+            min_tiles = std::min(min_tiles, n);
+        }
+        const int blocks = p.groups * p.nq;
+        int ks = split_env > 1 ? split_env : (split_env == 0 ? 1 : (blocks * 2 <= ctx->num_cus ? ctx->num_cus / blocks : 1));
+        ks = std::max(1, std::min(std::min(ks, 8), min_tiles));
+        if (ks > 1 && dbg == 0) {
+            const size_t rows = (size_t)p.groups * n_rows * ks;
+            const size_t need = rows * (HD + 2) * sizeof(float);
+            if (ctx->attn_part_bytes < need) {
+                E2EMV_HIP(ctx, hipStreamSynchronize(s));
+                if (ctx->d_attn_part) E2EMV_HIP(ctx, hipFree(ctx->d_attn_part));
+                ctx->d_attn_part = nullptr; ctx->attn_part_bytes = 0;
+                E2EMV_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_attn_part), need));
+                ctx->attn_part_bytes = need;
+            }
+            p.ksplit = ks;
+            p.part_o = ctx->d_attn_part;
+            p.part_ml = ctx->d_attn_part + rows * HD;
+            hipLaunchKernelGGL((attention_kernel<0, true>), dim3(8 * p.gper * p.nq * ks), dim3(256), 0, s, p);
+            const int64_t threads = (int64_t)p.groups * n_rows * 16;
+            hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p);
+            E2EMV_CHECK_LAUNCH(ctx, "attention_kernel (key-split)");
+            return E2EMV_OK;
+        }
+    }
     switch (dbg) {
         case 1: hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(256), 0, s, p); break;
         case 2: hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(256), 0, s, p); break;

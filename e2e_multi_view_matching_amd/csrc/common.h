@@ -90,6 +90,9 @@ struct e2emv_ctx {
     float* d_sparena = nullptr;
     float* sp_w[12] = {nullptr};
     float* sp_b[12] = {nullptr};
+    // partial results of the key-split attention (small problems), grown on demand
+    float* d_attn_part = nullptr;
+    size_t attn_part_bytes = 0;
     // workspace arena
     char* d_ws = nullptr;
     size_t ws_bytes = 0;

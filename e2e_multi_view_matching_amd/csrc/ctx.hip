@@ -106,6 +106,7 @@ void e2emv_destroy(e2emv_ctx* ctx) {
     if (ctx->d_warena) (void)hipFree(ctx->d_warena);
     if (ctx->d_w3arena) (void)hipFree(ctx->d_w3arena);
     if (ctx->d_sparena) (void)hipFree(ctx->d_sparena);
+    if (ctx->d_attn_part) (void)hipFree(ctx->d_attn_part);
     for (auto& pe : ctx->prof_events) {
         (void)hipEventDestroy(pe.a);
         (void)hipEventDestroy(pe.b);
