@@ -1,0 +1,85 @@
+"""Degenerate inputs (-m gpu): the cases a real evaluation run produces now and then - an image with one or two keypoints, a
+pair without usable matches, depth maps without valid pixels, a camera nobody observes - must give finite, defined results
+(the oracle's where the reference defines them)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n0,n1", [(1, 1), (1, 40), (2, 3), (130, 1)])
+def test_matcher_with_one_or_two_keypoints(gpu, n0, n1):
+    from e2e_multi_view_matching_amd import MultiViewMatcher
+    from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
+    from oracle.matcher import matcher_forward
+    torch.manual_seed(n0 * 7 + n1)
+    cfg = {"GNN_layers": ["self", "cross"] * 2, "sinkhorn_iterations": 12, "conf_mlp": True}
+    model = identity_like_state(MultiViewMatcher(cfg).eval())
+    data = make_tuples(batch=2, tuple_size=2, n_kpts=max(n0, n1), seed=n0 + n1)
+    for t, n in ((0, n0), (1, n1)):
+        data[f"keypoints{t}"] = data[f"keypoints{t}"][:, :n].contiguous()
+        data[f"scores{t}"] = data[f"scores{t}"][:, :n].contiguous()
+        data[f"descriptors{t}"] = data[f"descriptors{t}"][:, :, :n].contiguous()
+    ref = matcher_forward(data, model.state_dict(), {**model.config, "full_output": True})
+    out = model.to(gpu)({k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in data.items()})
+    z, zr = out["scores_0_1"].cpu(), ref["scores_0_1"]
+    assert z.shape == zr.shape == (2, n0 + 1, n1 + 1) and torch.isfinite(z).all() and float((z - zr).abs().max()) < 1e-4
+    assert torch.equal(out["matches0_0_1"].cpu(), ref["matches0_0_1"]) and torch.equal(out["matches1_0_1"].cpu(), ref["matches1_0_1"])
+
+
+def test_two_view_ba_with_too_few_or_zero_weight_matches(gpu):
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(1)
+    B, N = 3, 50
+    k0, k1 = torch.rand(B, N, 2, generator=g) - 0.5, torch.rand(B, N, 2, generator=g) - 0.5
+    conf = torch.rand(B, N, 1, generator=g)
+    conf[0] = 0.0            # nothing usable
+    conf[1, 6:] = 0.0        # 6 matches: below the reference's "more than 6" rule
+    T0 = torch.eye(4).repeat(B, 1, 1)
+    T0[:, 0, 3] = 1.0
+    Tr, valid = E.run_bundle_adjust_2_view(k0.to(gpu), k1.to(gpu), conf.to(gpu), T0.to(gpu), n_iterations=10)
+    assert valid.cpu().tolist() == [False, False, True] and Tr.shape == (1, 4, 4) and torch.isfinite(Tr).all()
+
+
+def test_gt_matches_without_valid_depth(gpu):
+    import e2e_multi_view_matching_amd as E
+    from e2e_multi_view_matching_amd.synthetic import make_depth_pairs
+    from oracle import gt_matches as OG
+    d = make_depth_pairs(2, n_kpts=64, seed=4)
+    d["depth0"][0] = 0.0   # sensor dropout over the whole image
+    d["depth1"][1] = 0.0
+    ref_i, ref_w = OG.compute_gt_matches_of_image_pair(d["keypoints0"], d["keypoints1"], d["intr0"], d["intr1"], d["T_0to1"], d["depth0"],
+                                                       d["depth1"], 5.0, 15.0)
+    dev = {k: v.to(gpu) for k, v in d.items()}
+    out_i, out_w = E.compute_gt_matches_of_image_pair(dev["keypoints0"], dev["keypoints1"], dev["intr0"], dev["intr1"], dev["T_0to1"],
+                                                      dev["depth0"], dev["depth1"], 5.0, 15.0)
+    assert torch.equal(out_i.cpu(), ref_i) and torch.isfinite(out_w).all() and float((out_w.cpu() - ref_w).abs().max()) < 1e-6
+
+
+def test_multi_view_ba_with_an_unobserved_camera_and_single_view_points(gpu):
+    from e2e_multi_view_matching_amd import multi_view
+    from oracle import mvba
+    rng = np.random.default_rng(0)
+    C, P = 4, 60
+    cams = np.zeros((C, 6))
+    cams[1:, :3] = rng.normal(0, 0.1, (C - 1, 3))
+    cams[1:, 3:] = rng.normal(0, 0.3, (C - 1, 3))
+    pts = np.stack([rng.uniform(-1, 1, P), rng.uniform(-1, 1, P), rng.uniform(4, 7, P)], 1)
+    ci, pi, obs = [], [], []
+    for p_ in range(P):
+        views = [0, 1] if p_ % 5 else [1]          # every fifth point is seen once; camera 3 sees nothing; camera 2 rarely
+        if p_ % 11 == 0:
+            views = [1, 2]
+        for c in views:
+            q = mvba.aa_to_R(cams[c, :3]) @ pts[p_] + cams[c, 3:]
+            ci.append(c); pi.append(p_); obs.append(q[:2] / q[2] + rng.normal(0, 1e-3, 2))
+    prob = dict(n_cams=C, fixed=0, intr=np.array([1.0, 1.0, 0.0, 0.0]), cam_idx=np.array(ci, np.int32), pt_idx=np.array(pi, np.int32),
+                obs=np.array(obs), wts=np.ones((len(ci), 2)), cams=cams + rng.normal(0, 0.01, cams.shape) * (np.arange(C) > 0)[:, None],
+                pts=pts + rng.normal(0, 0.02, pts.shape))
+    oc, op, osum = mvba.solve(prob)
+    gc, gp, gsum = multi_view.bundle_adjust(C, 0, prob["intr"], prob["cam_idx"], prob["pt_idx"], prob["obs"], prob["wts"], prob["cams"], prob["pts"])
+    assert np.isfinite(gc).all() and np.isfinite(gp).all()
+    assert np.array_equal(gc[3], prob["cams"][3])                      # the unobserved camera does not move
+    assert gsum["final_cost"] <= gsum["initial_cost"] and abs(gsum["final_cost"] - osum["final_cost"]) <= 1e-6 * max(osum["final_cost"], 1e-12)
+    assert np.abs(gc - oc).max() < 1e-5
