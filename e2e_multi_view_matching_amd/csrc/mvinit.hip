@@ -237,6 +237,31 @@ static bool admm_l1(const Dense& A, const std::vector<double>& b, const std::vec
     return true;
 }
 
+// Connected components of the view graph.  A view that shares no pair with the rest (an image without matches) is its own
+// component: it cannot be estimated and keeps its initial rotation / the origin; each component gets its own gauge view.
+static std::vector<int> components(int n_views, const std::vector<Pair>& pairs) {
+    std::vector<int> root(n_views);
+    for (int v = 0; v < n_views; ++v) root[v] = v;
+    auto find = [&](int v) { while (root[v] != v) v = root[v] = root[root[v]]; return v; };
+    for (const Pair& e : pairs) root[find(e.i)] = find(e.j);
+    for (int v = 0; v < n_views; ++v) root[v] = find(v);
+    return root;
+}
+// column index of every view in the linear systems (-1 = gauge of its component); highest / lowest id of a component is
+// the gauge when `highest` is set / cleared
+static std::vector<int> gauge_columns(int n_views, const std::vector<Pair>& pairs, bool highest, int& n_free) {
+    const std::vector<int> comp = components(n_views, pairs);
+    std::vector<int> gauge(n_views, -1), col(n_views, -1);
+    for (int v = 0; v < n_views; ++v) {
+        int& g = gauge[comp[v]];
+        if (g < 0 || (highest ? v > g : v < g)) g = v;
+    }
+    n_free = 0;
+    for (int v = 0; v < n_views; ++v)
+        if (gauge[comp[v]] != v) col[v] = n_free++;
+    return col;
+}
+
 // ---- robust rotation averaging -----------------------------------------------------------------------------------
 struct RotAvgOptions {
     int max_l1_steps = 5, max_irls_steps = 100;
@@ -246,12 +271,14 @@ struct RotAvgOptions {
 // rotations: angle-axis per view (in/out, index = view id 0..n-1); pairs: (i, j, angle-axis of R_ij with R_j = R_ij R_i)
 bool estimate_rotations(int n_views, const std::vector<Pair>& pairs, std::vector<double>& rot) {
     RotAvgOptions opt;
-    // Gauge: the rotation of the LAST view is held at its initial value.  Theia holds "the first view of its hash map";
-    // the reference's gtests (test_ba_init.cpp:95-180, absolute comparisons under noise) pin that to the last id.
-    const int fix = n_views - 1;
-    auto col = [&](int v) { return v == fix ? -1 : (v < fix ? v : v - 1); };
-    const int E = int(pairs.size()), nu = 3 * (n_views - 1);
-    if (n_views < 2 || E == 0) return n_views >= 1;
+    // Gauge: the rotation of the LAST view (of every connected component) is held at its initial value.  Theia holds "the
+    // first view of its hash map"; the reference's gtests (test_ba_init.cpp:95-180, absolute comparisons under noise) pin
+    // that to the last id.
+    int n_free = 0;
+    const std::vector<int> colv = gauge_columns(n_views, pairs, true, n_free);
+    auto col = [&](int v) { return colv[v]; };
+    const int E = int(pairs.size()), nu = 3 * n_free;
+    if (n_views < 2 || E == 0 || n_free == 0) return n_views >= 1;
     Dense A(3 * E, nu);
     for (int e = 0; e < E; ++e)
         for (int d = 0; d < 3; ++d) {
@@ -275,7 +302,7 @@ bool estimate_rotations(int n_views, const std::vector<Pair>& pairs, std::vector
     auto apply = [&]() -> double {  // R_v <- R_v exp(step_v); returns the mean step angle
         double avg = 0;
         for (int v = 0; v < n_views; ++v) {
-            if (v == fix) continue;
+            if (col(v) < 0) continue;
             const double* sv = &step[3 * col(v)];
             double dR[9], Rn[9];
             aa_to_R(sv, dR);
@@ -284,7 +311,7 @@ bool estimate_rotations(int n_views, const std::vector<Pair>& pairs, std::vector
             avg += std::sqrt(sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2]);
         }
         refresh();
-        return avg / (n_views - 1);
+        return avg / n_free;
     };
     refresh();
     residuals();
@@ -323,11 +350,14 @@ bool estimate_rotations(int n_views, const std::vector<Pair>& pairs, std::vector
 // ---- least-unsquared-deviation positions --------------------------------------------------------------------------
 // positions: 3 per view (out); view 0 at the origin.  Unknowns: positions of views 1.., one scale per pair (>= 1).
 bool estimate_positions(int n_views, const std::vector<Pair>& pairs, const std::vector<double>& rot, std::vector<double>& pos) {
-    const int E = int(pairs.size()), np = 3 * (n_views - 1), nu = np + E;
-    const int fix = 0;  // position gauge: view 0 at the origin (pinned by test_ba_init.cpp:183-266)
-    auto col = [&](int v) { return v == fix ? -1 : (v < fix ? v : v - 1); };
+    // position gauge: the lowest view of every connected component sits at the origin (view 0 for a connected graph,
+    // pinned by test_ba_init.cpp:183-266)
+    int n_free = 0;
+    const std::vector<int> colv = gauge_columns(n_views, pairs, false, n_free);
+    auto col = [&](int v) { return colv[v]; };
+    const int E = int(pairs.size()), np = 3 * n_free, nu = np + E;
     pos.assign(size_t(3) * n_views, 0.0);
-    if (n_views < 2 || E == 0) return n_views >= 1;
+    if (n_views < 2 || E == 0 || n_free == 0) return n_views >= 1;
     Dense A(3 * E, nu);
     for (int e = 0; e < E; ++e) {
         double Ri[9];
@@ -353,7 +383,7 @@ bool estimate_positions(int n_views, const std::vector<Pair>& pairs, const std::
     ao.rel_tol = 1e-10;
     if (!admm_l1(A, b, gv, gd, ao, x)) return false;
     for (int v = 0; v < n_views; ++v)
-        if (v != fix)
+        if (col(v) >= 0)
             for (int d = 0; d < 3; ++d) pos[3 * v + d] = x[3 * col(v) + d];
     return true;
 }

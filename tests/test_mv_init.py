@@ -188,3 +188,36 @@ def test_tokenizer_and_bad_files(tmp_path):
     assert lib.e2emv_mv_init_files(str(fin).encode(), str(tmp_path / "o.csv").encode()) == 0
     rows = [line.strip().split(",") for line in open(tmp_path / "o.csv")]
     assert len(rows) == 2 and [float(x) for x in rows[1]] == [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]
+
+
+def test_view_without_any_pair_keeps_its_initialisation():
+    """An image that matched nothing has no row in the pair list: it must not poison the solve of the others (singular normal
+    equations) - it keeps its initial rotation and the origin, the connected views are recovered as usual.  Also with the
+    isolated view in the middle of the id range and with two separate components."""
+    rng = np.random.default_rng(3)
+    lib = _lib.load_library()
+    for isolated in ([4], [2], [0]):
+        n = 5
+        Rw = [np.eye(3)] + [Rotation.from_rotvec(rng.normal(0, 0.4, 3)).as_matrix() for _ in range(n - 1)]
+        c = [np.zeros(3)] + [rng.normal(0, 1.0, 3) for _ in range(n - 1)]
+        ids, pR, pp = [], [], []
+        for j in range(n):
+            for i in range(j):
+                if i in isolated or j in isolated:
+                    continue
+                ids.append((i, j))
+                pR.append((Rw[j] @ Rw[i].T).T.reshape(-1))
+                pos = Rw[i] @ (c[j] - c[i])
+                pp.append(pos / np.linalg.norm(pos))
+        init = np.array([(Rw[v] @ Rotation.from_rotvec(rng.normal(0, 0.03, 3)).as_matrix()).T.reshape(-1) for v in range(n)])
+        ids, pR, pp = np.array(ids, np.int32), np.array(pR), np.array(pp)
+        oR, ot, st = np.zeros((n, 9)), np.zeros((n, 3)), ctypes.c_int32(0)
+        assert lib.e2emv_mv_init(n, p(init), len(ids), p(ids), p(pR), p(pp), p(oR), p(ot), ctypes.byref(st)) == 0
+        assert st.value == 0 and np.isfinite(oR).all() and np.isfinite(ot).all()
+        R0 = oR[0].reshape(3, 3).T
+        assert np.abs(R0 - np.eye(3)).max() < 1e-9  # output frame = camera 0
+        conn = [v for v in range(n) if v not in isolated]
+        ref = conn[0]
+        for a in conn:   # relative rotations among the connected views are exact
+            Ra, Rr = oR[a].reshape(3, 3).T, oR[ref].reshape(3, 3).T
+            assert np.abs(Ra @ Rr.T - Rw[a] @ Rw[ref].T).max() < 1e-5, (isolated, a)
