@@ -1,35 +1,124 @@
 #!/usr/bin/env python
 """bench.py - image-pairs/sec of the matcher -> Sinkhorn -> weighted-8-point path on MI355X.
 
-One step = one pass of the hot path over one batch of synthetic pairs, inputs resident in
-HBM: MultiViewMatcher.forward (kenc, 18 attention layers, final_proj, scores, 100 Sinkhorn
-iterations, match block, conf head) -> run_weighted_8_point (get_kpts + w8pt, fixed shape
-B x N like helpers.py:254-258) -> per-pair pose errors.  Workload at N=1: BASELINE.json
-configs[1] (tuple_size 2, 1024 keypoints, 256-d, 9x(self,cross), 100 Sinkhorn iterations,
-batch 32).  With --gpus N (launched by torch.distributed.run) every rank runs the same
-per-GPU batch on its own tuples (weak scaling, no data-path collective); the only
-collective is the final all-gather of per-pair pose errors for the AUC (RCCL).
+One step = one pass of the hot path over one batch of synthetic tuples, inputs resident in
+HBM: MultiViewMatcher.forward (kenc, GNN, final_proj, scores, Sinkhorn, match block, conf
+head) -> weighted 8-point pose of every pair of every tuple -> per-pair pose errors.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
-dominant kernel family (HIP events on the launch stream inside the timed region) and
-`cpu_baseline` (the torch-CPU oracle timed on a bounded sample, rank 0, N=1 only).
+Workloads (BASELINE.json `configs`, selected with --config, every field overridable):
+  c2 (default)  tuple_size 2, 1024 keypoints, 9x(self,cross), 100 Sinkhorn iterations, batch 32 pairs   = configs[1]
+  c4            tuple_size 5 (10 pairs per tuple), 1024 keypoints, batch 8 tuples                          = configs[3]
+  c5            tuple_size 5, 2048 keypoints, fp16 descriptors, batch 8 tuples per GPU                     = configs[4] per GPU
+  c1            tuple_size 2, 256 keypoints, batch 4, 5 Sinkhorn iterations                                = configs[0]
+configs[2] is c2 on 8 GPUs: `--gpus 8` (32 pairs per GPU, 256 in total).
+
+Multi-GPU: one process per GPU (reference launch: torch.distributed.launch --nproc_per_node=k, README.md:107,
+train.py:270-277).  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself
+through `python -m torch.distributed.run --nproc-per-node N`; under a launcher it asserts WORLD_SIZE == --gpus.
+Every rank runs the same per-GPU batch on its own tuples (weak scaling, no data-path collective); the only
+collective is the final all-gather of per-pair pose errors for the AUC (RCCL over xGMI), the counterpart of the
+reference's one-element all_reduce (train.py:102-106).
+
+Prints ONE JSON line on rank 0 with `roofline` for the dominant kernel family (HIP events on the launch stream
+inside the timed region) and `cpu_baseline` (the torch-CPU oracle on a bounded sample, rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 
+CONFIGS = {
+    "c1": dict(tuple_size=2, kpts=256, batch=4, sinkhorn_iters=5, desc="f32"),
+    "c2": dict(tuple_size=2, kpts=1024, batch=32, sinkhorn_iters=100, desc="f32"),
+    "c4": dict(tuple_size=5, kpts=1024, batch=8, sinkhorn_iters=100, desc="f32"),
+    "c5": dict(tuple_size=5, kpts=2048, batch=8, sinkhorn_iters=100, desc="f16"),
+}
+CONFIG_LABEL = {"c1": "configs[0]", "c2": "configs[1]", "c4": "configs[3]", "c5": "configs[4] (per-GPU share)"}
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--batch", type=int, default=None, help="tuples per GPU per step")
+    ap.add_argument("--kpts", type=int, default=None)
+    ap.add_argument("--tuple-size", type=int, default=None)
+    ap.add_argument("--sinkhorn-iters", type=int, default=None)
+    ap.add_argument("--desc", choices=["f32", "f16"], default=None, help="descriptor dtype handed to the matcher")
+    ap.add_argument("--gnn", default="9x1", help="GNN schedule gxc = (['self'] + ['cross']*c) * g (train.py:263-268): "
+                    "9x1 two-view / MegaDepth, 7x3 multi-view ScanNet")
+    ap.add_argument("--precision", choices=["default", "f32", "bf16x3"], default="default",
+                    help="arithmetic of the dense contractions for the timed region (default = the library default)")
+    ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs of the workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernel families with HIP events")
+    ap.add_argument("--ba", action="store_true", help="also run the two-view bundle adjustment (10 LM iterations) per pair "
+                    "inside the step (the reference's default eval mode w8pt_ba); off by default: SURVEY 8(d) defines the "
+                    "metric on matcher -> w8pt -> pose errors")
+    ap.add_argument("--front-end", action="store_true", help="extra (reported separately, never part of `value`): image-in "
+                    "pipeline = SuperPoint on tuple_size*batch 480x640 images -> matcher -> w8pt per step")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra measurement in the other arithmetic mode")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement (eval_pairs.py's loop shape)")
+    ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; the CPU test uses gloo)")
+    args = ap.parse_args(argv)
+    preset = CONFIGS[args.config]
+    for key, attr in (("tuple_size", "tuple_size"), ("kpts", "kpts"), ("batch", "batch"), ("sinkhorn_iters", "sinkhorn_iters"),
+                      ("desc", "desc")):
+        if getattr(args, attr) is None:
+            setattr(args, attr, preset[key])
+    g, c = (int(v) for v in args.gnn.lower().split("x"))
+    args.layers = (["self"] + ["cross"] * c) * g
+    return args
+
+
+def workload_string(args, world):
+    """`config.workload`, built from the arguments actually used (never a fixed label)."""
+    preset = CONFIGS[args.config]
+    exact = all(getattr(args, k) == preset[k] for k in ("tuple_size", "kpts", "batch", "sinkhorn_iters", "desc")) \
+        and args.gnn.lower() == "9x1"
+    P = args.tuple_size * (args.tuple_size - 1) // 2
+    label = CONFIG_LABEL[args.config] if exact else "custom (derived from %s)" % CONFIG_LABEL[args.config]
+    if exact and args.config == "c2" and world == 8:
+        label = "configs[2] (configs[1] per GPU x 8)"
+    return (f"{label}: tuple_size={args.tuple_size} ({P} pair{'s' if P > 1 else ''} per tuple), {args.kpts} keypoints, 256-dim "
+            f"{args.desc} descriptors, GNN {args.gnn} = {len(args.layers)} layers, {args.sinkhorn_iters} Sinkhorn iters, "
+            f"batch {args.batch} tuples/GPU = {args.batch * P} pairs/GPU, w8pt pose per pair")
+
+
+# ----------------------------------------------------------------------------------------- launch
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def maybe_self_spawn(args, argv):
+    """--gpus N > 1 without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------------------- flops model
 def algorithmic_flops(B, T, N, D, layers, conf_mlp):
     """Per-step dense flops by kernel family (SURVEY.md 8(d) formula, joint GNN)."""
     kenc = [3, 32, 64, 128, 256, D]
@@ -48,259 +137,449 @@ def algorithmic_flops(B, T, N, D, layers, conf_mlp):
     return {"gemm": gemm, "attention": attn, "score_gemm": score}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step")
-    ap.add_argument("--kpts", type=int, default=1024)
-    ap.add_argument("--tuple-size", type=int, default=2)
-    ap.add_argument("--sinkhorn-iters", type=int, default=100)
-    ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernel families with HIP events")
-    ap.add_argument("--ba", action="store_true", help="also run the two-view bundle adjustment (10 LM iterations) per pair "
-                    "inside the step (the reference's default eval mode w8pt_ba); off by default: SURVEY 8(d) defines the "
-                    "metric on matcher -> w8pt -> pose errors")
-    ap.add_argument("--front-end", action="store_true", help="extra (reported separately, never part of `value`): image-in "
-                    "pipeline = SuperPoint on 2*batch 480x640 images -> matcher -> w8pt per step")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-for-value) bf16x3-attention measurement")
-    args = ap.parse_args()
+# ----------------------------------------------------------------------------------------- workloads
+class HipWorkload:
+    """The product path on this rank's GPU."""
 
+    def __init__(self, args, rank, local_rank):
+        import torch
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        self.torch = torch
+        self.dev = torch.device("cuda", local_rank)
+        self.args = args
+
+    def setup(self, rank):
+        torch = self.torch
+        import e2e_multi_view_matching_amd as E
+        from e2e_multi_view_matching_amd import _lib
+        from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
+        a = self.args
+        self.E, self._lib = E, _lib
+        B, T, N = a.batch, a.tuple_size, a.kpts
+        self.cfg = {"GNN_layers": a.layers, "sinkhorn_iterations": a.sinkhorn_iters, "conf_mlp": True, "tuple_size": T,
+                    "multi_frame_matching": T > 2, "match_threshold": 0.2}
+        self.pairs = [(i, j) for j in range(T) for i in range(j)]
+        torch.manual_seed(1234)
+        self.model = E.MultiViewMatcher(self.cfg).eval().to(self.dev)           # W-rand: timed
+        torch.manual_seed(1234)
+        self.model_id = identity_like_state(E.MultiViewMatcher(self.cfg).eval()).to(self.dev)  # W-id: AUC leg
+        dt = torch.float16 if a.desc == "f16" else torch.float32
+        self.data_cpu = make_tuples(batch=B, tuple_size=T, n_kpts=N, seed=1000 + rank, desc_dtype=dt)
+        self.data = {k: (v.to(self.dev) if torch.is_tensor(v) else v) for k, v in self.data_cpu.items()}
+        self.ctx = _lib.context(self.dev)
+        if a.precision != "default":
+            self.set_precision(a.precision)
+
+    def set_precision(self, name):
+        self.ctx.set_precision(name)  # explicit override for every model on this device that does not pin its own
+
+    def precision(self):
+        return {self._lib.PRECISION_F32: "f32", self._lib.PRECISION_BF16X3: "bf16x3"}[self.ctx.precision()]
+
+    def step(self, model=None, data=None):
+        E, torch = self.E, self.torch
+        m = self.model if model is None else model
+        d = self.data if data is None else data
+        with torch.no_grad():
+            res = m(d)
+            poses = E.run_weighted_8_point_tuple(d, res)   # all pairs of all tuples: one batched solve
+            errs = []
+            for (i, j) in self.pairs:
+                Tp, info = poses[(i, j)]
+                if self.args.ba:  # eval_pairs.py:250-255
+                    c = E.mask_confidence(info["confidence"], info["pos_depth_mask"])
+                    Tr, vb = E.run_bundle_adjust_2_view(info["kpts0_norm"], info["kpts1_norm"], c, Tp, n_iterations=10)
+                    Tp[vb] = Tr
+                errs.append(E.pose_errors(Tp, d[f"T_{i}to{j}"]))
+        return res, errs
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def profile(self, on):
+        self.ctx.call("e2emv_profile", 1 if on else 0)
+        return self._lib.profile_read(self.ctx, reset=True)
+
+    def auc_errors(self):
+        from e2e_multi_view_matching_amd.metrics import pair_errors_deg
+        _, errs = self.step(self.model_id)
+        self.id_errs = errs
+        return np.concatenate([pair_errors_deg(r.cpu().numpy(), t.cpu().numpy()) for r, t in errs])
+
+
+class StubWorkload:
+    """E2EMV_BENCH_STUB=1: no GPU, no kernels - a fixed-duration stand-in for the step so that the launcher, the process
+    group, the barriers, the MAX-over-ranks timing, the error all-gather and the rank-0 JSON line of the N > 1 branch can
+    be exercised on CPU over gloo (tests/test_bench_distributed.py).  Never used for a reported number."""
+
+    def __init__(self, args, rank, local_rank):
+        self.args, self.rank, self.dev = args, rank, None
+        self.pairs = [(i, j) for j in range(args.tuple_size) for i in range(j)]
+
+    def setup(self, rank):
+        self.default_precision = 0
+
+    def set_precision(self, name):
+        pass
+
+    def precision(self):
+        return "stub"
+
+    def step(self, model=None, data=None):
+        time.sleep(0.002 * (1 + self.rank))
+        return None, None
+
+    def sync(self):
+        pass
+
+    def profile(self, on):
+        return None
+
+    def auc_errors(self):
+        n = self.args.batch * len(self.pairs)
+        return np.random.default_rng(100 + self.rank).uniform(0, 30, n)
+
+
+# ----------------------------------------------------------------------------------------- CPU baseline
+def host_cpu_info():
+    model, cores = "unknown", set()
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = None
+    try:
+        cpu, phys, core = None, 0, None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("processor"):
+                    cpu = int(line.split(":")[1])
+                elif line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = int(line.split(":")[1])
+                elif line.startswith("core id"):
+                    core = int(line.split(":")[1])
+                elif not line.strip() and cpu is not None:
+                    if allowed is None or cpu in allowed:
+                        cores.add((phys, core if core is not None else cpu))
+                    cpu, core = None, None
+    except OSError:
+        pass
+    logical = len(allowed) if allowed is not None else (os.cpu_count() or 1)
+    return {"model": model, "physical_cores": max(len(cores), 1) if cores else logical, "logical_cpus": logical}
+
+
+def cpu_baseline(args, wl):
+    """The oracle (torch CPU fp32, the reference's unfused op sequence) on a bounded sample of the workload - SURVEY 8(d):
+    threads = physical cores and 1, CPU model stated, configs[0] verbatim and the bench workload at a small batch."""
+    import torch
+    from e2e_multi_view_matching_amd.synthetic import make_tuples
+    from oracle import w8pt as OW
+    from oracle.matcher import matcher_forward
+    info = host_cpu_info()
+    phys = info["physical_cores"]
+    sd = {k: v.detach().cpu() for k, v in wl.model.state_dict().items()}
+    P = len(wl.pairs)
+
+    def run(data, cfg, sdict):
+        with torch.no_grad():
+            ref = matcher_forward(data, sdict, cfg)
+            T = data_tuple_size(data)
+            for j in range(T):
+                for i in range(j):
+                    Tr, _ = OW.run_weighted_8_point(data, ref, i, j)
+                    if Tr is not None:
+                        OW.compute_rotation_error(Tr, data[f"T_{i}to{j}"], reduce=False)
+        return ref
+
+    def data_tuple_size(d):
+        t = 0
+        while f"keypoints{t}" in d:
+            t += 1
+        return t
+
+    def timed(data, cfg, sdict, threads):
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        run(data, cfg, sdict)
+        return time.perf_counter() - t0
+
+    prev = torch.get_num_threads()
+    ocfg = {**wl.cfg, "full_output": True}
+    one = {k: (v[:1] if torch.is_tensor(v) else v) for k, v in wl.data_cpu.items()}
+    nb = max(1, min(args.cpu_pairs // max(P, 1), args.batch)) if P > 1 else min(args.cpu_pairs, args.batch)
+    small = {k: (v[:nb] if torch.is_tensor(v) else v) for k, v in wl.data_cpu.items()}
+    # thread scan on one tuple: more threads than the memory system feeds make the unfused torch ops slower
+    cand = sorted({n for n in (8, 16, 32, 64, phys) if n <= phys} or {phys})
+    scan = {}
+    for n in cand:
+        scan[n] = timed(one, ocfg, sd, n)
+    best = min(scan, key=scan.get)
+    t_best = timed(small, ocfg, sd, best)
+    t_one = scan[1] if 1 in scan else timed(one, ocfg, sd, 1)
+    # configs[0] verbatim: tuple_size 2, 256 keypoints, batch 4, 5 Sinkhorn iterations
+    c1cfg = {"GNN_layers": ["self", "cross"] * 9, "sinkhorn_iterations": 5, "conf_mlp": True, "tuple_size": 2,
+             "multi_frame_matching": False, "match_threshold": 0.2, "full_output": True}
+    torch.manual_seed(1234)
+    import e2e_multi_view_matching_amd as E
+    sd1 = {k: v.detach() for k, v in E.MultiViewMatcher(c1cfg).eval().state_dict().items()}
+    d1 = make_tuples(batch=4, tuple_size=2, n_kpts=256, seed=7)
+    timed(d1, c1cfg, sd1, best)  # warm
+    c1_best, c1_one = timed(d1, c1cfg, sd1, best), timed(d1, c1cfg, sd1, 1)
+    torch.set_num_threads(prev)
+    out = {"value": round(nb * P / t_best, 3), "unit": "pairs/s", "cores": best, "kind": "port",
+           "cpu_model": info["model"], "physical_cores": phys, "logical_cpus": info["logical_cpus"],
+           "sample": f"{nb * P} pairs ({nb} tuple{'s' if nb > 1 else ''}) of the bench workload through oracle/ (torch-CPU fp32, "
+                     f"{best} threads = the fastest of the scan {cand}, {t_best:.1f} s)",
+           "thread_scan_s_per_tuple": {str(k): round(v, 3) for k, v in scan.items()},
+           "single_thread": {"value": round(P / t_one, 4), "unit": "pairs/s", "cores": 1,
+                             "sample": f"{P} pair(s) (1 tuple) of the bench workload, {t_one:.1f} s"},
+           "configs0": {"workload": "configs[0] verbatim: tuple_size=2, 256 keypoints, batch 4, 5 Sinkhorn iters",
+                        "value": round(4 / c1_best, 2), "cores": best, "single_thread_value": round(4 / c1_one, 2),
+                        "unit": "pairs/s"}}
+    return out, small, nb, best
+
+
+# ----------------------------------------------------------------------------------------- main
+def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not os.environ.get("E2EMV_BENCH_FORCE_DIST"):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    stub = bool(os.environ.get("E2EMV_BENCH_STUB"))
+    wl = (StubWorkload if stub else HipWorkload)(args, rank, local_rank)
+
     dist = None
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("E2EMV_BENCH_FORCE_DIST"):  # the env knob exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
+        backend = args.backend or ("gloo" if stub else "nccl")
+        kw = {"device_id": wl.dev} if backend == "nccl" else {}
         # one process per GPU over RCCL ("nccl" on ROCm); binding the group to this rank's device up front keeps
         # barrier()/collectives from guessing it
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        dist.init_process_group(backend, init_method="env://", **kw)
+        assert dist.get_world_size() == world
 
-    import e2e_multi_view_matching_amd as E
-    from e2e_multi_view_matching_amd import _lib
     from e2e_multi_view_matching_amd.distributed import gather_pair_errors, reduce_max_seconds
-    from e2e_multi_view_matching_amd.metrics import pair_errors_deg, pose_auc
-    from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
+    from e2e_multi_view_matching_amd.metrics import pose_auc
 
+    wl.setup(rank)
     B, T, N, D = args.batch, args.tuple_size, args.kpts, 256
-    layers = ["self", "cross"] * 9
-    cfg = {"GNN_layers": layers, "sinkhorn_iterations": args.sinkhorn_iters, "conf_mlp": True, "tuple_size": T,
-           "multi_frame_matching": T > 2, "match_threshold": 0.2}
-    pairs = [(i, j) for j in range(T) for i in range(j)]
-    P = len(pairs)
+    P = len(wl.pairs)
 
-    torch.manual_seed(1234)
-    model = E.MultiViewMatcher(cfg).eval().to(dev)           # W-rand: timed
-    torch.manual_seed(1234)
-    model_id = identity_like_state(E.MultiViewMatcher(cfg).eval()).to(dev)  # W-id: AUC leg (meaningful matches)
-    data_cpu = make_tuples(batch=B, tuple_size=T, n_kpts=N, seed=1000 + rank)
-    data = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data_cpu.items()}
+    def barrier():
+        if dist is not None:
+            dist.barrier()
 
-    def step(m):
-        with torch.no_grad():
-            res = m(data)
-            errs = []
-            for (i, j) in pairs:
-                Tp, info = E.run_weighted_8_point(data, res, i, j)
-                if args.ba:  # eval_pairs.py:250-255
-                    c = info["confidence"] * info["pos_depth_mask"].unsqueeze(-1)
-                    Tr, vb = E.run_bundle_adjust_2_view(info["kpts0_norm"], info["kpts1_norm"], c, Tp, n_iterations=10)
-                    Tp[vb] = Tr
-                errs.append(E.pose_errors(Tp, data[f"T_{i}to{j}"]))
-        return res, errs
+    def timed_steps(k):
+        wl.sync()
+        barrier()
+        wl.sync()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            wl.step()
+        wl.sync()
+        barrier()
+        return reduce_max_seconds(time.perf_counter() - t0, device=wl.dev)  # MAX over ranks
 
-    ctx = _lib.context(dev)
     for _ in range(args.warmup):
-        step(model)
-    torch.cuda.synchronize()
+        wl.step()
+    wl.sync()
     if not args.no_profile:
-        ctx.call("e2emv_profile", 1)
-        _lib.profile_read(ctx, reset=True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(model)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+        wl.profile(True)
+    elapsed = timed_steps(args.steps)
     prof = None
     if not args.no_profile:
-        prof = _lib.profile_read(ctx, reset=True)
-        ctx.call("e2emv_profile", 0)
-    elapsed = reduce_max_seconds(elapsed, device=dev)  # MAX over ranks
+        prof = wl.profile(False)
+    mode = wl.precision()
 
-    # ---- optional second measurement: attention on the bf16 pipe with 3-way split operands (fp32-class accuracy,
-    # e2emv_set_precision); reported separately, `value` above is always the all-fp32-MFMA path
+    # the same K steps once more without the HIP-event brackets (what the instrumentation costs)
+    bare = None
+    if not args.no_profile and not stub:
+        bare = timed_steps(args.steps)
+
+    # ---- second measurement: the same workload in the other arithmetic mode (reported separately)
     alt = None
-    if not args.no_alt:
-        ctx.call("e2emv_set_precision", _lib.PRECISION_BF16X3)
+    if not args.no_alt and not stub:
+        other = "bf16x3" if mode == "f32" else "f32"
+        wl.set_precision(other)
         for _ in range(2):
-            step(model)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        a0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(model)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        alt_elapsed = time.perf_counter() - a0
-        alt_elapsed = reduce_max_seconds(alt_elapsed, device=dev)
-        ctx.call("e2emv_set_precision", _lib.PRECISION_F32)
-        alt = {"ms_per_step": round(1000.0 * alt_elapsed / args.steps, 3),
-               "value": round(B * len(pairs) * world * args.steps / alt_elapsed, 2), "unit": "pairs/s",
-               "note": "same workload with e2emv_set_precision(BF16X3): attention and the two MLP GEMMs of every layer run on the "
-                       "bf16 matrix pipe with 3-way split operands (6 bf16-MFMA products per block, fp32 accumulation; "
-                       "fp32-class accuracy - every parity test runs in both modes at the same 1e-4 / bit-exact-index bar)"}
+            wl.step()
+        alt_elapsed = timed_steps(args.steps)
+        wl.set_precision(mode)
+        alt = {"mode": other, "ms_per_step": round(1000.0 * alt_elapsed / args.steps, 3),
+               "value": round(B * P * world * args.steps / alt_elapsed, 2), "unit": "pairs/s"}
 
     # ---- optional: the image-in pipeline (SuperPoint front-end feeding the same matcher / pose path)
     image_in = None
-    if args.front_end:
+    if args.front_end and not stub:
+        import torch
         from e2e_multi_view_matching_amd.superpoint import SuperPoint
+        E = wl.E
         torch.manual_seed(7)
-        sp = SuperPoint({"max_keypoints": N, "nms_radius": 4, "remove_borders": 4, "fill_with_random_keypoints": True}).eval().to(dev)
-        images = torch.rand(T * B, 1, 480, 640, device=dev)
+        sp = SuperPoint({"max_keypoints": N, "nms_radius": 4, "remove_borders": 4, "fill_with_random_keypoints": True}).eval().to(wl.dev)
+        images = torch.rand(T * B, 1, 480, 640, device=wl.dev)
 
         def step_images():
             with torch.no_grad():
                 pred = sp({"image": [images]})  # helpers.run_super_point's merged batch (helpers.py:73-96)
-                d2 = dict(data)
+                d2 = dict(wl.data)
                 for key, v in pred.items():
                     res = torch.stack(v).view(T, B, *v[0].shape)
                     for m in range(T):
                         d2[key + str(m)] = res[m]
-                res = model(d2)
-                for (i, j) in pairs:
-                    E.run_weighted_8_point(d2, res, i, j)
+                E.run_weighted_8_point_tuple(d2, wl.model(d2))
         for _ in range(2):
             step_images()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        wl.sync()
+        barrier()
         f0 = time.perf_counter()
         for _ in range(args.steps):
             step_images()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        fe = reduce_max_seconds(time.perf_counter() - f0, device=dev)
-        image_in = {"ms_per_step": round(1000.0 * fe / args.steps, 3), "value": round(B * len(pairs) * world * args.steps / fe, 2),
+        wl.sync()
+        barrier()
+        fe = reduce_max_seconds(time.perf_counter() - f0, device=wl.dev)
+        image_in = {"ms_per_step": round(1000.0 * fe / args.steps, 3), "value": round(B * P * world * args.steps / fe, 2),
                     "unit": "pairs/s", "note": f"{T * B} random 480x640 images per GPU and step through the SuperPoint front-end "
                     f"(random weights, padded to {N} keypoints) -> matcher -> w8pt"}
 
+    # ---- batch-1 latency: the reference's eval_pairs.py loop is one pair at a time (eval_pairs.py:207-256)
+    latency = None
+    if not args.no_latency and not stub and world == 1:
+        torch = wl.torch
+        one = {k: (v[:1].contiguous() if torch.is_tensor(v) else v) for k, v in wl.data.items()}
+        for _ in range(3):
+            wl.step(data=one)
+        wl.sync()
+        l0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            wl.step(data=one)
+        wl.sync()
+        lt = (time.perf_counter() - l0) / reps
+        latency = {"ms_per_tuple": round(1000.0 * lt, 3), "pairs_per_s": round(P / lt, 1),
+                   "note": "batch 1 (one tuple per call, eval_pairs.py:207-256 loop shape), matcher -> w8pt -> pose errors"}
+
     # ---- AUC leg (not timed): identity-like weights give real matches; errors gathered over ranks
-    _, errs = step(model_id)
-    e_deg = np.concatenate([pair_errors_deg(r.cpu().numpy(), t.cpu().numpy()) for r, t in errs])
-    e_all = gather_pair_errors(e_deg, device=dev)  # the path's only data collective (RCCL over xGMI), B*P floats per rank
+    e_deg = wl.auc_errors()
+    e_all = gather_pair_errors(e_deg, device=wl.dev)  # the path's only data collective (RCCL over xGMI), B*P floats per rank
     auc = [100.0 * a for a in pose_auc(e_all, [5, 10, 20])]
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
-        return
+        return 0
 
     pairs_per_step = B * P * world
     value = pairs_per_step * args.steps / elapsed
+    dtype = {"f32": "f32", "bf16x3": "bf16x3 (fp32 operands split into 3 bf16 planes, 6 bf16-MFMA products, fp32 accumulate: "
+             "fp32-class accuracy, same 1e-4 / bit-exact-index parity bar)", "stub": "stub"}[mode]
     out = {
         "metric": "image-pairs/sec @1024 kpts + pose AUC@5/10/20deg vs reference",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: tuple_size={T}, {N} keypoints, 256-dim desc, 9x(self,cross) GNN, "
-                               f"{args.sinkhorn_iters} Sinkhorn iters, batch {B} pairs/GPU, w8pt pose per pair",
-                   "pairs_per_gpu": B * P, "global_pairs": pairs_per_step, "weights": "random init (timed), "
-                   "identity-like for the AUC leg", "parallelism": f"tuple-sharded x{world}"},
-        "auc_5_10_20": [round(a, 3) for a in auc],
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": workload_string(args, world), "pairs_per_gpu": B * P, "global_pairs": pairs_per_step,
+                   "weights": "random init (timed), identity-like for the AUC leg", "parallelism": f"tuple-sharded x{world}"},
+        "auc_5_10_20": [round(a, 3) for a in auc], "auc_pairs": int(len(e_all)),
     }
+    if bare is not None:
+        out["ms_per_step_without_event_brackets"] = round(1000.0 * bare / args.steps, 3)
     if alt:
-        out["bf16x3_attention"] = alt
+        out["other_precision"] = alt
     if image_in:
         out["image_in_pipeline"] = image_in
+    if latency:
+        out["batch1_latency"] = latency
 
     # ---- roofline of the dominant kernel family, from HIP events recorded in the timed region
     if prof:
-        fl = algorithmic_flops(B, T, N, D, layers, True)
+        fl = algorithmic_flops(B, T, N, D, args.layers, True)
         fam = max(("gemm", "attention"), key=lambda k: prof[k]["ms"])
-        ms, n = prof[fam]["ms"], prof[fam]["launches"]
-        achieved = fl[fam] * args.steps / (ms * 1e-3) / 1e12
-        kname = {"gemm": "gemm_nt_kernel", "attention": "attention_kernel"}[fam]
+        kname = {"f32": {"gemm": "gemm_nt_kernel", "attention": "attention_kernel"},
+                 "bf16x3": {"gemm": "gemm_x3_kernel", "attention": "attention3_kernel"}}[mode][fam]
+        # f32 mode: exact fp32 MFMA.  bf16x3 mode: every algorithmic flop is 6 bf16-MFMA flops, so the ceiling for
+        # ALGORITHMIC flops is the dense bf16 peak / 6.
+        peak = PEAK_F32_MFMA_TFLOPS if mode == "f32" else PEAK_BF16_MFMA_TFLOPS / 6.0
+
+        def family(f):
+            ms, n = prof[f]["ms"], prof[f]["launches"]
+            return fl[f] * args.steps / (ms * 1e-3) / 1e12, ms, n
+        achieved, ms, n = family(fam)
         # HBM bytes per launch of that kernel from the rocprofv3 --pmc passes of this same command (FETCH_SIZE x 2 per
-        # MI355X_MICROARCH.md, calibrated on sinkhorn_sweep's known byte count) - profiles/summarize_pmc.py
+        # MI355X_MICROARCH.md, calibrated on the Sinkhorn sweep's known byte count) - profiles/summarize_pmc.py
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                k = json.load(fh)["kernels"][kname]
-            traffic = int(k["read_bytes"] + k["write_bytes"])
+                pj = json.load(fh)
+            if pj.get("workload_key", "c2") == args.config and pj.get("mode", "f32") == mode:
+                k = pj["kernels"][kname]
+                traffic = int(k["read_bytes"] + k["write_bytes"])
         except Exception:
             traffic = None
         out["roofline"] = {"bound": "mfma", "kernel": kname,
-                           "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                           "traffic_note": "HBM bytes per launch (read + write), PMC passes committed under profiles/; "
-                                           "algorithmic flops include the merge conv that is folded into MLP0 (executed "
-                                           "flops are 18/20 of algorithmic)",
+                           "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                           "frac": round(achieved / peak, 4), "traffic": traffic,
+                           "note": ("algorithmic flops of the family / HIP-event time; " +
+                                    ("exact fp32 MFMA (v_mfma_f32_32x32x2_f32)" if mode == "f32" else
+                                     "peak = dense bf16 MFMA 2500 TFLOP/s / 6 products per algorithmic flop")) +
+                                   "; traffic = HBM bytes per launch (read + write) from the PMC passes under profiles/",
                            "avg_launch_ms": round(ms / max(n, 1), 4), "launches_per_step": n // args.steps}
-        sk = prof["sinkhorn"]
-        sk_bytes = B * P * (2 * args.sinkhorn_iters + 2) * (N + 1) ** 2 * 4
+        fam2 = "attention" if fam == "gemm" else "gemm"
+        a2, _, _ = family(fam2)
+        out["roofline_second"] = {"kernel": fam2, "achieved": round(a2, 2), "unit": "TFLOP/s", "frac": round(a2 / peak, 4)}
         out["families"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["launches"] // args.steps}
                            for k, v in prof.items() if v["launches"]}
+        sk = prof["sinkhorn"]
         if sk["ms"] > 0:
-            gbs = sk_bytes * args.steps / (sk["ms"] * 1e-3) / 1e9
+            model_bytes = B * P * (2 * args.sinkhorn_iters + 2) * (N + 1) ** 2 * 4
+            gbs = model_bytes * args.steps / (sk["ms"] * 1e-3) / 1e9
             out["sinkhorn_roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                        "note": "algorithmic bytes (2 sweeps/iter model) / time; the kernel streams S once per iteration"}
-        fam2 = "attention" if fam == "gemm" else "gemm"
-        a2 = fl[fam2] * args.steps / (prof[fam2]["ms"] * 1e-3) / 1e12
-        out["roofline_second"] = {"kernel": fam2, "achieved": round(a2, 2), "unit": "TFLOP/s",
-                                  "frac": round(a2 / PEAK_F32_MFMA_TFLOPS, 4)}
+                                        "note": "SURVEY 8(d) byte model (2 sweeps of the couplings per iteration) / time; the "
+                                                "resident kernel reads the scores once per CALL (they stay in registers for "
+                                                "all iterations), the streaming fallback once per iteration - physical HBM "
+                                                "bytes are in profiles/"}
 
     # ---- CPU baseline: the oracle (torch CPU, same unfused op sequence as the reference) on a bounded sample
-    if world == 1 and args.cpu_pairs > 0:
+    if world == 1 and args.cpu_pairs > 0 and not stub:
+        import torch
+        from e2e_multi_view_matching_amd.metrics import pair_errors_deg
         from oracle import w8pt as OW
         from oracle.matcher import matcher_forward
-        nb = min(args.cpu_pairs, B)
-        small = {k: (v[:nb] if torch.is_tensor(v) else v) for k, v in data_cpu.items()}
-        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        sd_id = {k: v.detach().cpu() for k, v in model_id.state_dict().items()}
-        ocfg = {**cfg, "full_output": True}
-        c0 = time.perf_counter()
-        with torch.no_grad():
-            ref = matcher_forward(small, sd, ocfg)
-            for (i, j) in pairs:
-                Tr, _ = OW.run_weighted_8_point(small, ref, i, j)
-                if Tr is not None:
-                    OW.compute_rotation_error(Tr, small[f"T_{i}to{j}"], reduce=False)
-        c1 = time.perf_counter()
-        out["cpu_baseline"] = {"value": round(nb * P / (c1 - c0), 3), "unit": "pairs/s", "cores": torch.get_num_threads(),
-                               "kind": "port", "sample": f"{nb * P} pairs of the same workload (oracle/ torch-CPU fp32, "
-                               f"{torch.get_num_threads()} threads, {c1 - c0:.1f} s)"}
+        base, small, nb, best = cpu_baseline(args, wl)
+        out["cpu_baseline"] = base
         # AUC parity on the sample (identity-like weights): HIP vs oracle on identical inputs
+        torch.set_num_threads(best)
+        sd_id = {k: v.detach().cpu() for k, v in wl.model_id.state_dict().items()}
         with torch.no_grad():
-            ref = matcher_forward(small, sd_id, ocfg)
+            ref = matcher_forward(small, sd_id, {**wl.cfg, "full_output": True})
             eo = []
-            for (i, j) in pairs:
+            for (i, j) in wl.pairs:
                 Tr, _ = OW.run_weighted_8_point(small, ref, i, j)
                 r = OW.compute_rotation_error(Tr, small[f"T_{i}to{j}"], reduce=False)
                 t = OW.compute_translation_error_as_angle(Tr, small[f"T_{i}to{j}"], reduce=False)
                 eo.append(pair_errors_deg(r.numpy(), t.numpy()))
         eo = np.concatenate(eo)
-        eh = np.concatenate([pair_errors_deg(r.cpu().numpy()[:nb], t.cpu().numpy()[:nb]) for r, t in errs])
+        eh = np.concatenate([pair_errors_deg(r.cpu().numpy()[:nb], t.cpu().numpy()[:nb]) for r, t in wl.id_errs])
         out["auc_parity_sample"] = {"pairs": int(nb * P), "hip": [round(100 * a, 3) for a in pose_auc(eh, [5, 10, 20])],
                                     "oracle": [round(100 * a, 3) for a in pose_auc(eo, [5, 10, 20])],
                                     "max_abs_err_deg_diff": float(np.max(np.abs(eh - eo)))}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    rc = maybe_self_spawn(args, argv)
+    if rc is not None:
+        return rc
+    return run(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

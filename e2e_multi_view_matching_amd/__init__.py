@@ -10,12 +10,14 @@ from .metrics import compute_pose_error, pose_auc  # noqa: F401
 from .ops import (attention, attention_bf16x3, extract_matches, gemm_bf16x3, gemm_nt,  # noqa: F401
                   log_optimal_transport)
 from .pose import (compute_rotation_error, compute_translation_error_as_angle, estimate_relative_pose_w8pt,  # noqa: F401
-                   get_kpts, normalize, pose_errors, run_bundle_adjust_2_view, run_weighted_8_point)
+                   get_kpts, mask_confidence, normalize, pose_errors, run_bundle_adjust_2_view,
+                   run_weighted_8_point, run_weighted_8_point_tuple)
 
 from .superpoint import SuperPoint  # noqa: F401,E402
-from .targets import (compute_gt_matches, compute_gt_matches_of_image_pair, compute_match_loss,  # noqa: F401,E402
-                      run_matcher)
+from .targets import (compute_gt_matches_of_image_pair, compute_match_loss, gt_matches_for_tuple,  # noqa: F401,E402
+                      relative_pose)
 
-__all__ = ["SuperPoint", "compute_gt_matches", "compute_gt_matches_of_image_pair", "compute_match_loss", "run_matcher", "MultiViewMatcher", "SuperGlue", "estimate_relative_pose_w8pt", "run_weighted_8_point", "get_kpts",
+__all__ = ["SuperPoint", "compute_gt_matches_of_image_pair", "compute_match_loss", "gt_matches_for_tuple", "relative_pose",
+           "run_weighted_8_point_tuple", "MultiViewMatcher", "SuperGlue", "estimate_relative_pose_w8pt", "run_weighted_8_point", "get_kpts",
            "run_bundle_adjust_2_view", "normalize", "compute_rotation_error", "compute_translation_error_as_angle", "pose_errors", "pose_auc",
            "compute_pose_error", "log_optimal_transport", "extract_matches", "gemm_nt", "attention"]

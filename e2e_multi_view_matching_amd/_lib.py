@@ -66,6 +66,15 @@ SIGNATURES = {
     "e2emv_w8pt": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                            c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                            c_void_p]),
+    "e2emv_w8pt_ragged": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                  c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+    "e2emv_w8pt_tuple": (c_int, [c_void_p, c_int, c_int, c_int, _PP, _PP, c_int, c_int, _PP, _PP, c_int, _PP, c_int, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e2emv_apply_mask": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e2emv_normalize_kpts": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "e2emv_relative_pose": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e2emv_pose_error_means": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_pose_errors": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_ba_2view": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "e2emv_gt_matches": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -87,6 +96,7 @@ SIGNATURES = {
                               c_int64, c_float, c_int, c_void_p]),
     "e2emv_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "e2emv_set_precision": (c_int, [c_void_p, c_int]),
+    "e2emv_get_precision": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "e2emv_gemm_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "e2emv_attention_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                        c_void_p]),
@@ -97,7 +107,15 @@ SIGNATURES = {
 
 _lib = None
 _lock = threading.Lock()
+_ctx_lock = threading.Lock()
 _contexts = {}
+_tokens = iter(range(1, 1 << 62))
+
+
+def new_owner_token():
+    """Process-unique id of a module instance (id() values are re-used after garbage collection)."""
+    with _lock:
+        return next(_tokens)
 
 
 class E2EMVError(RuntimeError):
@@ -137,6 +155,27 @@ class Context:
             raise E2EMVError(rc, f"cannot create a context on device {device}: no usable MI355X (gfx950) - "
                                  "the HIP path has no CPU fallback")
         self.h = h
+        # The library keeps ONE matcher weight set and ONE SuperPoint weight set per context.  `weights_owner` /
+        # `sp_weights_owner` name the module instance + parameter fingerprint they currently hold, so that two models
+        # alternating on one device (checkpoint comparison, EMA copy) re-push instead of running on each other's weights.
+        self.weights_owner = None
+        self.sp_weights_owner = None
+        self.default_precision = self.precision()  # E2EMV_PRECISION at creation time (else f32)
+        self.forced_precision = None               # set_precision(): explicit process-wide override for models with
+        #                                            config["mfma_precision"] = None
+
+    def precision(self):
+        v = c_int(0)
+        self.check(self.lib.e2emv_get_precision(self.h, ctypes.byref(v)))
+        return int(v.value)
+
+    def set_precision(self, precision):
+        """Arithmetic of the dense GNN contractions for every model on this device that does not pin its own
+        (``config["mfma_precision"]``): PRECISION_F32, PRECISION_BF16X3, "f32", "bf16x3", or None = library default."""
+        if isinstance(precision, str):
+            precision = {"f32": PRECISION_F32, "bf16x3": PRECISION_BF16X3}[precision]
+        self.forced_precision = precision
+        self.call("e2emv_set_precision", self.default_precision if precision is None else precision)
 
     def check(self, rc):
         if rc != OK:
@@ -159,12 +198,10 @@ def context(device=None):
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
     if isinstance(device, torch.device):
         device = device.index if device.index is not None else torch.cuda.current_device()
-    with _lock:
+    with _ctx_lock:  # creation under a lock: two threads asking for the same device share one context
         ctx = _contexts.get(device)
-    if ctx is None:
-        ctx = Context(device)
-        with _lock:
-            _contexts[device] = ctx
+        if ctx is None:
+            ctx = _contexts[device] = Context(device)
     return ctx
 
 

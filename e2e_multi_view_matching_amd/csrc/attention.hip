@@ -310,6 +310,7 @@ int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, in
 extern "C" int e2emv_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv,
                                int cross, float* d_out, void* stream) {
     if (!ctx || !d_qkv || !d_out) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     e2emv::prof_begin(ctx, e2emv::PS_ATTN, (hipStream_t)stream);
     if (T < 1 || T > E2EMV_MAX_TUPLE) return E2EMV_EINVAL;
     int nv[E2EMV_MAX_TUPLE];

@@ -337,6 +337,7 @@ using namespace e2emv;
 extern "C" int e2emv_ba_2view(e2emv_ctx* ctx, int B, int N, const float* d_kpts0n, const float* d_kpts1n, const float* d_conf,
                               const float* d_T_init, int n_iterations, float* d_T_out, uint8_t* d_valid, void* stream) {
     if (!ctx || !d_kpts0n || !d_kpts1n || !d_conf || !d_T_init || !d_T_out || !d_valid) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (B <= 0 || N <= 0 || n_iterations < 0) return set_err(ctx, E2EMV_ESHAPE, "ba_2view: B=%d N=%d iterations=%d", B, N, n_iterations);
     hipStream_t s = (hipStream_t)stream;
     int rc = ws_reserve(ctx, (size_t)B * N * 3 * sizeof(double) + 256);

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -96,6 +97,13 @@ struct e2emv_ctx {
     // workspace arena
     char* d_ws = nullptr;
     size_t ws_bytes = 0;
+    // One call at a time per context: every compute entry point holds `mu` while it carves the shared workspace and
+    // enqueues its kernels (Python threads / several torch streams on one device would otherwise interleave inside the
+    // arena).  Work of consecutive calls is ordered by the stream; when the caller switches streams the previous one is
+    // drained first, because the arena contents of the earlier call may still be in use there.
+    std::recursive_mutex mu;
+    hipStream_t last_stream = nullptr;
+    bool have_last_stream = false;
     // profiling
     bool prof = false;
     std::vector<e2emv::ProfEvent> prof_events;
@@ -122,6 +130,20 @@ int set_err(e2emv_ctx* ctx, int code, const char* fmt, ...);
         if (_e != hipSuccess)                                                                     \
             return e2emv::set_err(ctx, E2EMV_EHIP, "launch of %s failed: %s", what, hipGetErrorString(_e)); \
     } while (0)
+
+// RAII guard of a compute entry point: serialises calls on the context and orders the shared workspace across streams.
+struct CallGuard {
+    std::unique_lock<std::recursive_mutex> lk;
+    CallGuard(e2emv_ctx* ctx, void* stream) : lk(ctx->mu) {
+        hipStream_t s = (hipStream_t)stream;
+        (void)hipSetDevice(ctx->device);
+        if (ctx->have_last_stream && ctx->last_stream != s) (void)hipStreamSynchronize(ctx->last_stream);
+        ctx->last_stream = s;
+        ctx->have_last_stream = true;
+    }
+};
+#define E2EMV_ENTER(ctx, stream) e2emv::CallGuard _call_guard(ctx, stream)
+#define E2EMV_LOCK(ctx) std::unique_lock<std::recursive_mutex> _call_lock((ctx)->mu)
 
 // workspace: makes ctx->d_ws at least `bytes` large, growing the arena (synchronising) when needed; each
 // top-level entry point carves it with 256-byte aligned offsets.

@@ -119,6 +119,7 @@ const char* e2emv_last_error(const e2emv_ctx* ctx) { return ctx ? ctx->err.c_str
 
 int e2emv_malloc(e2emv_ctx* ctx, void** d_ptr, size_t bytes) {
     if (!ctx || !d_ptr) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
     (void)hipSetDevice(ctx->device);
     if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) {
         (void)hipGetLastError();
@@ -129,30 +130,35 @@ int e2emv_malloc(e2emv_ctx* ctx, void** d_ptr, size_t bytes) {
 
 int e2emv_free(e2emv_ctx* ctx, void* d_ptr) {
     if (!ctx) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
     if (d_ptr) E2EMV_HIP(ctx, hipFree(d_ptr));
     return E2EMV_OK;
 }
 
 int e2emv_h2d(e2emv_ctx* ctx, void* d_dst, const void* src, size_t bytes, void* stream) {
     if (!ctx || (!d_dst && bytes) || (!src && bytes)) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     E2EMV_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return E2EMV_OK;
 }
 
 int e2emv_d2h(e2emv_ctx* ctx, void* dst, const void* d_src, size_t bytes, void* stream) {
     if (!ctx || (!dst && bytes) || (!d_src && bytes)) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     E2EMV_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return E2EMV_OK;
 }
 
 int e2emv_sync(e2emv_ctx* ctx, void* stream) {
     if (!ctx) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     E2EMV_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     return E2EMV_OK;
 }
 
 int e2emv_set_weight(e2emv_ctx* ctx, const char* key, const float* data, const int64_t* shape, int ndim) {
     if (!ctx || !key || !data || ndim < 0 || ndim > 4 || (ndim && !shape)) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
     std::string k(key);
     if (k.rfind("module.", 0) == 0) k = k.substr(7);
     HostTensor t;
@@ -257,6 +263,7 @@ int fold_bn(e2emv_ctx* ctx, const std::string& bn, int out, int in, std::vector<
 
 extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     if (!ctx || !m) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
     const int D = m->desc_dim, H = m->num_heads;
     if (D <= 0 || H <= 0 || D % H != 0 || D / H != 64 || D % 64 != 0)
         return set_err(ctx, E2EMV_ESHAPE, "descriptor_dim %d / num_heads %d: head dim must be 64", D, H);
@@ -435,6 +442,7 @@ extern "C" {
 
 int e2emv_set_precision(e2emv_ctx* ctx, int precision) {
     if (!ctx) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
     if (precision != E2EMV_PRECISION_F32 && precision != E2EMV_PRECISION_BF16X3)
         return set_err(ctx, E2EMV_EINVAL, "unknown precision %d", precision);
     if (precision == E2EMV_PRECISION_BF16X3 && !ctx->fuse_merge)
@@ -443,14 +451,23 @@ int e2emv_set_precision(e2emv_ctx* ctx, int precision) {
     return E2EMV_OK;
 }
 
+int e2emv_get_precision(e2emv_ctx* ctx, int* precision) {
+    if (!ctx || !precision) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
+    *precision = ctx->precision;
+    return E2EMV_OK;
+}
+
 int e2emv_profile(e2emv_ctx* ctx, int enable) {
     if (!ctx) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
     ctx->prof = enable != 0;
     return E2EMV_OK;
 }
 
 int e2emv_profile_read(e2emv_ctx* ctx, float* ms, int64_t* launches, int n_slots, int reset) {
     if (!ctx) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
     E2EMV_HIP(ctx, hipDeviceSynchronize());
     for (auto& pe : ctx->prof_events) {
         float t = 0.f;

@@ -384,6 +384,7 @@ extern "C" int e2emv_matcher_forward(e2emv_ctx* ctx, const e2emv_forward_desc* f
                                      int64_t* const* d_matches0, int64_t* const* d_matches1, float* const* d_mscores0,
                                      float* const* d_mscores1, float* const* d_conf, void* stream) {
     if (!ctx || !fd || !d_kpts || !d_kscores || !d_desc) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (!ctx->committed) return set_err(ctx, E2EMV_ESTATE, "matcher_forward: weights not committed");
     const int B = fd->batch, T = fd->tuple_size;
     if (B <= 0 || T < 2 || T > E2EMV_MAX_TUPLE) return set_err(ctx, E2EMV_ESHAPE, "matcher_forward: batch=%d tuple_size=%d", B, T);

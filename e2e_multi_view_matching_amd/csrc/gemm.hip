@@ -458,6 +458,7 @@ extern "C" int e2emv_gemm_nt(e2emv_ctx* ctx, int batch, int M, int Nout, int K, 
                              int64_t strideR, float* d_C, int64_t ldc, int64_t strideC, float scale, int flags,
                              void* stream) {
     if (!ctx || !d_A || !d_W || !d_C) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     e2emv::GemmArgs a;
     a.batch = batch; a.M = M; a.N = Nout; a.K = K; a.K1 = K1;
     a.A = d_A; a.lda = lda; a.sA = strideA;

@@ -247,6 +247,7 @@ extern "C" int e2emv_gt_matches(e2emv_ctx* ctx, int B, int N, const float* d_kpt
                                 float* d_weights, void* stream) {
     if (!ctx || !d_kpts0 || !d_kpts1 || !d_K0 || !d_K1 || !d_T0to1 || !d_depth0 || !d_depth1 || !d_indices || !d_weights)
         return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (B <= 0 || N <= 0 || H <= 0 || W <= 0) return set_err(ctx, E2EMV_ESHAPE, "gt_matches: B=%d N=%d H=%d W=%d", B, N, H, W);
     hipStream_t s = (hipStream_t)stream;
     auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
@@ -278,6 +279,7 @@ extern "C" int e2emv_gt_matches(e2emv_ctx* ctx, int B, int N, const float* d_kpt
 extern "C" int e2emv_match_loss(e2emv_ctx* ctx, int B, int N, const float* d_logZ, const int64_t* d_indices,
                                 const float* d_weights, float* d_loss, void* stream) {
     if (!ctx || !d_logZ || !d_indices || !d_weights || !d_loss) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (B <= 0 || N <= 0) return set_err(ctx, E2EMV_ESHAPE, "match_loss: B=%d N=%d", B, N);
     hipStream_t s = (hipStream_t)stream;
     int rc = ws_reserve(ctx, (size_t)B * 8 + 256);

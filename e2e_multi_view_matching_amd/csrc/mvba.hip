@@ -564,6 +564,7 @@ extern "C" int e2emv_mv_bundle_adjust(e2emv_ctx* ctx, int n_cams, int fixed_cam,
                                       const int32_t* cam_idx, const int32_t* pt_idx, const double* obs_xy, const double* obs_w,
                                       double* cams, double* pts, int max_iterations, double* summary, void* stream) {
     if (!ctx) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (n_cams < 1 || n_cams > kMvMaxCams || n_pts < 0 || n_obs < 0 || !intr || !cams || (n_pts && !pts) ||
         (n_obs && (!cam_idx || !pt_idx || !obs_xy || !obs_w)))
         return set_err(ctx, E2EMV_EINVAL, "mv_bundle_adjust: bad argument (1 <= n_cams <= %d)", kMvMaxCams);
@@ -630,6 +631,7 @@ extern "C" int e2emv_mv_bundle_adjust(e2emv_ctx* ctx, int n_cams, int fixed_cam,
 
 extern "C" int e2emv_mv_bundle_adjust_files(e2emv_ctx* ctx, const char* in_csv, const char* out_csv, void* stream) {
     if (!ctx) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (!in_csv || !out_csv) return set_err(ctx, E2EMV_EINVAL, "mv_bundle_adjust_files: NULL path");
     std::ifstream file(in_csv);
     if (!file) return set_err(ctx, E2EMV_EINVAL, "mv_bundle_adjust_files: cannot open %s", in_csv);
@@ -686,6 +688,7 @@ extern "C" int e2emv_mv_bundle_adjust_files(e2emv_ctx* ctx, const char* in_csv, 
 extern "C" int e2emv_mv_triangulate(e2emv_ctx* ctx, int n, const double* P0, const double* P1, const double* x0, const double* x1,
                                     double* xyz, void* stream) {
     if (!ctx) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (n < 0 || !P0 || !P1 || (n && (!x0 || !x1 || !xyz))) return set_err(ctx, E2EMV_EINVAL, "mv_triangulate: bad argument");
     if (n == 0) return E2EMV_OK;
     hipStream_t s = (hipStream_t)stream;

@@ -71,6 +71,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 struct W8Params {
     int B, N, kdim, intr_batch;
+    const int* n_per;  // optional [B]: sample b uses its first n_per[b] <= N correspondences (rows stay N apart)
     const float* k0;
     const float* k1;
     const float* K0;
@@ -125,16 +126,21 @@ __global__ __launch_bounds__(256) void w8pt_fundamental(W8Params p) {
     __shared__ double sred[4 * 48];
     __shared__ double sstat[16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = p.N;
+    const int N = p.n_per ? p.n_per[b] : p.N;  // correspondences of this sample
+    const int ldN = p.N;                        // row stride of every per-correspondence buffer
     const float* K0 = p.K0 + (p.intr_batch == 1 ? 0 : (int64_t)b * p.kdim * p.kdim);
     const float* K1 = p.K1 + (p.intr_batch == 1 ? 0 : (int64_t)b * p.kdim * p.kdim);
     const float fx0 = K0[0], fy0 = K0[p.kdim + 1], cx0 = K0[2], cy0 = K0[p.kdim + 2];
     const float fx1 = K1[0], fy1 = K1[p.kdim + 1], cx1 = K1[2], cy1 = K1[p.kdim + 2];
-    const float* k0 = p.k0 + (int64_t)b * N * 2;
-    const float* k1 = p.k1 + (int64_t)b * N * 2;
-    const float* cf = p.conf + (int64_t)b * N;
-    float* k0n = p.k0n + (int64_t)b * N * 2;
-    float* k1n = p.k1n + (int64_t)b * N * 2;
+    const float* k0 = p.k0 + (int64_t)b * ldN * 2;
+    const float* k1 = p.k1 + (int64_t)b * ldN * 2;
+    const float* cf = p.conf + (int64_t)b * ldN;
+    float* k0n = p.k0n + (int64_t)b * ldN * 2;
+    float* k1n = p.k1n + (int64_t)b * ldN * 2;
+    for (int i = N + tid; i < ldN; i += 256) {  // rows beyond this sample's count: defined, weightless
+        k0n[2 * i] = 0.f; k0n[2 * i + 1] = 0.f; k1n[2 * i] = 0.f; k1n[2 * i + 1] = 0.f;
+        p.conf_n[(int64_t)b * ldN + i] = 0.f;
+    }
 
     // pass 1: intrinsics normalisation (fp32 like the reference), sums for Hartley + weights
     double acc[5] = {0, 0, 0, 0, 0};  // sum x0,y0,x1,y1,conf
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256) void w8pt_fundamental(W8Params p) {
     for (int j = 0; j < 45; ++j) g[j] = 0.0;
     for (int i = tid; i < N; i += 256) {
         const float wn = cf[i] / wsum;
-        p.conf_n[(int64_t)b * N + i] = wn;
+        p.conf_n[(int64_t)b * ldN + i] = wn;
         const double w = wn;
         const double x1 = s0 * ((double)k0n[2 * i] - mx0), y1 = s0 * ((double)k0n[2 * i + 1] - my0);
         const double x2 = s1 * ((double)k1n[2 * i] - mx1), y2 = s1 * ((double)k1n[2 * i + 1] - my1);
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(256) void w8pt_triangulate(W8Params p) {
     if (threadIdx.x < 12) sRt[threadIdx.x] = p.cands[(int64_t)b * 48 + c * 12 + threadIdx.x];
     __syncthreads();
     bool ok = false;
-    if (i < p.N) {
+    if (i < (p.n_per ? p.n_per[b] : p.N)) {
         const float* a = p.k0n + ((int64_t)b * p.N + i) * 2;
         const float* q = p.k1n + ((int64_t)b * p.N + i) * 2;
         double d0, d1;
@@ -393,6 +399,11 @@ __global__ __launch_bounds__(256) void w8pt_select(W8Params p) {
         if (!fin && p.status) p.status[b] |= 2;
     }
     if (i >= p.N) return;
+    if (p.n_per && i >= p.n_per[b]) {  // padding row of a ragged batch
+        p.posdepth[(int64_t)b * p.N + i] = 0;
+        if (p.determine_inliers) p.inliers[(int64_t)b * p.N + i] = 0;
+        return;
+    }
     bool pos;
     if (sel >= 0) {
         pos = p.pd_c[((int64_t)b * 4 + sel) * p.N + i] != 0;
@@ -454,6 +465,128 @@ __global__ void pose_errors_kernel(int B, const float* T, const float* Tg, float
     tr[b] = e;
 }
 
+
+// ---- all pairs of a tuple in ONE solve: get_kpts of every pair (i < j) into pair-major batches ----
+struct TupleGatherParams {
+    int B, T, N, kdim, intr_batch;
+    const float* kpts[E2EMV_MAX_TUPLE];      // [B][N][2]
+    const float* intr[E2EMV_MAX_TUPLE];      // [intr_batch][kdim][kdim]
+    const int64_t* matches[kMaxGroups];      // pair (i, j): matches of image i in image j, [B][N]
+    const float* conf[kMaxGroups];           // [B][N]
+    const float* Tgt[kMaxGroups];            // [B][4][4] or null
+    float* k0;                               // [P*B][N][2]
+    float* k1g;                              // [P*B][N][2]
+    float* cf;                               // [P*B][N]
+    float* K0;                               // [P*B][kdim][kdim]
+    float* K1;
+    float* Tg;                               // [P*B][16] (choose_closest) or null
+};
+
+// grid (ceil(N/256), B, P); pair index q enumerates (i, j) with j outer, i inner (the reference's loop order)
+__global__ __launch_bounds__(256) void tuple_gather_kernel(TupleGatherParams p) {
+    const int b = blockIdx.y, q = blockIdx.z, n = blockIdx.x * 256 + threadIdx.x;
+    int i = 0, j = 1;
+    for (int c = 0; c < q; ++c) {
+        if (++i == j) { i = 0; ++j; }
+    }
+    const int64_t ob = (int64_t)q * p.B + b;
+    if (blockIdx.x == 0) {
+        const int kk = p.kdim * p.kdim;
+        const int64_t ib = p.intr_batch == 1 ? 0 : (int64_t)b * kk;
+        if ((int)threadIdx.x < kk) {
+            p.K0[ob * kk + threadIdx.x] = p.intr[i][ib + threadIdx.x];
+            p.K1[ob * kk + threadIdx.x] = p.intr[j][ib + threadIdx.x];
+        }
+        if (p.Tg && threadIdx.x < 16) p.Tg[ob * 16 + threadIdx.x] = p.Tgt[q][(int64_t)b * 16 + threadIdx.x];
+    }
+    if (n >= p.N) return;
+    const int64_t src = (int64_t)b * p.N + n, dst = ob * p.N + n;
+    int64_t m = p.matches[q][src];
+    const bool valid = m >= 0;
+    if (m < 0) m += p.N;  // python negative index: -1 -> last keypoint (its weight is 0)
+    m = m < 0 ? 0 : (m >= p.N ? p.N - 1 : m);
+    p.k0[dst * 2] = p.kpts[i][src * 2];
+    p.k0[dst * 2 + 1] = p.kpts[i][src * 2 + 1];
+    p.k1g[dst * 2] = p.kpts[j][((int64_t)b * p.N + m) * 2];
+    p.k1g[dst * 2 + 1] = p.kpts[j][((int64_t)b * p.N + m) * 2 + 1];
+    p.cf[dst] = valid ? p.conf[q][src] : 0.f;
+}
+
+// normalize (estimate_relative_pose.py:9-14): pixel -> camera coordinates, fp32 like the reference
+__global__ void normalize_kpts_kernel(int N, int kdim, int intr_batch, const float* kpts, const float* intr, float* out) {
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float* K = intr + (intr_batch == 1 ? 0 : (int64_t)b * kdim * kdim);
+    const int64_t o = ((int64_t)b * N + n) * 2;
+    out[o] = (kpts[o] - K[2]) / K[0];
+    out[o + 1] = (kpts[o + 1] - K[kdim + 2]) / K[kdim + 1];
+}
+
+// means of the two angle errors: rotation over all B entries, translation over the entries whose norm product
+// exceeds 1e-6 (compute_pose_error.py:12,22; an empty selection gives NaN like torch's mean of nothing)
+__global__ __launch_bounds__(64) void pose_error_means_kernel(int B, const float* rot, const float* tr, const uint8_t* valid,
+                                                              float* out2) {
+    float sr = 0.f, st = 0.f, nv = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) {
+        sr += rot[b];
+        if (valid[b]) { st += tr[b]; nv += 1.f; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sr += __shfl_xor(sr, o);
+        st += __shfl_xor(st, o);
+        nv += __shfl_xor(nv, o);
+    }
+    if (threadIdx.x == 0) {
+        out2[0] = sr / (float)B;
+        out2[1] = st / nv;  // 0 / 0 = NaN
+    }
+}
+
+// T_a_to_b = inv(pose_b) @ pose_a for general 4x4 matrices (helpers.py:219, 254): Gauss-Jordan with partial pivoting in
+// fp64, rounded once to fp32
+__global__ void relative_pose_kernel(int B, const float* pose_a, const float* pose_b, float* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double M[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            M[r][c] = pose_b[(int64_t)b * 16 + r * 4 + c];
+            M[r][4 + c] = pose_a[(int64_t)b * 16 + r * 4 + c];
+        }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r)
+            if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+        if (piv != c)
+            for (int k = 0; k < 8; ++k) { const double t = M[c][k]; M[c][k] = M[piv][k]; M[piv][k] = t; }
+        const double d = 1.0 / M[c][c];
+        for (int k = 0; k < 8; ++k) M[c][k] *= d;
+        for (int r = 0; r < 4; ++r)
+            if (r != c) {
+                const double f = M[r][c];
+                for (int k = 0; k < 8; ++k) M[r][k] -= f * M[c][k];
+            }
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) out[(int64_t)b * 16 + r * 4 + c] = (float)M[r][4 + c];
+}
+
+__global__ void apply_mask_kernel(int64_t n, const float* x, const uint8_t* mask, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = mask[i] ? x[i] : 0.f;
+}
+
+__global__ void pose_error_valid_kernel(int B, const float* T, const float* Tg, uint8_t* valid) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* A = T + (int64_t)b * 16;
+    const float* G = Tg + (int64_t)b * 16;
+    const float n0 = sqrtf(A[3] * A[3] + A[7] * A[7] + A[11] * A[11]);
+    const float n1 = sqrtf(G[3] * G[3] + G[7] * G[7] + G[11] * G[11]);
+    valid[b] = n0 * n1 > 1e-6f ? 1 : 0;
+}
+
 }  // namespace e2emv
 
 using namespace e2emv;
@@ -461,6 +594,7 @@ using namespace e2emv;
 extern "C" int e2emv_gather_matched(e2emv_ctx* ctx, int B, int N0, int N1, const float* d_kpts1, const int64_t* d_matches,
                                     const float* d_conf, float* d_kpts1_g, float* d_conf_out, void* stream) {
     if (!ctx || !d_kpts1 || !d_matches || !d_conf || !d_kpts1_g || !d_conf_out) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (B <= 0 || N0 <= 0 || N1 <= 0) return set_err(ctx, E2EMV_ESHAPE, "gather_matched: empty problem");
     hipStream_t s = (hipStream_t)stream;
     prof_begin(ctx, PS_W8PT, s);
@@ -471,31 +605,18 @@ extern "C" int e2emv_gather_matched(e2emv_ctx* ctx, int B, int N0, int N1, const
     return E2EMV_OK;
 }
 
-extern "C" int e2emv_w8pt(e2emv_ctx* ctx, int B, int N, const float* d_kpts0, const float* d_kpts1, const float* d_intr0,
-                          const float* d_intr1, int kdim, int intr_batch, const float* d_conf, int choose_closest,
-                          const float* d_T_gt, int determine_inliers, float* d_T, float* d_kpts0n, float* d_kpts1n,
-                          float* d_conf_n, uint8_t* d_inliers, uint8_t* d_posdepth, float* d_F, int32_t* d_status,
-                          void* stream) {
-    if (!ctx || !d_kpts0 || !d_kpts1 || !d_intr0 || !d_intr1 || !d_conf || !d_T || !d_kpts0n || !d_kpts1n || !d_conf_n ||
-        !d_posdepth)
-        return E2EMV_EINVAL;
-    if (choose_closest && !d_T_gt) return set_err(ctx, E2EMV_EINVAL, "w8pt: choose_closest needs T_021");
-    if (determine_inliers && !d_inliers) return set_err(ctx, E2EMV_EINVAL, "w8pt: determine_inliers needs an output buffer");
-    if (B <= 0) return set_err(ctx, E2EMV_ESHAPE, "w8pt: empty batch");
-    if (N < 8) return set_err(ctx, E2EMV_ESHAPE, "w8pt: fewer than 8 correspondences (N=%d)", N);
-    if (kdim != 3 && kdim != 4) return set_err(ctx, E2EMV_ESHAPE, "w8pt: intrinsics must be 3x3 or 4x4");
-    hipStream_t s = (hipStream_t)stream;
+static int run_w8pt(e2emv_ctx* ctx, char* ws, int B, int N, const float* d_kpts0, const float* d_kpts1, const float* d_intr0,
+                    const float* d_intr1, int kdim, int intr_batch, const float* d_conf, int choose_closest, const float* d_T_gt,
+                    int determine_inliers, float* d_T, float* d_kpts0n, float* d_kpts1n, float* d_conf_n, uint8_t* d_inliers,
+                    uint8_t* d_posdepth, float* d_F, int32_t* d_status, hipStream_t s, const int32_t* d_n_per = nullptr) {
     auto al = [](size_t n) { return (n + 255) & ~size_t(255); };
-    size_t need = al((size_t)B * 9 * 8) + al((size_t)B * 48 * 8) + 2 * al((size_t)B * 4 * 4) + al((size_t)B * 4 * N);
-    int rc = ws_reserve(ctx, need);
-    if (rc) return rc;
     W8Params p{};
-    p.B = B; p.N = N; p.kdim = kdim; p.intr_batch = intr_batch;
+    p.B = B; p.N = N; p.kdim = kdim; p.intr_batch = intr_batch; p.n_per = d_n_per;
     p.k0 = d_kpts0; p.k1 = d_kpts1; p.K0 = d_intr0; p.K1 = d_intr1; p.conf = d_conf;
     p.choose_closest = choose_closest; p.Tgt = d_T_gt; p.determine_inliers = determine_inliers;
     p.T = d_T; p.k0n = d_kpts0n; p.k1n = d_kpts1n; p.conf_n = d_conf_n; p.inliers = d_inliers; p.posdepth = d_posdepth;
     p.F = d_F; p.status = d_status;
-    char* w = ctx->d_ws;
+    char* w = ws;
     p.E = (double*)w; w += al((size_t)B * 9 * 8);
     p.cands = (double*)w; w += al((size_t)B * 48 * 8);
     p.sel = (int*)w; w += al((size_t)B * 4 * 4);
@@ -510,9 +631,158 @@ extern "C" int e2emv_w8pt(e2emv_ctx* ctx, int B, int N, const float* d_kpts0, co
     return E2EMV_OK;
 }
 
+static size_t w8pt_ws_bytes(int B, int N) {
+    auto al = [](size_t n) { return (n + 255) & ~size_t(255); };
+    return al((size_t)B * 9 * 8) + al((size_t)B * 48 * 8) + 2 * al((size_t)B * 4 * 4) + al((size_t)B * 4 * N);
+}
+
+extern "C" int e2emv_w8pt(e2emv_ctx* ctx, int B, int N, const float* d_kpts0, const float* d_kpts1, const float* d_intr0,
+                          const float* d_intr1, int kdim, int intr_batch, const float* d_conf, int choose_closest,
+                          const float* d_T_gt, int determine_inliers, float* d_T, float* d_kpts0n, float* d_kpts1n,
+                          float* d_conf_n, uint8_t* d_inliers, uint8_t* d_posdepth, float* d_F, int32_t* d_status,
+                          void* stream) {
+    if (!ctx || !d_kpts0 || !d_kpts1 || !d_intr0 || !d_intr1 || !d_conf || !d_T || !d_kpts0n || !d_kpts1n || !d_conf_n ||
+        !d_posdepth)
+        return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    if (choose_closest && !d_T_gt) return set_err(ctx, E2EMV_EINVAL, "w8pt: choose_closest needs T_021");
+    if (determine_inliers && !d_inliers) return set_err(ctx, E2EMV_EINVAL, "w8pt: determine_inliers needs an output buffer");
+    if (B <= 0) return set_err(ctx, E2EMV_ESHAPE, "w8pt: empty batch");
+    if (N < 8) return set_err(ctx, E2EMV_ESHAPE, "w8pt: fewer than 8 correspondences (N=%d)", N);
+    if (kdim != 3 && kdim != 4) return set_err(ctx, E2EMV_ESHAPE, "w8pt: intrinsics must be 3x3 or 4x4");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ws_reserve(ctx, w8pt_ws_bytes(B, N));
+    if (rc) return rc;
+    return run_w8pt(ctx, ctx->d_ws, B, N, d_kpts0, d_kpts1, d_intr0, d_intr1, kdim, intr_batch, d_conf, choose_closest, d_T_gt,
+                    determine_inliers, d_T, d_kpts0n, d_kpts1n, d_conf_n, d_inliers, d_posdepth, d_F, d_status, s);
+}
+
+extern "C" int e2emv_w8pt_ragged(e2emv_ctx* ctx, int B, int N, const int32_t* d_n_per, const float* d_kpts0, const float* d_kpts1,
+                                 const float* d_intr0, const float* d_intr1, int kdim, int intr_batch, const float* d_conf,
+                                 int choose_closest, const float* d_T_gt, int determine_inliers, float* d_T, float* d_kpts0n,
+                                 float* d_kpts1n, float* d_conf_n, uint8_t* d_inliers, uint8_t* d_posdepth, float* d_F,
+                                 int32_t* d_status, void* stream) {
+    if (!ctx || !d_n_per || !d_kpts0 || !d_kpts1 || !d_intr0 || !d_intr1 || !d_conf || !d_T || !d_kpts0n || !d_kpts1n ||
+        !d_conf_n || !d_posdepth)
+        return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    if (choose_closest && !d_T_gt) return set_err(ctx, E2EMV_EINVAL, "w8pt_ragged: choose_closest needs T_021");
+    if (determine_inliers && !d_inliers) return set_err(ctx, E2EMV_EINVAL, "w8pt_ragged: determine_inliers needs an output buffer");
+    if (B <= 0) return set_err(ctx, E2EMV_ESHAPE, "w8pt_ragged: empty batch");
+    if (N < 8) return set_err(ctx, E2EMV_ESHAPE, "w8pt_ragged: fewer than 8 correspondences (N=%d)", N);
+    if (kdim != 3 && kdim != 4) return set_err(ctx, E2EMV_ESHAPE, "w8pt_ragged: intrinsics must be 3x3 or 4x4");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ws_reserve(ctx, w8pt_ws_bytes(B, N));
+    if (rc) return rc;
+    return run_w8pt(ctx, ctx->d_ws, B, N, d_kpts0, d_kpts1, d_intr0, d_intr1, kdim, intr_batch, d_conf, choose_closest, d_T_gt,
+                    determine_inliers, d_T, d_kpts0n, d_kpts1n, d_conf_n, d_inliers, d_posdepth, d_F, d_status, s, d_n_per);
+}
+
+extern "C" int e2emv_w8pt_tuple(e2emv_ctx* ctx, int B, int T, int N, const float* const* d_kpts, const float* const* d_intr,
+                                int kdim, int intr_batch, const int64_t* const* d_matches, const float* const* d_conf,
+                                int choose_closest, const float* const* d_T_gt, int determine_inliers, float* d_T,
+                                float* d_kpts0n, float* d_kpts1n, float* d_conf_n, uint8_t* d_inliers, uint8_t* d_posdepth,
+                                float* d_F, int32_t* d_status, void* stream) {
+    if (!ctx || !d_kpts || !d_intr || !d_matches || !d_conf || !d_T || !d_kpts0n || !d_kpts1n || !d_conf_n || !d_posdepth)
+        return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    if (B <= 0 || T < 2 || T > E2EMV_MAX_TUPLE) return set_err(ctx, E2EMV_ESHAPE, "w8pt_tuple: batch=%d tuple_size=%d", B, T);
+    if (N < 8) return set_err(ctx, E2EMV_ESHAPE, "w8pt_tuple: fewer than 8 correspondences (N=%d)", N);
+    if (kdim != 3 && kdim != 4) return set_err(ctx, E2EMV_ESHAPE, "w8pt_tuple: intrinsics must be 3x3 or 4x4");
+    if (intr_batch != 1 && intr_batch != B) return set_err(ctx, E2EMV_ESHAPE, "w8pt_tuple: intr_batch must be 1 or B");
+    if (choose_closest && !d_T_gt) return set_err(ctx, E2EMV_EINVAL, "w8pt_tuple: choose_closest needs T_021 per pair");
+    if (determine_inliers && !d_inliers) return set_err(ctx, E2EMV_EINVAL, "w8pt_tuple: determine_inliers needs an output buffer");
+    const int P = T * (T - 1) / 2;
+    const int PB = P * B;
+    TupleGatherParams g{};
+    g.B = B; g.T = T; g.N = N; g.kdim = kdim; g.intr_batch = intr_batch;
+    for (int t = 0; t < T; ++t) {
+        if (!d_kpts[t] || !d_intr[t]) return set_err(ctx, E2EMV_EINVAL, "w8pt_tuple: null input for image %d", t);
+        g.kpts[t] = d_kpts[t];
+        g.intr[t] = d_intr[t];
+    }
+    for (int q = 0; q < P; ++q) {
+        if (!d_matches[q] || !d_conf[q] || (choose_closest && !d_T_gt[q]))
+            return set_err(ctx, E2EMV_EINVAL, "w8pt_tuple: null input for pair %d", q);
+        g.matches[q] = d_matches[q];
+        g.conf[q] = d_conf[q];
+        g.Tgt[q] = choose_closest ? d_T_gt[q] : nullptr;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    auto al = [](size_t n) { return (n + 255) & ~size_t(255); };
+    const size_t sz_k = al((size_t)PB * N * 2 * 4), sz_c = al((size_t)PB * N * 4), sz_K = al((size_t)PB * kdim * kdim * 4),
+                 sz_T = al((size_t)PB * 16 * 4);
+    int rc = ws_reserve(ctx, 2 * sz_k + sz_c + 2 * sz_K + sz_T + w8pt_ws_bytes(PB, N));
+    if (rc) return rc;
+    char* w = ctx->d_ws;
+    g.k0 = (float*)w; w += sz_k;
+    g.k1g = (float*)w; w += sz_k;
+    g.cf = (float*)w; w += sz_c;
+    g.K0 = (float*)w; w += sz_K;
+    g.K1 = (float*)w; w += sz_K;
+    g.Tg = choose_closest ? (float*)w : nullptr; w += sz_T;
+    prof_begin(ctx, PS_W8PT, s);
+    hipLaunchKernelGGL(tuple_gather_kernel, dim3((N + 255) / 256, B, P), dim3(256), 0, s, g);
+    prof_end(ctx, s);
+    E2EMV_CHECK_LAUNCH(ctx, "tuple_gather_kernel");
+    return run_w8pt(ctx, w, PB, N, g.k0, g.k1g, g.K0, g.K1, kdim, PB, g.cf, choose_closest, g.Tg, determine_inliers, d_T,
+                    d_kpts0n, d_kpts1n, d_conf_n, d_inliers, d_posdepth, d_F, d_status, s);
+}
+
+extern "C" int e2emv_normalize_kpts(e2emv_ctx* ctx, int B, int N, const float* d_kpts, const float* d_intr, int kdim,
+                                    int intr_batch, float* d_out, void* stream) {
+    if (!ctx || !d_kpts || !d_intr || !d_out) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    if (B <= 0 || N <= 0) return set_err(ctx, E2EMV_ESHAPE, "normalize_kpts: empty problem");
+    if ((kdim != 3 && kdim != 4) || (intr_batch != 1 && intr_batch != B))
+        return set_err(ctx, E2EMV_ESHAPE, "normalize_kpts: intrinsics must be [1|B] x 3x3 or 4x4");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(normalize_kpts_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, kdim, intr_batch, d_kpts, d_intr, d_out);
+    E2EMV_CHECK_LAUNCH(ctx, "normalize_kpts_kernel");
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_apply_mask(e2emv_ctx* ctx, int64_t n, const float* d_x, const uint8_t* d_mask, float* d_out, void* stream) {
+    if (!ctx || !d_x || !d_mask || !d_out) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    if (n <= 0) return set_err(ctx, E2EMV_ESHAPE, "apply_mask: empty input");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(apply_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, d_x, d_mask, d_out);
+    E2EMV_CHECK_LAUNCH(ctx, "apply_mask_kernel");
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_relative_pose(e2emv_ctx* ctx, int B, const float* d_pose_a, const float* d_pose_b, float* d_T_a2b,
+                                   void* stream) {
+    if (!ctx || !d_pose_a || !d_pose_b || !d_T_a2b) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    if (B <= 0) return set_err(ctx, E2EMV_ESHAPE, "relative_pose: empty batch");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(relative_pose_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, d_pose_a, d_pose_b, d_T_a2b);
+    E2EMV_CHECK_LAUNCH(ctx, "relative_pose_kernel");
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_pose_error_means(e2emv_ctx* ctx, int B, const float* d_T, const float* d_T_gt, float* d_rot_err,
+                                      float* d_transl_err, uint8_t* d_transl_valid, float* d_means2, void* stream) {
+    if (!ctx || !d_T || !d_T_gt || !d_rot_err || !d_transl_err || !d_transl_valid) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    if (B <= 0) return set_err(ctx, E2EMV_ESHAPE, "pose_error_means: empty batch");
+    hipStream_t s = (hipStream_t)stream;
+    prof_begin(ctx, PS_W8PT, s);
+    hipLaunchKernelGGL(pose_errors_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, d_T, d_T_gt, d_rot_err, d_transl_err);
+    hipLaunchKernelGGL(pose_error_valid_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, d_T, d_T_gt, d_transl_valid);
+    if (d_means2)
+        hipLaunchKernelGGL(pose_error_means_kernel, dim3(1), dim3(64), 0, s, B, d_rot_err, d_transl_err, d_transl_valid, d_means2);
+    prof_end(ctx, s);
+    E2EMV_CHECK_LAUNCH(ctx, "pose error kernels");
+    return E2EMV_OK;
+}
+
 extern "C" int e2emv_pose_errors(e2emv_ctx* ctx, int B, const float* d_T, const float* d_T_gt, float* d_rot_err,
                                  float* d_transl_err, void* stream) {
     if (!ctx || !d_T || !d_T_gt || !d_rot_err || !d_transl_err) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (B <= 0) return set_err(ctx, E2EMV_ESHAPE, "pose_errors: empty batch");
     hipStream_t s = (hipStream_t)stream;
     prof_begin(ctx, PS_W8PT, s);

@@ -573,6 +573,7 @@ using namespace e2emv;
 extern "C" int e2emv_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* d_scores, float bin_score, int iters,
                               float* d_logZ, void* stream) {
     if (!ctx || !d_scores || !d_logZ) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (B <= 0 || M <= 0 || N <= 0 || iters < 0) return set_err(ctx, E2EMV_ESHAPE, "sinkhorn: bad sizes");
     hipStream_t s = (hipStream_t)stream;
     const int ldS = round_up(N, 4);
@@ -600,6 +601,7 @@ extern "C" int e2emv_extract_matches(e2emv_ctx* ctx, int B, int M, int N, const 
                                      int64_t* d_matches0, int64_t* d_matches1, float* d_mscores0, float* d_mscores1,
                                      void* stream) {
     if (!ctx || !d_logZ) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (B <= 0 || M <= 0 || N <= 0) return set_err(ctx, E2EMV_ESHAPE, "extract_matches: bad sizes");
     if ((size_t)(2 * M + N) * 4 > 60000) return set_err(ctx, E2EMV_ESHAPE, "extract_matches: too many keypoints");
     hipStream_t s = (hipStream_t)stream;

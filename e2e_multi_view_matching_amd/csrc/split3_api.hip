@@ -49,6 +49,7 @@ using namespace e2emv;
 extern "C" int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const float* d_A, const float* d_W,
                                  const float* d_bias, float* d_C, int flags, void* stream) {
     if (!ctx || !d_A || !d_W || !d_C) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (M <= 0 || Nout <= 0 || K <= 0 || K % 32 || Nout % 4) return set_err(ctx, E2EMV_ESHAPE, "gemm_bf16x3: M=%d N=%d K=%d", M, Nout, K);
     hipStream_t s = (hipStream_t)stream;
     auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
@@ -79,6 +80,7 @@ extern "C" int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const f
 extern "C" int e2emv_attention_bf16x3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv,
                                       int cross, float* d_out, void* stream) {
     if (!ctx || !d_qkv || !d_out) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (B <= 0 || T <= 0 || n_rows <= 0) return set_err(ctx, E2EMV_ESHAPE, "attention_bf16x3: empty problem");
     hipStream_t s = (hipStream_t)stream;
     const int64_t rows = (int64_t)B * T * n_rows;

@@ -349,6 +349,7 @@ using namespace e2emv;
 // ---- weights --------------------------------------------------------------------------------------------------------------
 extern "C" int e2emv_superpoint_commit(e2emv_ctx* ctx) {
     if (!ctx) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
     size_t total = 0;
     for (int l = 0; l < 12; ++l) total += (size_t)kSpCout[l] * kSpCin[l] * kSpK[l] * kSpK[l] + ((kSpCout[l] + 3) & ~3);
     std::vector<float> host(total + 64, 0.f);
@@ -417,6 +418,7 @@ int sp_conv1x1(e2emv_ctx* ctx, int layer, const float* in, float* out, int64_t r
 extern "C" int e2emv_superpoint_forward(e2emv_ctx* ctx, const e2emv_superpoint_desc* d, const float* d_images, float* d_kpts, float* d_scores,
                                         float* d_desc, int32_t* d_count, float* d_score_map, void* stream) {
     if (!ctx) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
     if (!d || !d_images || !d_kpts || !d_scores || !d_desc || !d_count) return set_err(ctx, E2EMV_EINVAL, "superpoint_forward: NULL argument");
     if (!ctx->sp_committed) return set_err(ctx, E2EMV_ESTATE, "superpoint_forward: weights not committed (e2emv_superpoint_commit)");
     const int B = d->batch, H = d->height, W = d->width, K = d->max_keypoints, r = d->nms_radius;

@@ -100,7 +100,7 @@ class MultiViewMatcher(nn.Module):
         self.bin_score = nn.Parameter(torch.tensor(1.0))
         if self.config["conf_mlp"]:
             self.conf_mlp = _mlp([2 * D, D, 1])
-        self._pushed = {}  # device index -> weight fingerprint
+        self._token = _lib.new_owner_token()
 
     # ------------------------------------------------------------------ weights -> library
     def _fingerprint(self):
@@ -127,9 +127,11 @@ class MultiViewMatcher(nn.Module):
         return md
 
     def _push_weights(self, ctx):
-        fp = self._fingerprint()
-        if self._pushed.get(ctx.device) == fp:
+        # the context holds one weight set: re-push whenever another module (or other parameter values) own it
+        owner = (self._token, self._fingerprint())
+        if ctx.weights_owner == owner:
             return
+        ctx.weights_owner = None
         for k, v in self.state_dict().items():
             if not v.dtype.is_floating_point:
                 continue  # num_batches_tracked
@@ -138,7 +140,7 @@ class MultiViewMatcher(nn.Module):
             ctx.call("e2emv_set_weight", k.encode(), ctypes.c_void_p(h.data_ptr()), shape, h.dim())
         md = self._model_desc()
         ctx.call("e2emv_commit_weights", ctypes.byref(md))
-        self._pushed[ctx.device] = fp
+        ctx.weights_owner = owner
 
     # ------------------------------------------------------------------ forward
     @staticmethod
@@ -159,8 +161,15 @@ class MultiViewMatcher(nn.Module):
                                "the CPU oracle lives in oracle/ and is test infrastructure)")
         ctx = _lib.context(dev)
         self._push_weights(ctx)
-        if cfg.get("mfma_precision") is not None:
-            ctx.call("e2emv_set_precision", {"f32": _lib.PRECISION_F32, "bf16x3": _lib.PRECISION_BF16X3}[cfg["mfma_precision"]])
+        # the precision switch is context-global and sticky: resolve it on EVERY call (None = the context's explicit
+        # override, else the library default), so a model never inherits what the previous model selected
+        mode = cfg.get("mfma_precision")
+        if mode is None:
+            want = ctx.forced_precision if ctx.forced_precision is not None else ctx.default_precision
+        else:
+            want = {"f32": _lib.PRECISION_F32, "bf16x3": _lib.PRECISION_BF16X3}[mode]
+        if ctx.precision() != want:
+            ctx.call("e2emv_set_precision", want)
         kpts, scores, descs = [], [], []
         fd = _lib.ForwardDesc()
         for m in range(T):

@@ -40,3 +40,27 @@ def pair_errors_deg(rot_rad, transl_rad):
     er = np.rad2deg(np.asarray(rot_rad, dtype=np.float64))
     et = np.rad2deg(np.asarray(transl_rad, dtype=np.float64))
     return np.maximum(er, np.minimum(et, 180 - et))
+
+
+# ---- image-plane rotation helpers of upstream's ``models/utils.py`` (imported by ``eval_pairs.py:16`` for the ScanNet
+# in-plane rotations; host-side, numpy; restated from upstream's published semantics - the submodule is absent) ----
+_QUARTER_TURNS_DEG = (0.0, 270.0, 180.0, 90.0)  # rot = number of clockwise quarter turns of the image
+
+
+def rotate_pose_inplane(i_T_w, rot):
+    """World-to-camera pose after rotating the image by ``rot`` quarter turns about the optical axis."""
+    a = np.deg2rad(_QUARTER_TURNS_DEG[rot])
+    Rz = np.eye(4, dtype=np.float32)
+    Rz[0, 0], Rz[0, 1], Rz[1, 0], Rz[1, 1] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+    return Rz @ i_T_w
+
+
+def rotate_intrinsics(K, image_shape, rot):
+    """3x3 intrinsics after rotating the image by ``rot`` quarter turns; ``image_shape`` = shape AFTER the rotation."""
+    if not 0 <= rot <= 3:
+        raise AssertionError(rot)
+    h, w = image_shape[:2][::-1 if (rot % 2) else 1]
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    focal, centre = {1: ((fy, fx), (cy, w - 1 - cx)), 2: ((fx, fy), (w - 1 - cx, h - 1 - cy)),
+                     3: ((fy, fx), (h - 1 - cy, cx)), 0: ((fy, fx), (h - 1 - cy, cx))}[rot % 4]
+    return np.array([[focal[0], 0.0, centre[0]], [0.0, focal[1], centre[1]], [0.0, 0.0, 1.0]], dtype=K.dtype)

@@ -23,8 +23,7 @@ import torch
 from scipy.sparse.csgraph import minimum_spanning_tree
 
 from . import _lib
-from .metrics import compute_pose_error
-from .pose import estimate_relative_pose_w8pt, run_bundle_adjust_2_view
+from .pose import mask_confidence, run_bundle_adjust_2_view
 
 
 def _dev():
@@ -37,19 +36,53 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def estimate_relative_pose_w8pt_ba(intr0, intr1, mkpts0, mkpts1, conf):
-    """``estimate_relative_pose_w8pt_ba`` (bundle_adjust_io.py:12-23): numpy in, ``(success, R, t, inliers)`` out."""
+def relative_poses_w8pt_ba(problems, n_iterations=10):
+    """Relative pose of MANY image pairs with different numbers of matches in one device pass: ragged weighted 8-point
+    (``e2emv_w8pt_ragged``: every pair keeps its own Hartley statistics) -> confidences of negative-depth matches zeroed
+    -> two-view bundle adjustment (zero-weight padding rows do not enter it).  ``problems`` = list of
+    ``(intr0, intr1, mkpts0 [n,2], mkpts1 [n,2], conf [n,c])`` numpy tuples; returns one ``(success, R, t, inliers)`` per
+    problem with the meaning of the reference's ``estimate_relative_pose_w8pt_ba`` (bundle_adjust_io.py:12-23):
+    ``success`` is False below 8 matches."""
+    out = [(False, None, None, None)] * len(problems)
+    live = [q for q, pr in enumerate(problems) if pr[2].shape[0] >= 8]
+    if not live:
+        return out
     dev = _dev()
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).unsqueeze(0)  # noqa: E731
-    pred_T021, info = estimate_relative_pose_w8pt(t(mkpts0), t(mkpts1), t(intr0), t(intr1), t(conf), determine_inliers=True)
-    if pred_T021 is None:
-        return False, None, None, None
-    confidence = info["confidence"]
-    confidence[torch.logical_not(info["pos_depth_mask"]).reshape(confidence.shape)] = 0.
-    pred_T021_refine, valid_refine = run_bundle_adjust_2_view(info["kpts0_norm"], info["kpts1_norm"], confidence, pred_T021,
-                                                              n_iterations=10)
-    pred_T021[valid_refine] = pred_T021_refine
-    return True, pred_T021[0, :3, :3].cpu().numpy(), pred_T021[0, :3, 3].cpu().numpy(), info["inliers"].squeeze(0).cpu().numpy()
+    ctx = _lib.context(dev)
+    n_per = np.array([problems[q][2].shape[0] for q in live], np.int32)
+    Pn, Nmax = len(live), int(n_per.max())
+    kdim = problems[live[0]][0].shape[-1]
+    k0, k1 = np.zeros((Pn, Nmax, 2), np.float32), np.zeros((Pn, Nmax, 2), np.float32)
+    cf = np.zeros((Pn, Nmax), np.float32)
+    K0, K1 = np.zeros((Pn, kdim, kdim), np.float32), np.zeros((Pn, kdim, kdim), np.float32)
+    for r, q in enumerate(live):
+        intr0, intr1, m0, m1, conf = problems[q]
+        k0[r, :n_per[r]], k1[r, :n_per[r]] = m0, m1
+        cf[r, :n_per[r]] = np.asarray(conf).reshape(n_per[r], -1)[:, 0]
+        K0[r], K1[r] = intr0, intr1
+    up = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    d_n, d_k0, d_k1, d_cf, d_K0, d_K1 = up(n_per), up(k0), up(k1), up(cf), up(K0), up(K1)
+    T = torch.empty((Pn, 4, 4), dtype=torch.float32, device=dev)
+    k0n, k1n, cfn = torch.empty_like(d_k0), torch.empty_like(d_k1), torch.empty_like(d_cf)
+    inl = torch.empty((Pn, Nmax), dtype=torch.uint8, device=dev)
+    pos = torch.empty((Pn, Nmax), dtype=torch.uint8, device=dev)
+    status = torch.empty((Pn,), dtype=torch.int32, device=dev)
+    P = _lib.ptr
+    with torch.cuda.device(dev):
+        ctx.call("e2emv_w8pt_ragged", Pn, Nmax, P(d_n), P(d_k0), P(d_k1), P(d_K0), P(d_K1), kdim, Pn, P(d_cf), 0, P(None), 1, P(T),
+                 P(k0n), P(k1n), P(cfn), P(inl), P(pos), P(None), P(status), _lib.stream_ptr(dev))
+    refined, ok = run_bundle_adjust_2_view(k0n, k1n, mask_confidence(cfn, pos), T, n_iterations=n_iterations)
+    T[ok] = refined
+    T_h, inl_h = T.cpu().numpy(), inl.cpu().numpy().astype(bool)
+    for r, q in enumerate(live):
+        out[q] = (True, T_h[r, :3, :3], T_h[r, :3, 3], inl_h[r, :n_per[r]])
+    return out
+
+
+def estimate_relative_pose_w8pt_ba(intr0, intr1, mkpts0, mkpts1, conf):
+    """``estimate_relative_pose_w8pt_ba`` (bundle_adjust_io.py:12-23): numpy in, ``(success, R, t, inliers)`` out - the
+    one-pair form of ``relative_poses_w8pt_ba``."""
+    return relative_poses_w8pt_ba([(intr0, intr1, mkpts0, mkpts1, conf)])[0]
 
 
 def _pairs(n_images):
@@ -127,18 +160,18 @@ def initialize_bundle_adjust(n_images, data, result, file_path, conf_thresh=0., 
     pw = _collect_matches(n_images, data, result, conf_thresh)
     graph = np.zeros((n_images, n_images), dtype=int)
     rel = {}
-    for i, j in _pairs(n_images):
-        k0, k1 = _key("mkpts", str(i), i, j), _key("mkpts", str(j), i, j)
-        if k0 not in pw:
-            continue
-        ok, R, t, inl = estimate_relative_pose_w8pt_ba(pw["intr" + str(i)], pw["intr" + str(j)], pw[k0], pw[k1], pw[_key("conf", str(i), i, j)])
+    have = [(i, j) for i, j in _pairs(n_images) if _key("mkpts", str(i), i, j) in pw]
+    # all pairs of the tuple in one device pass (they differ in their number of matches)
+    solved = relative_poses_w8pt_ba([(pw["intr" + str(i)], pw["intr" + str(j)], pw[_key("mkpts", str(i), i, j)],
+                                      pw[_key("mkpts", str(j), i, j)], pw[_key("conf", str(i), i, j)]) for i, j in have])
+    for (i, j), (ok, R, t, inl) in zip(have, solved):
         # every match is kept for the bundle adjustment; the inlier count only weights the match graph (:111-113, :133)
         pw[_key("inlier_count", i, j)] = inl.sum() if ok else 0
         if ok:
             T = np.eye(4)
             T[:3, :3], T[:3, 3] = R, t
             pw[_key("rel_pose", i, j)] = rel[(i, j)] = T
-            graph[i, j] = len(pw[k0])
+            graph[i, j] = len(pw[_key("mkpts", str(i), i, j)])
 
     # maximum spanning tree = minimum spanning tree of (max - w + 1) on the existing edges (:135-138)
     has_edge = graph != 0
@@ -250,27 +283,46 @@ def bundle_adjust(n_cams, fixed_cam, intr, cam_idx, pt_idx, obs_xy, obs_w, cams,
     return cams, pts, dict(initial_cost=summary[0], final_cost=summary[1], iterations=int(summary[2]), termination=names[int(summary[3])])
 
 
-def eval_bundle_adjust(tuple_size, data, result, tmp_dir, pose_errors, verbose=False):
-    """``eval_bundle_adjust`` (eval_multi_view.py:21-68): the full multi-view back-end for one tuple; appends
-    max(err_t, err_R), err_t, err_R (degrees) of every image pair to ``pose_errors``."""
+def solve_tuple_poses(tuple_size, data, result, tmp_dir):
+    """Pairwise poses -> averaging -> weighted bundle adjustment for one tuple through the reference's four CSV files in
+    ``tmp_dir``; returns the refined world-to-camera extrinsics [tuple_size,4,4]."""
     os.makedirs(tmp_dir, exist_ok=True)
-    pair_wise_data = initialize_bundle_adjust(tuple_size, data, result, os.path.join(tmp_dir, "ba_init_in.csv"))
+    path = lambda name: os.path.join(tmp_dir, name)  # noqa: E731
+    pair_wise_data = initialize_bundle_adjust(tuple_size, data, result, path("ba_init_in.csv"))
     run_ba_initializer(tmp_dir)
-    extrinsics = np.array(read_bundle_adjust_result(os.path.join(tmp_dir, "ba_init_out.csv")))
-    write_bundle_adjust_problem(tuple_size, pair_wise_data, extrinsics, os.path.join(tmp_dir, "ba_in.csv"))
+    start = np.array(read_bundle_adjust_result(path("ba_init_out.csv")))
+    write_bundle_adjust_problem(tuple_size, pair_wise_data, start, path("ba_in.csv"))
     run_bundle_adjuster(tmp_dir)
-    extrinsics = read_bundle_adjust_result(os.path.join(tmp_dir, "ba_out.csv"))
-    for id1 in range(tuple_size):
-        for id0 in range(id1):
-            pose0, pose1 = data["pose{}".format(id0)][0].cpu().numpy(), data["pose{}".format(id1)][0].cpu().numpy()
-            T_021 = np.linalg.inv(pose1) @ pose0
-            T_021_pred = extrinsics[id1] @ np.linalg.inv(extrinsics[id0])
-            err_t, err_R = compute_pose_error(T_021, T_021_pred[:3, :3], T_021_pred[:3, 3])
-            pose_errors[0].append(np.maximum(err_t, err_R))
-            pose_errors[1].append(err_t)
-            pose_errors[2].append(err_R)
-            if verbose:
-                logging.info("{} -> {}: rot {:>5.1f}deg\tt {:>5.1f}deg".format(id0, id1, err_R, err_t))
+    return np.array(read_bundle_adjust_result(path("ba_out.csv")))
+
+
+def tuple_pose_errors(extrinsics, cam_to_world):
+    """Angular errors (degrees) of every image pair of a tuple, pairs in ``_pairs`` order: predicted relative pose
+    ``E_j inv(E_i)`` against ``inv(pose_j) pose_i``.  Returns ``(err_t [P], err_R [P])`` with upstream's conventions
+    (``compute_pose_error``: translation error folded to <= 90 degrees)."""
+    pairs = _pairs(len(extrinsics))
+    i_idx, j_idx = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
+    E, C = np.asarray(extrinsics, np.float64), np.asarray(cam_to_world, np.float64)
+    gt = np.linalg.inv(C[j_idx]) @ C[i_idx]
+    pred = E[j_idx] @ np.linalg.inv(E[i_idx])
+    cos_r = np.clip((np.einsum("pab,pab->p", gt[:, :3, :3], pred[:, :3, :3]) - 1.0) / 2.0, -1.0, 1.0)
+    tg, tp = gt[:, :3, 3], pred[:, :3, 3]
+    cos_t = np.clip(np.einsum("pa,pa->p", tg, tp) / (np.linalg.norm(tg, axis=1) * np.linalg.norm(tp, axis=1)), -1.0, 1.0)
+    err_t = np.rad2deg(np.arccos(cos_t))
+    return np.minimum(err_t, 180.0 - err_t), np.rad2deg(np.abs(np.arccos(cos_r)))
+
+
+def eval_bundle_adjust(tuple_size, data, result, tmp_dir, pose_errors, verbose=False):
+    """``eval_bundle_adjust`` (eval_multi_view.py:21-68): the multi-view back-end for one tuple (batch element 0);
+    extends ``pose_errors = [max errors, translation errors, rotation errors]`` by one entry per image pair."""
+    extrinsics = solve_tuple_poses(tuple_size, data, result, tmp_dir)
+    err_t, err_R = tuple_pose_errors(extrinsics, [data["pose" + str(v)][0].cpu().numpy() for v in range(tuple_size)])
+    pose_errors[0].extend(np.maximum(err_t, err_R))
+    pose_errors[1].extend(err_t)
+    pose_errors[2].extend(err_R)
+    if verbose:
+        for (i, j), et, er in zip(_pairs(tuple_size), err_t, err_R):
+            logging.info("%d -> %d: rot %5.1fdeg\tt %5.1fdeg", i, j, er, et)
     return pose_errors
 
 

@@ -24,14 +24,30 @@ def _prep(t, dev):
     return t.to(dev, torch.float32).contiguous()
 
 
+def _intr_batch(K, B):
+    """[k,k] or [1|B,k,k] intrinsics -> (contiguous [nb,k,k], k, nb)."""
+    if K.dim() == 2:
+        K = K.unsqueeze(0)
+    kdim = K.shape[-1]
+    if K.shape[-2:] != (kdim, kdim) or kdim not in (3, 4) or K.shape[0] not in (1, B):
+        raise AssertionError(K.shape)
+    return K, kdim, K.shape[0]
+
+
 def normalize(kpts, intr):
-    """``normalize`` (:9-14): pixel -> camera coordinates; a trivial elementwise op kept in
-    torch for callers that use it stand-alone (``eval_pairs.py:240-241``)."""
-    fx, fy, cx, cy = intr[..., 0, 0], intr[..., 1, 1], intr[..., 0, 2], intr[..., 1, 2]
-    out = torch.zeros_like(kpts)
-    out[..., 0] = (kpts[..., 0] - cx.unsqueeze(-1)) / fx.unsqueeze(-1)
-    out[..., 1] = (kpts[..., 1] - cy.unsqueeze(-1)) / fy.unsqueeze(-1)
-    return out
+    """``normalize`` (:9-14): pixel -> camera coordinates (``e2emv_normalize_kpts``; stand-alone callers:
+    ``eval_pairs.py:240-241``)."""
+    dev = _dev_of(kpts, intr)
+    ctx = _lib.context(dev)
+    squeeze = kpts.dim() == 2
+    k = _prep(kpts.unsqueeze(0) if squeeze else kpts, dev)
+    B, N = k.shape[:2]
+    K, kdim, nb = _intr_batch(_prep(intr, dev), B)
+    out = torch.empty_like(k)
+    if B * N:
+        with torch.cuda.device(dev):
+            ctx.call("e2emv_normalize_kpts", B, N, _lib.ptr(k), _lib.ptr(K), kdim, nb, _lib.ptr(out), _lib.stream_ptr(dev))
+    return out[0] if squeeze else out
 
 
 def get_kpts(data, result, id0, id1):
@@ -112,34 +128,119 @@ def run_weighted_8_point(data, result, id0, id1, choose_closest=False, target_T_
     return None, None
 
 
-def pose_errors(T0, T1):
-    """Per-sample (rotation, translation-direction) angle errors in radians on the device."""
+def run_weighted_8_point_tuple(data, result, choose_closest=False, targets=None, determine_inliers=False):
+    """Weighted 8-point pose of EVERY pair of the tuple in one batched solve (``e2emv_w8pt_tuple``): what the reference
+    does by calling ``run_weighted_8_point`` inside its pair loops (``helpers.py:250-258``, ``bundle_adjust_io.py:62-100``),
+    with 4 kernel launches per tuple batch instead of 4 per pair.  Returns ``{(id0, id1): (T_021 [B,4,4], info)}`` with
+    the per-pair values of ``estimate_relative_pose_w8pt`` (views into the batched outputs) and ``(None, None)`` for a pair
+    whose matches are missing.  ``targets``: ``{(id0, id1): T_021 [B,4,4]}`` when ``choose_closest``.  Images with
+    different keypoint counts (or per-pair keypoint keys) go through the per-pair call."""
+    T = 0
+    while "keypoints" + str(T) in data:
+        T += 1
+    pairs = [(i, j) for j in range(T) for i in range(j)]
+    mkeys = ["matches{}_{}_{}".format(i, i, j) for i, j in pairs]
+    shapes = {tuple(data["keypoints" + str(t)].shape) for t in range(T)}
+    batched = T >= 2 and len(shapes) == 1 and all(k in result for k in mkeys) and next(iter(shapes))[1] >= 8
+    if batched and choose_closest and (targets is None or any(p not in targets for p in pairs)):
+        raise ValueError("choose_closest=True needs a target T_021 for every pair")
+    if not batched:
+        out = {}
+        for (i, j) in pairs:
+            tgt = targets[(i, j)] if (choose_closest and targets is not None) else None
+            out[(i, j)] = run_weighted_8_point(data, result, i, j, choose_closest=choose_closest, target_T_021=tgt)
+        return out
+    dev = _dev_of(result[mkeys[0]], data["keypoints0"])
+    ctx = _lib.context(dev)
+    B, N = data["keypoints0"].shape[:2]
+    P = len(pairs)
+    kpts = [_prep(data["keypoints" + str(t)], dev) for t in range(T)]
+    intr = [_intr_batch(_prep(data["intr" + str(t)], dev), B) for t in range(T)]
+    kdim, nb = intr[0][1], intr[0][2]
+    if any(k[1:] != (kdim, nb) for k in intr):
+        raise AssertionError("intrinsics of a tuple must share their layout")
+    intr = [k[0] for k in intr]
+    matches = [result[k].to(dev, torch.int64).contiguous() for k in mkeys]
+    conf_shapes = [result["conf_scores_{}_{}".format(i, j)].shape for i, j in pairs]
+    conf = [_prep(result["conf_scores_{}_{}".format(i, j)].reshape(B, -1), dev) for i, j in pairs]
+    if any(c.shape != (B, N) for c in conf) or any(m.shape != (B, N) for m in matches):
+        raise AssertionError("matches / conf_scores must be [B, N]")
+    tg = [_prep(targets[p], dev) for p in pairs] if choose_closest else [None] * P
+    Tout = torch.empty((P, B, 4, 4), dtype=torch.float32, device=dev)
+    k0n = torch.empty((P, B, N, 2), dtype=torch.float32, device=dev)
+    k1n = torch.empty_like(k0n)
+    cfn = torch.empty((P, B, N), dtype=torch.float32, device=dev)
+    inl = torch.empty((P, B, N), dtype=torch.uint8, device=dev) if determine_inliers else None
+    pos = torch.empty((P, B, N), dtype=torch.uint8, device=dev)
+    F = torch.empty((P, B, 3, 3), dtype=torch.float32, device=dev)
+    status = torch.empty((P, B), dtype=torch.int32, device=dev)
+    keep, args = [], []
+    for lst in (kpts, intr, matches, conf, tg):
+        pa, arr = _lib.ptr_array(lst)
+        keep.append(arr)
+        args.append(pa)
+    with torch.cuda.device(dev):
+        ctx.call("e2emv_w8pt_tuple", B, T, N, args[0], args[1], kdim, nb, args[2], args[3], 1 if choose_closest else 0, args[4],
+                 1 if determine_inliers else 0, _lib.ptr(Tout), _lib.ptr(k0n), _lib.ptr(k1n), _lib.ptr(cfn), _lib.ptr(inl),
+                 _lib.ptr(pos), _lib.ptr(F), _lib.ptr(status), _lib.stream_ptr(dev))
+    posb = pos.bool()
+    inlb = inl.bool() if inl is not None else None
+    out = {}
+    for q, p in enumerate(pairs):
+        info = {"kpts0_norm": k0n[q], "kpts1_norm": k1n[q], "confidence": cfn[q].reshape(conf_shapes[q]),
+                "inliers": inlb[q] if inlb is not None else None, "pos_depth_mask": posb[q], "F": F[q], "status": status[q]}
+        out[p] = (Tout[q], info)
+    return out
+
+
+def _pose_error_buffers(T0, T1, means):
     dev = _dev_of(T0, T1)
     ctx = _lib.context(dev)
     a, b = _prep(T0, dev), _prep(T1, dev)
     B = a.shape[0]
     rot = torch.empty((B,), dtype=torch.float32, device=dev)
     tr = torch.empty((B,), dtype=torch.float32, device=dev)
+    valid = torch.empty((B,), dtype=torch.uint8, device=dev)
+    m2 = torch.empty((2,), dtype=torch.float32, device=dev) if means else None
     with torch.cuda.device(dev):
-        ctx.call("e2emv_pose_errors", B, _lib.ptr(a), _lib.ptr(b), _lib.ptr(rot), _lib.ptr(tr), _lib.stream_ptr(dev))
+        ctx.call("e2emv_pose_error_means", B, _lib.ptr(a), _lib.ptr(b), _lib.ptr(rot), _lib.ptr(tr), _lib.ptr(valid),
+                 _lib.ptr(m2), _lib.stream_ptr(dev))
+    return rot, tr, valid, m2
+
+
+def pose_errors(T0, T1):
+    """Per-sample (rotation, translation-direction) angle errors in radians on the device, fixed shape [B] each
+    (entries whose translation norm product is <= 1e-6 read 0)."""
+    rot, tr, _, _ = _pose_error_buffers(T0, T1, means=False)
     return rot, tr
 
 
 def compute_rotation_error(T0, T1, reduce=True):
-    """``compute_rotation_error`` (compute_pose_error.py:3-12)."""
-    rot, _ = pose_errors(T0, T1)
-    return rot.mean() if reduce else rot
+    """``compute_rotation_error`` (compute_pose_error.py:3-12); the mean is reduced on the device."""
+    rot, _, _, m2 = _pose_error_buffers(T0, T1, means=reduce)
+    return m2[0] if reduce else rot
 
 
 def compute_translation_error_as_angle(T0, T1, reduce=True):
-    """``compute_translation_error_as_angle`` (compute_pose_error.py:14-22); ``reduce=True``
-    averages over the entries whose norm product exceeds 1e-6 like the reference."""
-    _, tr = pose_errors(T0, T1)
-    if not reduce:
-        return tr
-    n = torch.linalg.norm(T0[..., :3, 3], dim=-1) * torch.linalg.norm(T1[..., :3, 3], dim=-1)
-    valid = (n > 1e-6).to(tr.device)
-    return tr[valid].mean()
+    """``compute_translation_error_as_angle`` (compute_pose_error.py:14-22): only the entries whose norm product
+    exceeds 1e-6 count - ``reduce=True`` averages over them on the device, ``reduce=False`` returns exactly those
+    entries (shape [n_valid], like the reference's boolean indexing)."""
+    _, tr, valid, m2 = _pose_error_buffers(T0, T1, means=reduce)
+    return m2[1] if reduce else tr[valid.bool()]
+
+
+def mask_confidence(confidence, mask):
+    """``confidence[~mask] = 0`` as a new tensor, on the device (``e2emv_apply_mask``): the step between the weighted 8-point
+    solve and the two-view bundle adjustment (``eval_pairs.py:250-251``, ``bundle_adjust_io.py:18-19``)."""
+    dev = _dev_of(confidence, mask)
+    ctx = _lib.context(dev)
+    c = _prep(confidence, dev)
+    m = mask.to(dev).reshape(c.shape).to(torch.uint8).contiguous() if mask.dtype != torch.uint8 else mask.to(dev).reshape(c.shape).contiguous()
+    out = torch.empty_like(c)
+    if c.numel():
+        with torch.cuda.device(dev):
+            ctx.call("e2emv_apply_mask", c.numel(), _lib.ptr(c), _lib.ptr(m), _lib.ptr(out), _lib.stream_ptr(dev))
+    return out
 
 
 def run_bundle_adjust_2_view(kpts0_norm, kpts1_norm, confidence, init_T021, n_iterations, check_lu_info_strict=False,

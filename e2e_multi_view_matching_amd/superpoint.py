@@ -8,6 +8,7 @@ reference's dict of per-image lists: ``keypoints`` [n,2] (x, y), ``scores`` [n],
 computes anything; no CPU fallback.
 """
 import ctypes
+import warnings
 
 import torch
 from torch import nn
@@ -32,19 +33,21 @@ class SuperPoint(nn.Module):
         mk = self.config["max_keypoints"]
         if mk == 0 or mk > MAX_KEYPOINTS_CAPACITY:
             raise ValueError('"max_keypoints" must be positive (<= {}) or -1'.format(MAX_KEYPOINTS_CAPACITY))
-        self._uploaded = None
+        self._token = _lib.new_owner_token()
         self.requires_grad_(False)  # the reference runs SuperPoint frozen, under no_grad (helpers.py:86)
 
     def _upload(self, ctx):
-        stamp = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if self._uploaded == (id(ctx), stamp):
+        # one SuperPoint weight set per context: re-upload whenever another instance (or other values) own it
+        owner = (self._token, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        if ctx.sp_weights_owner == owner:
             return
+        ctx.sp_weights_owner = None
         for k, v in self.state_dict().items():
             t = v.detach().to("cpu", torch.float32).contiguous()
             shape = (ctypes.c_int64 * t.dim())(*t.shape)
             ctx.call("e2emv_set_weight", ("superpoint." + k).encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim())
         ctx.call("e2emv_superpoint_commit")
-        self._uploaded = (id(ctx), stamp)
+        ctx.sp_weights_owner = owner
 
     def forward(self, data):
         images = data["image"]
@@ -60,6 +63,14 @@ class SuperPoint(nn.Module):
             B, C, H, W = batch.shape
             if C != 1:
                 raise AssertionError("SuperPoint takes one-channel images, got {}".format(tuple(batch.shape)))
+            # the encoder pools three times: like upstream only the top-left (H//8*8) x (W//8*8) region yields keypoints.
+            # Upstream's convolutions still SEE the cut rows/columns before its pools floor them away; here they are
+            # cropped first (documented deviation, INTEGRATION.md: responses within ~16 px of a cropped edge can differ).
+            if H % 8 or W % 8:
+                H, W = H // 8 * 8, W // 8 * 8
+                if H == 0 or W == 0:
+                    raise AssertionError("SuperPoint needs images of at least 8x8 pixels")
+                batch = batch[:, :, :H, :W]
             img = batch.to(torch.float32).contiguous()
             cfg = self.config
             K = cfg["max_keypoints"] if cfg["max_keypoints"] > 0 else MAX_KEYPOINTS_CAPACITY
@@ -75,6 +86,9 @@ class SuperPoint(nn.Module):
                 ctx.call("e2emv_superpoint_forward", ctypes.byref(d), _lib.ptr(img), _lib.ptr(kpts), _lib.ptr(scores), _lib.ptr(desc),
                          _lib.ptr(count), _lib.ptr(smap), _lib.stream_ptr(dev))
             n = count.tolist()
+            if cfg["max_keypoints"] <= 0 and max(n) >= MAX_KEYPOINTS_CAPACITY:
+                warnings.warn("SuperPoint(max_keypoints=-1): an image reached the device capacity of {} keypoints; the lowest-"
+                              "scoring candidates beyond it were dropped (upstream keeps all)".format(MAX_KEYPOINTS_CAPACITY))
             for b in range(B):
                 out["keypoints"].append(kpts[b, :n[b]])
                 out["scores"].append(scores[b, :n[b]])

@@ -1,10 +1,12 @@
-"""Validation targets and loss on the device: drop-ins for ``helpers.compute_gt_matches_of_image_pair`` (:121-203),
-``helpers.compute_gt_matches`` (:215-226), ``helpers.compute_match_loss`` (:228-241) and the forward-only part of
-``helpers.run_matcher`` (:243-260) on top of libe2emv.so (``csrc/gtmatch.hip``).  Inference/validation only: no autograd."""
+"""Validation targets and match loss on the device: the two data-parallel N^2 steps of the reference's validation pass,
+``helpers.compute_gt_matches_of_image_pair`` (:121-203) and ``helpers.compute_match_loss`` (:228-241), on top of
+libe2emv.so (``csrc/gtmatch.hip``).  The reference's own ``helpers.compute_gt_matches`` / ``helpers.run_matcher`` stay
+the callers (they only loop over the pairs of a tuple); ``gt_matches_for_tuple`` is the batched equivalent of that loop
+for device-resident data.  Inference/validation only: no autograd."""
 import torch
 
 from . import _lib
-from .pose import _dev_of, _prep, compute_rotation_error, compute_translation_error_as_angle, run_weighted_8_point
+from .pose import _dev_of, _prep
 
 
 def compute_gt_matches_of_image_pair(kpts0, kpts1, K0, K1, T0to1, depth0, depth1, max_matched_reproj_err,
@@ -30,18 +32,32 @@ def compute_gt_matches_of_image_pair(kpts0, kpts1, K0, K1, T0to1, depth0, depth1
     return idx, w
 
 
-def compute_gt_matches(opt, data):
-    """``helpers.compute_gt_matches``: fills ``gt_indices_k_m`` / ``gt_weights_k_m`` for every pair of the tuple and pops
-    the depth maps, like the reference."""
-    T = len(data["ids"])
-    for m in range(T):
-        for k in range(m):
-            T_k2m = torch.linalg.inv(data["pose" + str(m)]) @ data["pose" + str(k)]
-            data["gt_indices_{}_{}".format(k, m)], data["gt_weights_{}_{}".format(k, m)] = compute_gt_matches_of_image_pair(
-                data["keypoints" + str(k)], data["keypoints" + str(m)], data["intr" + str(k)], data["intr" + str(m)], T_k2m,
-                data["depth" + str(k)], data["depth" + str(m)], opt.match_reproj_err, opt.unmatch_reproj_err)
-    for m in range(T):
-        data.pop("depth" + str(m))
+def relative_pose(pose_from, pose_to):
+    """``inv(pose_to) @ pose_from`` per batch element on the device (the relative pose ``helpers.py:219, 254`` builds with
+    torch ops): [B,4,4] x [B,4,4] -> [B,4,4]."""
+    dev = _dev_of(pose_from, pose_to)
+    ctx = _lib.context(dev)
+    a, b = _prep(pose_from, dev), _prep(pose_to, dev)
+    if a.shape != b.shape or a.shape[-2:] != (4, 4):
+        raise AssertionError(a.shape, b.shape)
+    out = torch.empty_like(a)
+    with torch.cuda.device(dev):
+        ctx.call("e2emv_relative_pose", a.shape[0], _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.stream_ptr(dev))
+    return out
+
+
+def gt_matches_for_tuple(data, max_matched_reproj_err, min_unmatched_reproj_err, n_images=None):
+    """Ground-truth match targets of every pair of a device-resident tuple: returns
+    ``{(k, m): (indices, weights)}`` for k < m, the values ``helpers.compute_gt_matches`` stores under
+    ``gt_indices_k_m`` / ``gt_weights_k_m``.  Does not touch ``data``."""
+    if n_images is None:
+        n_images = len(data["ids"])
+    rel = {(k, m): relative_pose(data["pose%d" % k], data["pose%d" % m]) for m in range(n_images) for k in range(m)}
+    return {km: compute_gt_matches_of_image_pair(data["keypoints%d" % km[0]], data["keypoints%d" % km[1]],
+                                                 data["intr%d" % km[0]], data["intr%d" % km[1]], T_km,
+                                                 data["depth%d" % km[0]], data["depth%d" % km[1]],
+                                                 max_matched_reproj_err, min_unmatched_reproj_err)
+            for km, T_km in rel.items()}
 
 
 def compute_match_loss(log_p, gt_indices_0_1, gt_weights_0_1):
@@ -56,27 +72,3 @@ def compute_match_loss(log_p, gt_indices_0_1, gt_weights_0_1):
     with torch.cuda.device(dev):
         ctx.call("e2emv_match_loss", B, ft - 1, _lib.ptr(lp), _lib.ptr(idx), _lib.ptr(w), _lib.ptr(loss), _lib.stream_ptr(dev))
     return loss[0]
-
-
-def run_matcher(opt, data, matcher):
-    """Forward-only ``helpers.run_matcher`` (:243-260): matcher -> match loss per pair (+ pose losses when
-    ``opt.pose_loss``).  ``matcher`` may be wrapped in DataParallel/DDP (``.module``) like in the reference."""
-    T = len(data["ids"])
-    inner = getattr(matcher, "module", matcher)
-    inner.config["full_output"] = opt.pose_loss
-    result = matcher(data)
-    dev = result["scores_0_1"].device
-    match_loss = torch.zeros(1, device=dev)
-    rot_loss = torch.zeros(1, device=dev)
-    transl_loss = torch.zeros(1, device=dev)
-    for id1 in range(T):
-        for id0 in range(id1):
-            match_loss = match_loss + compute_match_loss(result["scores_{}_{}".format(id0, id1)],
-                                                         data["gt_indices_{}_{}".format(id0, id1)],
-                                                         data["gt_weights_{}_{}".format(id0, id1)])
-            if opt.pose_loss:
-                target = torch.linalg.inv(data["pose{}".format(id1)]) @ data["pose{}".format(id0)]
-                pred, _ = run_weighted_8_point(data, result, id0, id1, choose_closest=True, target_T_021=target)
-                rot_loss = rot_loss + compute_rotation_error(pred, target)
-                transl_loss = transl_loss + compute_translation_error_as_angle(pred, target)
-    return {"match_loss": match_loss, "rot_loss": rot_loss, "transl_loss": transl_loss}, result

@@ -151,6 +151,46 @@ int e2emv_w8pt(e2emv_ctx* ctx, int B, int N, const float* d_kpts0, const float* 
                float* d_conf_n, uint8_t* d_inliers, uint8_t* d_posdepth, float* d_F, int32_t* d_status,
                void* stream);
 
+/* e2emv_w8pt on a RAGGED batch: sample b uses its first d_n_per[b] (8 <= n <= N) correspondences; every per-correspondence
+ * buffer keeps the row stride N and the rows beyond n read 0 / false in the outputs.  The Hartley statistics of sample b
+ * run over its own n rows only (a zero-weight padding row would change them - estimate_relative_pose.py:56-57), which is
+ * what lets the pairs of a tuple with different numbers of matches share one launch (bundle_adjust_io.py:98-131). */
+int e2emv_w8pt_ragged(e2emv_ctx* ctx, int B, int N, const int32_t* d_n_per, const float* d_kpts0, const float* d_kpts1,
+                      const float* d_intr0, const float* d_intr1, int kdim, int intr_batch, const float* d_conf,
+                      int choose_closest, const float* d_T_gt, int determine_inliers, float* d_T, float* d_kpts0n,
+                      float* d_kpts1n, float* d_conf_n, uint8_t* d_inliers, uint8_t* d_posdepth, float* d_F, int32_t* d_status,
+                      void* stream);
+
+/* All T(T-1)/2 pairs of B tuples in ONE solve (the loop of helpers.py:250-258 / bundle_adjust_io.py:62-100 over the pairs
+ * of a tuple, batched): pair q enumerates (i, j), i < j, j outer (q = 0: (0,1), 1: (0,2), 2: (1,2), ...).  get_kpts
+ * (estimate_relative_pose.py:16-31) of every pair is fused in: d_kpts[t] [B,N,2] and d_intr[t] [intr_batch,kdim,kdim] per
+ * image, d_matches[q] [B,N] int64 / d_conf[q] [B,N] per pair (matches of image i in image j, -1 wraps to the last keypoint
+ * with weight 0), d_T_gt[q] [B,4,4] per pair when choose_closest.  All images carry the same N (the fixed-shape batches of
+ * helpers.py:89-92).  Outputs are pair-major: element (q, b) at index q*B + b of d_T [P*B,4,4], d_kpts0n / d_kpts1n
+ * [P*B,N,2], d_conf_n [P*B,N], d_inliers / d_posdepth [P*B,N], d_F [P*B,3,3], d_status [P*B]; semantics per element as
+ * e2emv_w8pt.  3 kernel launches + 1 gather instead of 4 per pair.                                                    */
+int e2emv_w8pt_tuple(e2emv_ctx* ctx, int B, int T, int N, const float* const* d_kpts, const float* const* d_intr, int kdim,
+                     int intr_batch, const int64_t* const* d_matches, const float* const* d_conf, int choose_closest,
+                     const float* const* d_T_gt, int determine_inliers, float* d_T, float* d_kpts0n, float* d_kpts1n,
+                     float* d_conf_n, uint8_t* d_inliers, uint8_t* d_posdepth, float* d_F, int32_t* d_status, void* stream);
+
+/* d_out[i] = d_mask[i] ? d_x[i] : 0 - the confidence masking between w8pt and the two-view BA
+ * (eval_pairs.py:250-251, bundle_adjust_io.py:18-19: confidence[~pos_depth_mask] = 0). */
+int e2emv_apply_mask(e2emv_ctx* ctx, int64_t n, const float* d_x, const uint8_t* d_mask, float* d_out, void* stream);
+
+/* normalize (estimate_relative_pose.py:9-14): d_out[b,n] = ((x - cx) / fx, (y - cy) / fy), fp32. */
+int e2emv_normalize_kpts(e2emv_ctx* ctx, int B, int N, const float* d_kpts, const float* d_intr, int kdim, int intr_batch,
+                         float* d_out, void* stream);
+
+/* T_a_to_b = inv(pose_b) @ pose_a per batch element (helpers.py:219, 254: the relative pose the GT-match builder and
+ * the pose losses use), 4x4 row-major, solved in fp64. */
+int e2emv_relative_pose(e2emv_ctx* ctx, int B, const float* d_pose_a, const float* d_pose_b, float* d_T_a2b, void* stream);
+
+/* e2emv_pose_errors plus the reference's reductions (compute_pose_error.py:12, 22): d_transl_valid[b] = |t0||t1| > 1e-6,
+ * d_means2 (optional) = {mean rotation error over B, mean translation error over the valid entries (NaN if none)}. */
+int e2emv_pose_error_means(e2emv_ctx* ctx, int B, const float* d_T, const float* d_T_gt, float* d_rot_err, float* d_transl_err,
+                           uint8_t* d_transl_valid, float* d_means2, void* stream);
+
 /* compute_rotation_error / compute_translation_error_as_angle(reduce=False)
  * (compute_pose_error.py:3-22), radians; entries with |t0||t1| <= 1e-6 give 0.             */
 int e2emv_pose_errors(e2emv_ctx* ctx, int B, const float* d_T, const float* d_T_gt, float* d_rot_err,
@@ -264,6 +304,7 @@ int e2emv_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D
 #define E2EMV_PRECISION_F32 0
 #define E2EMV_PRECISION_BF16X3 1
 int e2emv_set_precision(e2emv_ctx* ctx, int precision);
+int e2emv_get_precision(e2emv_ctx* ctx, int* precision);
 /* building blocks of the bf16x3 path on fp32 buffers (split / merge done internally; for tests):
  * C = act(A W^T + bias), A [M,K], W [N,K], C [M,N]; flags bit0 relu, bit1 = first-generation kernel reading pre-split
  * activation planes (gemm3.hip) instead of the default gemm_x3.hip (fp32 activations split on the way into LDS). */

@@ -1,0 +1,76 @@
+"""bench.py's launch and N > 1 branch on CPU (gloo, world_size 2): `--gpus 2` without a launcher re-executes through
+torch.distributed.run, every rank joins the process group, the timing is the MAX over ranks, the per-pair errors are
+all-gathered and rank 0 prints ONE line with n_gpus = 2.  The step itself is the stub workload (E2EMV_BENCH_STUB) - the
+kernels need a GPU; everything around them is the code the driver's `python bench.py --gpus N` runs."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_gpus_2_self_spawns_two_ranks_and_gathers_the_metric():
+    from e2e_multi_view_matching_amd.metrics import pose_auc
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "5", "--tuple-size", "3"],
+                       capture_output=True, text=True, timeout=600, env=_env(E2EMV_BENCH_STUB="1"), cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    P = 3
+    assert out["config"]["pairs_per_gpu"] == 5 * P and out["config"]["global_pairs"] == 2 * 5 * P
+    assert out["auc_pairs"] == 2 * 5 * P
+    # the gathered errors are rank 0's then rank 1's (the stub draws them from seed 100 + rank)
+    e = np.concatenate([np.random.default_rng(100 + rk).uniform(0, 30, 5 * P) for rk in range(2)]).astype(np.float32)
+    assert np.allclose(out["auc_5_10_20"], [100 * a for a in pose_auc(e, [5, 10, 20])], atol=2e-3)
+    # MAX over ranks: the stub's rank 1 sleeps 4 ms per step, rank 0 2 ms
+    assert out["ms_per_step"] >= 3.9
+    assert abs(out["value"] - 2 * 5 * P * 3 / (out["ms_per_step"] * 3e-3)) < 0.02 * out["value"]
+    # the label is built from the arguments, and this is not one of the BASELINE configs
+    w = out["config"]["workload"]
+    assert w.startswith("custom") and "tuple_size=3" in w and "batch 5 tuples/GPU" in w and out["config"]["parallelism"] == "tuple-sharded x2"
+
+
+def test_world_size_must_match_gpus():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, env=_env(E2EMV_BENCH_STUB="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0",
+                                             MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"), cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)
+
+
+def test_workload_label_follows_the_arguments():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args([])
+    assert bench.workload_string(a, 1).startswith("configs[1]:") and "batch 32 tuples/GPU = 32 pairs/GPU" in bench.workload_string(a, 1)
+    assert bench.workload_string(a, 8).startswith("configs[2]")
+    a = bench.parse_args(["--config", "c4"])
+    assert a.tuple_size == 5 and a.batch == 8 and bench.workload_string(a, 1).startswith("configs[3]:")
+    a = bench.parse_args(["--config", "c5"])
+    assert a.kpts == 2048 and a.desc == "f16" and "f16 descriptors" in bench.workload_string(a, 1)
+    a = bench.parse_args(["--tuple-size", "5"])
+    assert bench.workload_string(a, 1).startswith("custom") and "tuple_size=5 (10 pairs per tuple)" in bench.workload_string(a, 1)
+    a = bench.parse_args(["--config", "c4", "--gnn", "7x3"])
+    assert len(a.layers) == 28 and a.layers[:4] == ["self", "cross", "cross", "cross"]
+
+
+def test_single_rank_stub_line_is_the_contract():
+    r = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--batch", "2"], capture_output=True, text=True,
+                       timeout=300, env=_env(E2EMV_BENCH_STUB="1"), cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config"):
+        assert key in out
+    assert out["n_gpus"] == 1 and out["vs_baseline"] is None and out["unit"] == "pairs/s"

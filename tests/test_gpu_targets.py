@@ -52,8 +52,9 @@ def test_gt_matches_larger_and_loss_vs_oracle(gpu):
     assert abs(lh - lo) < 1e-4 * abs(lo)
 
 
-def test_run_matcher_validation_step(gpu):
-    """helpers.run_matcher forward: matcher -> match loss (+ pose losses with choose_closest) on the device."""
+def test_validation_step_pieces_as_the_reference_caller_uses_them(gpu):
+    """What helpers.run_matcher (helpers.py:243-260, the unchanged caller) asks of the package per validation step: the
+    matcher wrapped in DataParallel, the match loss per pair, the relative target pose and the choose_closest pose losses."""
     import e2e_multi_view_matching_amd as E
     from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
     from oracle import gt_matches as OG, w8pt as OW
@@ -63,7 +64,6 @@ def test_run_matcher_validation_step(gpu):
     shell = identity_like_state(E.MultiViewMatcher(cfg).eval())
     sd = {k: v.clone() for k, v in shell.state_dict().items()}
     d = make_tuples(batch=2, tuple_size=2, n_kpts=128, seed=3)
-    # targets from the synthetic ground truth (same container layout the GT builder produces)
     gt = d["gt_matches0_0_1"]
     idx = torch.full((2, 2, 129), -1, dtype=torch.int64)
     idx[:, 0, :128] = gt
@@ -71,16 +71,43 @@ def test_run_matcher_validation_step(gpu):
         v = gt[b] >= 0
         idx[b, 1, gt[b][v]] = torch.nonzero(v)[:, 0]
     w = torch.rand(2, 2, 129, generator=torch.Generator().manual_seed(1))
-    d["gt_indices_0_1"], d["gt_weights_0_1"] = idx, w
-    # the reference's dataset stores camera-to-world poses (target = inv(pose1) @ pose0, helpers.py:255); the synthetic
-    # generator stores world-to-camera ones
-    d["pose0"], d["pose1"] = torch.linalg.inv(d["pose0"]), torch.linalg.inv(d["pose1"])
-    opt = types.SimpleNamespace(pose_loss=True)
+    # the reference's dataset stores camera-to-world poses (target = inv(pose1) @ pose0); the generator world-to-camera
+    c2w0, c2w1 = torch.linalg.inv(d["pose0"]), torch.linalg.inv(d["pose1"])
     model = torch.nn.DataParallel(shell.to(gpu), device_ids=[0]) if torch.cuda.device_count() == 1 else shell.to(gpu)
-    losses, result = E.run_matcher(opt, _to(d, gpu), model)
+    getattr(model, "module", model).config["full_output"] = True
+    dg = _to(d, gpu)
+    result = model(dg)
     ref = matcher_forward(d, sd, {**cfg, "full_output": True})
+    lh = E.compute_match_loss(result["scores_0_1"], idx.to(gpu), w.to(gpu))
     lo = OG.compute_match_loss(ref["scores_0_1"], idx, w)
-    assert abs(float(losses["match_loss"]) - float(lo)) < 1e-3 * abs(float(lo))
+    assert abs(float(lh) - float(lo)) < 1e-3 * abs(float(lo))
+    target = E.relative_pose(c2w0.to(gpu), c2w1.to(gpu))
+    assert float((target.cpu() - d["T_0to1"]).abs().max()) < 1e-5
+    pred, _ = E.run_weighted_8_point(dg, result, 0, 1, choose_closest=True, target_T_021=target)
     Tr, _ = OW.run_weighted_8_point(d, ref, 0, 1, choose_closest=True, target_T_021=d["T_0to1"])
-    assert abs(float(losses["rot_loss"]) - float(OW.compute_rotation_error(Tr, d["T_0to1"]))) < 2e-3
+    rot = E.compute_rotation_error(pred, target)
+    tra = E.compute_translation_error_as_angle(pred, target)
+    assert rot.dim() == 0 and tra.dim() == 0 and rot.is_cuda
+    assert abs(float(rot) - float(OW.compute_rotation_error(Tr, d["T_0to1"]))) < 2e-3
+    assert abs(float(tra) - float(OW.compute_translation_error_as_angle(Tr, d["T_0to1"]))) < 2e-3
     assert "matches0_0_1" in result
+
+
+def test_gt_matches_for_tuple_equals_the_pair_loop(gpu):
+    """The batched stand-in for helpers.compute_gt_matches' pair loop: relative poses on the device + one call per pair."""
+    import e2e_multi_view_matching_amd as E
+    from e2e_multi_view_matching_amd.synthetic import make_depth_pairs
+    d = make_depth_pairs(3, 256, seed=4, height=240, width=320)
+    # camera-to-world poses as the dataset stores them
+    data = {"ids": [0, 1], "pose0": torch.linalg.inv(d["pose0"]), "pose1": torch.linalg.inv(d["pose1"])}
+    for k in ("keypoints0", "keypoints1", "intr0", "intr1", "depth0", "depth1"):
+        data[k] = d[k]
+    dg = _to(data, gpu)
+    out = E.gt_matches_for_tuple(dg, 5.0, 15.0)
+    assert set(out) == {(0, 1)} and "depth0" in dg
+    T01 = torch.linalg.inv(data["pose1"]) @ data["pose0"]
+    assert float((E.relative_pose(dg["pose0"], dg["pose1"]).cpu() - T01).abs().max()) < 1e-5
+    idx, w = E.compute_gt_matches_of_image_pair(dg["keypoints0"], dg["keypoints1"], dg["intr0"], dg["intr1"], T01.to(gpu),
+                                                dg["depth0"], dg["depth1"], 5.0, 15.0)
+    assert int((out[(0, 1)][0] != idx).sum()) <= 2  # fp64 vs fp32 relative pose: flips only on a threshold
+    assert int((idx[:, 0] >= 0).sum()) > 100
