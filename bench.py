@@ -559,7 +559,7 @@ def run(args):
             for (i, j) in wl.pairs:
                 Tr, _ = OW.run_weighted_8_point(small, ref, i, j)
                 r = OW.compute_rotation_error(Tr, small[f"T_{i}to{j}"], reduce=False)
-                t = OW.compute_translation_error_as_angle(Tr, small[f"T_{i}to{j}"], reduce=False)
+                t = OW.compute_translation_error_as_angle(Tr, small[f"T_{i}to{j}"], keep_shape=True)
                 eo.append(pair_errors_deg(r.numpy(), t.numpy()))
         eo = np.concatenate(eo)
         eh = np.concatenate([pair_errors_deg(r.cpu().numpy()[:nb], t.cpu().numpy()[:nb]) for r, t in wl.id_errs])

@@ -74,20 +74,21 @@ def compute_rotation_error(T0, T1, reduce=True):
     return a.mean() if reduce else a
 
 
-def compute_translation_error_as_angle(T0, T1, reduce=True):
+def compute_translation_error_as_angle(T0, T1, reduce=True, keep_shape=False):
     """compute_pose_error.py:14-22 - angle between translation directions.
 
-    reduce=True follows the reference exactly (mean over entries whose norm product exceeds
-    1e-6); reduce=False keeps the batch shape (deviation E7).
+    Like the reference only the entries whose norm product exceeds 1e-6 count: reduce=True is their mean,
+    reduce=False returns exactly those entries (shape [n_valid]).  keep_shape=True (not in the reference) returns
+    [B] with 0 for the skipped entries - what the choose_closest loop below needs to stay batched.
     """
     t0, t1 = T0[..., :3, 3], T1[..., :3, 3]
     n = t0.norm(dim=-1) * t1.norm(dim=-1)
     valid = n > 1e-6
     cos = ((t0 * t1).sum(-1) / torch.where(valid, n, torch.ones_like(n))).clamp(-1.0, 1.0)
     err = torch.arccos(cos).abs()
-    if reduce:
-        return err[valid].mean()
-    return torch.where(valid, err, torch.zeros_like(err))
+    if keep_shape:
+        return torch.where(valid, err, torch.zeros_like(err))
+    return err[valid].mean() if reduce else err[valid]
 
 
 def pose_from_Rt(R, t):
@@ -115,7 +116,7 @@ def estimate_relative_pose_w8pt(kpts0, kpts1, intr0, intr1, confidence, choose_c
         for c in range(4):
             cand = pose_from_Rt(Rs[:, c], ts[:, c])
             err = compute_rotation_error(cand, T_021, reduce=False) + \
-                compute_translation_error_as_angle(cand, T_021, reduce=False)
+                compute_translation_error_as_angle(cand, T_021, keep_shape=True)
             upd = err < best
             best = torch.where(upd, err, best)
             T = torch.where(upd[:, None, None], cand, T)
@@ -128,12 +129,14 @@ def estimate_relative_pose_w8pt(kpts0, kpts1, intr0, intr1, confidence, choose_c
     depth1 = K.depth_from_point(T[:, :3, :3], T[:, :3, 3:], X)
     pos_depth = (depth0 > 0.0) & (depth1 > 0.0)
     inliers = None
+    extra = {}
     if determine_inliers:
         err = K.symmetrical_epipolar_distance(k0n, k1n, Fs).sqrt()
         thr = 3.0 / ((intr0[:, 0, 0] + intr0[:, 1, 1] + intr1[:, 0, 0] + intr1[:, 1, 1]) / 4.0)
         inliers = pos_depth & (err <= thr.unsqueeze(-1))
+        extra = {"epi_err": err, "epi_thr": thr.unsqueeze(-1)}  # for the tests' decision margins, not in the reference
     info = {"kpts0_norm": k0n, "kpts1_norm": k1n, "confidence": confidence, "inliers": inliers,
-            "pos_depth_mask": pos_depth, "F": Fs, "depth0": depth0, "depth1": depth1}
+            "pos_depth_mask": pos_depth, "F": Fs, "depth0": depth0, "depth1": depth1, **extra}
     return T, info
 
 

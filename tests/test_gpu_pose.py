@@ -40,7 +40,11 @@ def test_w8pt_vs_oracle(gpu, B, N, seed, closest):
     # masks: identical except where the fp64 oracle itself is within rounding of the decision boundary
     margin = torch.minimum(i64["depth0"].abs(), i64["depth1"].abs()) < 1e-6
     assert bool(((info["pos_depth_mask"].cpu() == i64["pos_depth_mask"]) | margin).all())
-    assert (info["inliers"].cpu() != i64["inliers"]).sum() <= 1 + 0.002 * B * N
+    # inliers = pos_depth & (epipolar error <= thr): may differ from fp64 only where the fp64 error is within 5e-3 of
+    # the threshold (0.015 px at the 3 px threshold - the effect of fp32 normalised coordinates + 1e-5 relative F) or
+    # where the depth decision itself is marginal
+    near = (i64["epi_err"] - i64["epi_thr"]).abs() < 5e-3 * i64["epi_thr"]
+    assert bool(((info["inliers"].cpu() == i64["inliers"]) | near | margin).all())
     Fh = info["F"].cpu().double()
     F64 = i64["F"]
     # N == 8 selects the smallest NON-null singular vector (thin-SVD quirk): conditioned by sigma7/sigma8

@@ -68,8 +68,12 @@ def test_w8pt_random_shapes(gpu, seed):
         Tr, iref = OW.estimate_relative_pose_w8pt(p0.double(), p1.double(), K0.double(), K0.double(), conf.double(), determine_inliers=True)
         T, info = E.estimate_relative_pose_w8pt(p0.to(gpu), p1.to(gpu), K0.to(gpu), K0.to(gpu), conf.to(gpu), determine_inliers=True)
         assert float((T.cpu().double() - Tr).abs().max()) < 1e-4, (B, N, kdim)
-        same = (info["inliers"].cpu() == iref["inliers"]).float().mean()
-        assert same > 0.995, (B, N, float(same))  # a point sitting exactly on the 3 px threshold may flip in fp32
+        # decisions equal except inside a stated margin of the fp64 decision boundary (0.015 px of the 3 px threshold,
+        # |depth| < 1e-6)
+        near = (iref["epi_err"] - iref["epi_thr"]).abs() < 5e-3 * iref["epi_thr"]
+        marg = torch.minimum(iref["depth0"].abs(), iref["depth1"].abs()) < 1e-6
+        assert bool(((info["inliers"].cpu() == iref["inliers"]) | near | marg).all()), (B, N)
+        assert bool(((info["pos_depth_mask"].cpu() == iref["pos_depth_mask"]) | marg).all()), (B, N)
 
 
 @pytest.mark.parametrize("seed", range(6))
