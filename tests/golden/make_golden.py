@@ -272,6 +272,65 @@ def gen_superglue_hf():
     print("superglue_hf_small.npz", "matched:", int((matches[:, 0] >= 0).sum()))
 
 
+def gen_superglue_hf_d256():
+    """The library's real width (D = 256, 4 heads of 64, keypoint encoder [32, 64, 128, 256]) through the HF port:
+    2 layers, weights from hf_superglue_weights.seeded_hf_tensors (reproduced from the seed by the tests)."""
+    from transformers.models.superglue import modeling_superglue as HF
+    from transformers.models.superglue.configuration_superglue import SuperGlueConfig
+    from hf_superglue_weights import seeded_hf_tensors
+    D, H, N, B, seed = 256, 4, 96, 2, 4242
+    kenc, layers = [32, 64, 128, 256], ["self", "cross"]
+    cfg = SuperGlueConfig(hidden_size=D, keypoint_encoder_sizes=kenc, gnn_layers_types=layers, num_attention_heads=H,
+                          sinkhorn_iterations=50, matching_threshold=0.0)
+    cfg._attn_implementation = "eager"
+    enc, gnn, fproj = HF.SuperGlueKeypointEncoder(cfg), HF.SuperGlueAttentionalGNN(cfg), HF.SuperGlueFinalProjection(cfg)
+    t = seeded_hf_tensors(seed, D, kenc, len(layers))
+
+    def put_bn(bn, prefix):
+        for k in ("running_mean", "running_var"):
+            getattr(bn, k).copy_(t[f"{prefix}.{k}"])
+        bn.weight.data.copy_(t[f"{prefix}.weight"])
+        bn.bias.data.copy_(t[f"{prefix}.bias"])
+
+    def put(lin, prefix):
+        lin.weight.data.copy_(t[f"{prefix}.w"])
+        lin.bias.data.copy_(t[f"{prefix}.b"])
+
+    n_enc = len(enc.encoder)
+    for i, layer in enumerate(enc.encoder):
+        put(layer.linear if hasattr(layer, "linear") else layer, f"enc.{i}")
+        if i < n_enc - 1:
+            put_bn(layer.batch_norm, f"enc.{i}.bn")
+    for li, L in enumerate(gnn.layers):
+        att = L.attention
+        put(att.self.query, f"gnn.{li}.q"), put(att.self.key, f"gnn.{li}.k"), put(att.self.value, f"gnn.{li}.v")
+        put(att.output.dense, f"gnn.{li}.o")
+        put(L.mlp[0].linear, f"gnn.{li}.mlp0"), put_bn(L.mlp[0].batch_norm, f"gnn.{li}.mlp0.bn"), put(L.mlp[1], f"gnn.{li}.mlp1")
+    put(fproj.final_proj, "final")
+    for m in (enc, gnn, fproj):
+        m.eval()
+    bin_score = torch.nn.Parameter(torch.tensor(0.7))
+    shell = types.SimpleNamespace(config=cfg, keypoint_encoder=enc, gnn=gnn, final_projection=fproj, bin_score=bin_score)
+    g = torch.Generator().manual_seed(seed + 1)
+    Himg, Wimg = 480, 640
+    kpts = torch.rand(B, 2, N, 2, generator=g) * torch.tensor([Wimg, Himg])
+    desc = torch.nn.functional.normalize(torch.randn(B, 2, N, D, generator=g), dim=-1)
+    desc[:, 1, :70] = torch.nn.functional.normalize(desc[:, 0, :70] + 0.02 * torch.randn(B, 70, D, generator=g), dim=-1)
+    sc = torch.rand(B, 2, N, generator=g)
+    with torch.no_grad():
+        matches, mscores, hidden, _ = HF.SuperGlueForKeypointMatching._match_image_pair(
+            shell, kpts, desc, sc, Himg, Wimg, mask=None, output_hidden_states=True)
+        proj = hidden[-1]
+        f0, f1 = proj[:, 0].transpose(-1, -2), proj[:, 1].transpose(-1, -2)
+        logZ = HF.log_optimal_transport(f0 @ f1.transpose(1, 2) / D ** 0.5, bin_score, cfg.sinkhorn_iterations)
+    out = {"seed": np.array(seed), "keypoints": kpts.numpy(), "descriptors_bnd": desc.numpy(), "kscores": sc.numpy(),
+           "image_hw": np.array([Himg, Wimg]), "layers": np.array(layers), "iters": np.array(cfg.sinkhorn_iterations),
+           "kenc": np.array(kenc), "heads": np.array(H), "bin_score": np.array(0.7, np.float32), "mdesc": proj.numpy(),
+           "logZ": logZ.numpy(), "matches": matches.numpy(), "matching_scores": mscores.numpy()}
+    np.savez_compressed(os.path.join(HERE, "superglue_hf_d256.npz"), **out)
+    print("superglue_hf_d256.npz", "matched:", int((matches[:, 0] >= 0).sum()))
+
+
 def gen_multi_view():
     """Multi-view back-end host logic: the reference's own bundle_adjust_io.py (imported unmodified) turns a 4-image
     tuple's matches into ``ba_init_in.csv`` and ``ba_in.csv``.  Absent third-party names it imports are provided in
@@ -382,11 +441,15 @@ if __name__ == "__main__":
     if "--superpoint" in sys.argv:
         gen_superpoint_hf()
         sys.exit(0)
+    if "--d256" in sys.argv:
+        gen_superglue_hf_d256()
+        sys.exit(0)
     if "--multi-view" in sys.argv:
         gen_multi_view()
         sys.exit(0)
     gen_sinkhorn_hf()
     gen_superglue_hf()
+    gen_superglue_hf_d256()
     gen_w8pt()
     gen_ba()
     gen_gt_matches()

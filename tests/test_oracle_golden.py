@@ -51,6 +51,43 @@ def test_matcher_matches_hf_port_small_model():
     assert torch.equal(out["conf_scores_0_1"][..., 0] > 0, matches[:, 0] >= 0)
 
 
+def load_hf_d256():
+    """(data dict, upstream-named state dict, config, golden arrays) of superglue_hf_d256.npz; weights re-created from the seed."""
+    import sys
+    sys.path.insert(0, G)
+    from hf_superglue_weights import seeded_hf_tensors, to_upstream_state
+    z = np.load(os.path.join(G, "superglue_hf_d256.npz"))
+    kenc, layers, H = [int(v) for v in z["kenc"]], [str(v) for v in z["layers"]], int(z["heads"])
+    de = torch.from_numpy(z["descriptors_bnd"])
+    D = de.shape[-1]
+    sd = to_upstream_state(seeded_hf_tensors(int(z["seed"]), D, kenc, len(layers)), D, H, len(kenc) + 1, len(layers), float(z["bin_score"]))
+    kp, sc = torch.from_numpy(z["keypoints"]), torch.from_numpy(z["kscores"])
+    Himg, Wimg = [int(v) for v in z["image_hw"]]
+    data = {"image_size0": (Himg, Wimg), "image_size1": (Himg, Wimg)}
+    for m in range(2):
+        data[f"keypoints{m}"] = kp[:, m]
+        data[f"scores{m}"] = sc[:, m]
+        data[f"descriptors{m}"] = de[:, m].transpose(1, 2).contiguous()  # upstream layout [B, D, N]
+    cfg = {"descriptor_dim": D, "num_heads": H, "keypoint_encoder": kenc, "GNN_layers": layers,
+           "sinkhorn_iterations": int(z["iters"]), "match_threshold": 0.0, "full_output": True}
+    return data, sd, cfg, z
+
+
+def test_matcher_matches_hf_port_at_the_real_width():
+    """D = 256, 4 heads of 64, keypoint encoder [32, 64, 128, 256] (the only width the HIP library supports): oracle vs the
+    HF port of upstream SuperGlue, weights reproduced from the fixture's seed."""
+    from oracle.matcher import matcher_forward
+    data, sd, cfg, z = load_hf_d256()
+    out = matcher_forward(data, sd, cfg)
+    mdesc = torch.from_numpy(z["mdesc"])
+    assert float((out["_mdesc"][0] - mdesc[:, 0]).abs().max()) < 5e-5
+    assert float((out["scores_0_1"] - torch.from_numpy(z["logZ"])).abs().max()) < 1e-4
+    matches = torch.from_numpy(z["matches"]).long()
+    assert torch.equal(out["matches0_0_1"], matches[:, 0]) and torch.equal(out["matches1_0_1"], matches[:, 1])
+    assert (matches[:, 0] >= 0).sum() > 50
+    assert float((out["matching_scores0_0_1"] - torch.from_numpy(z["matching_scores"])[:, 0]).abs().max()) < 1e-5
+
+
 @pytest.fixture(scope="module")
 def w8():
     return np.load(os.path.join(G, "w8pt_reference.npz"))
