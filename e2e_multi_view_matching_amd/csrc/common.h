@@ -94,6 +94,8 @@ struct e2emv_ctx {
     // partial results of the key-split attention (small problems), grown on demand
     float* d_attn_part = nullptr;
     size_t attn_part_bytes = 0;
+    // device flags: [0] give-up flag of the running resident Sinkhorn launch, [1] sticky count of give-ups
+    unsigned* d_flags = nullptr;
     // workspace arena
     char* d_ws = nullptr;
     size_t ws_bytes = 0;

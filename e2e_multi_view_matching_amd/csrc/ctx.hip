@@ -107,6 +107,7 @@ void e2emv_destroy(e2emv_ctx* ctx) {
     if (ctx->d_w3arena) (void)hipFree(ctx->d_w3arena);
     if (ctx->d_sparena) (void)hipFree(ctx->d_sparena);
     if (ctx->d_attn_part) (void)hipFree(ctx->d_attn_part);
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     for (auto& pe : ctx->prof_events) {
         (void)hipEventDestroy(pe.a);
         (void)hipEventDestroy(pe.b);
@@ -153,6 +154,15 @@ int e2emv_sync(e2emv_ctx* ctx, void* stream) {
     if (!ctx) return E2EMV_EINVAL;
     E2EMV_ENTER(ctx, stream);
     E2EMV_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    if (ctx->d_flags) {  // an inter-workgroup exchange that gave up poisoned its outputs with NaN: report it
+        unsigned f[2] = {0, 0};
+        E2EMV_HIP(ctx, hipMemcpy(f, ctx->d_flags, sizeof(f), hipMemcpyDeviceToHost));
+        if (f[1]) {
+            unsigned zero = 0;
+            (void)hipMemcpy(ctx->d_flags + 1, &zero, sizeof(zero), hipMemcpyHostToDevice);
+            return set_err(ctx, E2EMV_EHIP, "sinkhorn: %u inter-workgroup waits gave up (outputs of that call are NaN)", f[1]);
+        }
+    }
     return E2EMV_OK;
 }
 

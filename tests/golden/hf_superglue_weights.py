@@ -30,7 +30,7 @@ def seeded_hf_tensors(seed, D, kenc_sizes, n_layers):
         for k, v in bn(2 * D).items():
             t[f"gnn.{li}.mlp0.bn.{k}"] = v
         t[f"gnn.{li}.mlp1.w"], t[f"gnn.{li}.mlp1.b"] = lin(D, 2 * D)
-    t["final.w"], t["final.b"] = lin(D, D, scale=4.0)
+    t["final.w"], t["final.b"] = lin(D, D, scale=2.5)
     return t
 
 

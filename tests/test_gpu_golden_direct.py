@@ -87,7 +87,7 @@ def test_superglue_hf_golden_through_the_hip_path(gpu):
         assert float((out["scores_0_1"].cpu() - torch.from_numpy(z["logZ"])).abs().max()) < 1e-4, precision
         assert torch.equal(out["matches0_0_1"].cpu(), matches[:, 0]) and torch.equal(out["matches1_0_1"].cpu(), matches[:, 1])
         assert float((out["matching_scores0_0_1"].cpu() - ms[:, 0]).abs().max()) < 1e-5
-    assert (matches[:, 0] >= 0).sum() > 50
+    assert (matches[:, 0] >= 0).sum() > 30
 
 
 def test_pair_errors_and_auc_equal_the_oracle_chain_within_a_stated_bound(gpu):

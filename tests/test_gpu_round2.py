@@ -87,7 +87,10 @@ def test_tuple_batched_w8pt_equals_the_pair_loop(gpu, closest):
         assert torch.equal(ib["pos_depth_mask"], info["pos_depth_mask"]) and torch.equal(ib["confidence"], info["confidence"])
         assert torch.equal(ib["kpts1_norm"], info["kpts1_norm"]) and ib["confidence"].shape == (B, N, 1)
         assert ib["inliers"].dtype == torch.bool
-        assert float((Tb.cpu() - d[f"T_{i}to{j}"]).abs().max()) < 0.05     # and it is the right pose (up to scale of t)
+        Tg = d[f"T_{i}to{j}"]                                                # and it is the right pose (t up to scale)
+        assert float((Tb[:, :3, :3].cpu() - Tg[:, :3, :3]).abs().max()) < 0.02
+        tdir = torch.nn.functional.normalize(Tg[:, :3, 3], dim=-1)
+        assert float((Tb[:, :3, 3].cpu() * tdir).sum(-1).min()) > 0.99
     # a pair without matches in `result` -> per-pair path, (None, None) for that pair
     rg2 = {k: v for k, v in rg.items() if k != "matches0_0_1"}
     out2 = E.run_weighted_8_point_tuple(dg, rg2)

@@ -101,7 +101,9 @@ def test_errors(gpu):
     from e2e_multi_view_matching_amd.superpoint import SuperPoint
     sp = _model(gpu, max_keypoints=64)
     with pytest.raises(_lib.E2EMVError):
-        sp({"image": [torch.rand(1, 1, 100, 100, device=gpu)]})  # not a multiple of 8
+        sp({"image": [torch.rand(1, 1, 15, 100, device=gpu)]})   # floors to 8 x 96: below the encoder's 16-pixel minimum
+    out = sp({"image": [torch.rand(1, 1, 100, 100, device=gpu)]})  # not a multiple of 8: floored to 96 x 96 like upstream
+    assert float(out["keypoints"][0].max()) < 96
     with pytest.raises(AssertionError):
         sp({"image": [torch.rand(1, 3, 96, 96, device=gpu)]})
     with pytest.raises(RuntimeError):

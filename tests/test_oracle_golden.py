@@ -84,7 +84,7 @@ def test_matcher_matches_hf_port_at_the_real_width():
     assert float((out["scores_0_1"] - torch.from_numpy(z["logZ"])).abs().max()) < 1e-4
     matches = torch.from_numpy(z["matches"]).long()
     assert torch.equal(out["matches0_0_1"], matches[:, 0]) and torch.equal(out["matches1_0_1"], matches[:, 1])
-    assert (matches[:, 0] >= 0).sum() > 50
+    assert (matches[:, 0] >= 0).sum() > 30
     assert float((out["matching_scores0_0_1"] - torch.from_numpy(z["matching_scores"])[:, 0]).abs().max()) < 1e-5
 
 

@@ -1,0 +1,47 @@
+"""Development aid: per-phase timing of the resident Sinkhorn kernel (E2EMV_SKR_DEBUG timestamps, 100 MHz clock)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import e2e_multi_view_matching_amd as E  # noqa: E402
+
+
+def run(B, N, iters, flags, path):
+    os.environ["E2EMV_SKR_FLAGS"] = str(flags)
+    s = torch.randn(B, N, N, device="cuda") * 3
+    for _ in range(3):
+        E.log_optimal_transport(s, 1.0, iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        E.log_optimal_transport(s, 1.0, iters)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    os.environ["E2EMV_SKR_DEBUG"] = path
+    if os.path.exists(path):
+        os.remove(path)
+    E.log_optimal_transport(s, 1.0, iters)
+    torch.cuda.synchronize()
+    del os.environ["E2EMV_SKR_DEBUG"]
+    rows = np.loadtxt(path, comments="#").reshape(-1, 9)
+    t = rows[:, 2:].reshape(-1, int(rows[:, 1].max()) + 1, 7)  # [it][g][7]
+    t = t[2:14]  # steady-state iterations
+    d = np.diff(t, axis=2) * 10.0  # ns
+    names = ["rows+cols", "sync1", "fold+pubA", "stageA+pubB", "vN", "stageB poll", "sync2"]
+    per = d.mean(axis=(0, 1))
+    it_time = (t[1:, :, 0] - t[:-1, :, 0]).mean() * 10.0
+    print(f"B={B} N={N} flags={flags}: {dt * 1e3:.3f} ms/call incl. final+match ({dt / iters * 1e6:.2f} us/iter); "
+          f"iteration {it_time / 1e3:.2f} us = " + ", ".join(f"{n} {v / 1e3:.2f}" for n, v in zip(names[:6], per)) +
+          f"; spread of iteration start over workgroups {((t[:, :, 0].max(1) - t[:, :, 0].min(1)).mean()) * 10 / 1e3:.2f} us")
+
+
+if __name__ == "__main__":
+    for flags in (0, 1):
+        for B in (1, 16, 32):
+            run(B, 1024, 100, flags, "/tmp/skr.txt")
+    run(64, 256, 100, 0, "/tmp/skr.txt")
