@@ -237,6 +237,242 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(Attn3Params p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Same attention, fed with the fp32 q|k|v matrix of the projection GEMM ([n_img*n_rows][3D], the fp32 kernel's layout):
+// the three bf16 planes of Q (registers), K and V^T (LDS) are produced HERE, on the way in, instead of by the producing
+// GEMM.  The q|k|v GEMM then is an ordinary split-operand GEMM with a 4-byte-per-element output (201 MB per launch at
+// config 2) where the plane-emitting epilogue wrote 644 MB and ran on the fp32 matrix pipe; the price is that the
+// query tiles of one (image, head) each split the same K / V tiles again (VALU work next to a matrix-bound loop).
+// Numerics are those of attention3_kernel: q is scaled by log2(e)/sqrt(d) in fp32 before it is split.
+struct Attn3fParams {
+    const float* qkv;     // [n_img*n_rows][3D]  q | k | v, head-major channels
+    float* out32;         // [n_img*n_rows][D]
+    int B, T, n_rows, D, H, cross;
+    int nv[E2EMV_MAX_TUPLE];
+    int nq, groups, gper;
+    float q_scale;
+};
+
+__global__ __launch_bounds__(256, 2) void attention3f_kernel(Attn3fParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[3 * A3_PLANE];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[3 * A3_PLANE];
+
+    const int lin = blockIdx.x;
+    const int xcd = lin & 7, idx = lin >> 3;
+    const int g = xcd * p.gper + idx / p.nq;
+    if (g >= p.groups) return;
+    const int qt = idx % p.nq;
+    const int img = g / p.H, head = g % p.H;
+    const int b = img / p.T, t = img % p.T;
+    if (qt * A3_Q >= p.nv[t]) return;  // shorter image of a ragged tuple: no queries in this tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int64_t ld = 3 * (int64_t)p.D;  // floats per q|k|v row
+
+    // ---- Q fragments (B operand): lane (q, lh) holds Q_pl[q][16 s + 8 lh .. +7]
+    const int q_row = qt * A3_Q + wave * 32 + l31;
+    bf16x8 Qf[3][4];
+    {
+        const float* qp = p.qkv + ((int64_t)img * p.n_rows + q_row) * ld + head * A3_HD + lh * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(qp + s * 16), hi = *reinterpret_cast<const f32x4*>(qp + s * 16 + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 a, bb, c;
+                split3f((e < 4 ? lo[e] : hi[e - 4]) * p.q_scale, a, bb, c);
+                Qf[0][s][e] = a; Qf[1][s][e] = bb; Qf[2][s][e] = c;
+            }
+        }
+    }
+
+    f32x16 O0, O1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int n_src = p.cross ? p.T - 1 : 1;
+    auto src_t = [&](int si) { return !p.cross ? t : (si < t ? si : si + 1); };
+    int n_tiles = 0;
+    for (int si = 0; si < n_src; ++si) n_tiles += (p.nv[src_t(si)] + A3_KV - 1) / A3_KV;
+    auto locate = [&](int tile, int& tt, int& kt) {
+        int si = 0;
+        for (;; ++si) {
+            const int n = (p.nv[src_t(si)] + A3_KV - 1) / A3_KV;
+            if (tile < n || si + 1 == n_src) break;
+            tile -= n;
+        }
+        tt = src_t(si);
+        kt = tile;
+    };
+
+    // staging.  K tile (64 keys x 64 dims fp32): thread -> key row tid/4, 16 dims (tid&3)*16: 4 x 16 B, 64 B contiguous.
+    // V tile: thread -> a 4 keys x 4 dims block: key block kb = (lane>>2) (16 blocks), dims 16*wave + 4*(lane&3): 4 x 16 B
+    // from 4 consecutive key rows; after the split it owns, per dim, 4 consecutive keys = one 8-byte V^T write per plane.
+    const int k_row = tid >> 2, k_c16 = (tid & 3) * 16;
+    const int v_kb = lane >> 2, v_d0 = 16 * wave + 4 * (lane & 3);
+    // V^T LDS position of keys 4 kb .. 4 kb + 3 inside their 16-key group (permuted order, see the header)
+    const int v_lds = 16 * (v_kb >> 2) + 4 * ((v_kb & 3) >> 1) + 8 * (v_kb & 1);
+    f32x4 rk[4], rv[4];
+    auto gload = [&](int tile) {
+        int tt, kt;
+        locate(tile, tt, kt);
+        const float* base = p.qkv + ((int64_t)(b * p.T + tt) * p.n_rows + kt * A3_KV) * ld + head * A3_HD;
+        const float* kp = base + p.D + (int64_t)k_row * ld + k_c16;
+        const float* vp = base + 2 * p.D + (int64_t)(4 * v_kb) * ld + v_d0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rk[i] = *reinterpret_cast<const f32x4*>(kp + 4 * i);
+            rv[i] = *reinterpret_cast<const f32x4*>(vp + (int64_t)i * ld);
+        }
+    };
+    auto lstore = [&]() {
+        // K: 16 values -> 3 planes x 32 B
+        bf16x8 kh[3][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 a, bb, c;
+                split3f(rk[i][e], a, bb, c);
+                kh[0][i >> 1][(i & 1) * 4 + e] = a; kh[1][i >> 1][(i & 1) * 4 + e] = bb; kh[2][i >> 1][(i & 1) * 4 + e] = c;
+            }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            uint16_t* kd = &Ks[pl * A3_PLANE + k_row * A3_LD + k_c16];
+            *reinterpret_cast<bf16x8*>(kd) = kh[pl][0];
+            *reinterpret_cast<bf16x8*>(kd + 8) = kh[pl][1];
+        }
+        // V^T: rv[i][e] = V[key 4 kb + i][dim d0 + e]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bf16x4 vh[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __bf16 a, bb, c;
+                split3f(rv[i][e], a, bb, c);
+                vh[0][i] = a; vh[1][i] = bb; vh[2][i] = c;
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<bf16x4*>(&Vs[pl * A3_PLANE + (v_d0 + e) * A3_LD + v_lds]) = vh[pl];
+        }
+    };
+
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};  // plane of the A operand (K or V^T), smallest terms first
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};  // plane of the B operand (Q or P)
+
+    gload(0);
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (tile + 1 < n_tiles) gload(tile + 1);
+
+        int tt_cur, kt;
+        locate(tile, tt_cur, kt);
+        const int valid_in_tile = p.nv[tt_cur] - kt * A3_KV;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (sub * 32 >= valid_in_tile) break;
+            f32x16 S;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[r] = 0.f;
+            const uint16_t* kp = &Ks[(sub * 32 + l31) * A3_LD + lh * 8];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 kf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const bf16x8*>(kp + pl * A3_PLANE + s * 16);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA[q]], Qf[PB[q]][s], S, 0, 0, 0);
+            }
+            if (valid_in_tile < sub * 32 + 32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= valid_in_tile) S[r] = -INFINITY;
+                }
+            }
+            float mx = S[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float ps = 0.f;
+            bf16x8 Pf[3][2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(S[r] - m_new);
+                ps += pv;
+                __bf16 a, bb, c;
+                split3f(pv, a, bb, c);
+                Pf[0][r >> 3][r & 7] = a;
+                Pf[1][r >> 3][r & 7] = bb;
+                Pf[2][r >> 3][r & 7] = c;
+            }
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { O0[r] *= alpha; O1[r] *= alpha; }
+            const uint16_t* vp = &Vs[l31 * A3_LD + lh * 8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bf16x8 v0[3], v1[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    v0[pl] = *reinterpret_cast<const bf16x8*>(vp + pl * A3_PLANE + 16 * (2 * sub + u));
+                    v1[pl] = *reinterpret_cast<const bf16x8*>(vp + pl * A3_PLANE + 32 * A3_LD + 16 * (2 * sub + u));
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0[PA[q]], Pf[PB[q]][u], O0, 0, 0, 0);
+                    O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1[PA[q]], Pf[PB[q]][u], O1, 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    float* op = p.out32 + ((int64_t)img * p.n_rows + q_row) * p.D + head * A3_HD + 4 * lh;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        f32x4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = O0[gq * 4 + e] * inv; c[e] = O1[gq * 4 + e] * inv; }
+        *reinterpret_cast<f32x4*>(op + 8 * gq) = a;
+        *reinterpret_cast<f32x4*>(op + 32 + 8 * gq) = c;
+    }
+}
+
+int launch_attention3f(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, int D, int H, const float* qkv, int cross,
+                       float* out32, hipStream_t s) {
+    int n_valid = 0;
+    for (int t = 0; t < T; ++t) {
+        if (nv[t] <= 0 || nv[t] > n_rows) return set_err(ctx, E2EMV_ESHAPE, "attention3f: image %d has %d keypoints (n_rows %d)", t, nv[t], n_rows);
+        n_valid = std::max(n_valid, nv[t]);
+    }
+    if (D != H * A3_HD) return set_err(ctx, E2EMV_ESHAPE, "attention3f: head dim must be 64 (D=%d H=%d)", D, H);
+    if (n_rows % A3_Q || n_valid <= 0 || n_valid > n_rows)
+        return set_err(ctx, E2EMV_ESHAPE, "attention3f: n_rows=%d must be a multiple of %d and >= n_valid=%d", n_rows, A3_Q, n_valid);
+    if (cross && T < 2) return set_err(ctx, E2EMV_ESHAPE, "attention3f: cross layer needs T >= 2");
+    if (!qkv || !out32 || (uintptr_t)qkv % 16 || (uintptr_t)out32 % 16) return set_err(ctx, E2EMV_EINVAL, "attention3f: null / unaligned buffer");
+    Attn3fParams p;
+    p.qkv = qkv; p.out32 = out32; p.B = B; p.T = T; p.n_rows = n_rows; p.D = D; p.H = H;
+    for (int t = 0; t < E2EMV_MAX_TUPLE; ++t) p.nv[t] = t < T ? nv[t] : 0;
+    p.cross = cross;
+    p.nq = (n_valid + A3_Q - 1) / A3_Q;
+    p.groups = B * T * H;
+    p.gper = (p.groups + 7) / 8;
+    p.q_scale = 0.125f * 1.4426950408889634f;  // log2(e) / sqrt(64)
+    hipLaunchKernelGGL(attention3f_kernel, dim3(8 * p.gper * p.nq), dim3(256), 0, s, p);
+    E2EMV_CHECK_LAUNCH(ctx, "attention3f_kernel");
+    return E2EMV_OK;
+}
+
 int launch_attention3(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, int D, int H, const uint16_t* qk,
                       const uint16_t* vt, int cross, uint16_t* out3, float* out32, hipStream_t s) {
     int n_valid = 0;

@@ -73,6 +73,7 @@ struct e2emv_ctx {
     uint16_t* d_w3arena = nullptr;
     size_t w3arena_elems = 0;
     int precision = 0;  // E2EMV_PRECISION_F32 | E2EMV_PRECISION_BF16X3 (dense GNN contractions)
+    bool b3_planes = false;  // bf16x3 mode: q|k|v handed to the attention as planes from the GEMM epilogue (E2EMV_B3_PLANES=1)
     // keypoint encoder: layer 0 (3->c0) used by the ingest kernel, the rest through the GEMM
     float* kenc_w0 = nullptr;  // [c0][3] folded
     float* kenc_b0 = nullptr;  // [c0]
@@ -214,6 +215,9 @@ int launch_gemm3(e2emv_ctx* ctx, const Gemm3Args& a, hipStream_t s);
 int launch_gemm_x3(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* W3, int64_t ldw3, hipStream_t s);
 int launch_split3(e2emv_ctx* ctx, const float* src, int64_t rows, int C, int64_t ld_src, uint16_t* dst, int64_t ld,
                   hipStream_t s);
+// the same attention fed with the fp32 q|k|v matrix (planes produced inside the kernel)
+int launch_attention3f(e2emv_ctx* ctx, int B, int T, int n_rows, const int* n_valid_img, int D, int H, const float* qkv,
+                       int cross, float* out32, hipStream_t s);
 int launch_attention3(e2emv_ctx* ctx, int B, int T, int n_rows, const int* n_valid_img, int D, int H, const uint16_t* qk,
                       const uint16_t* vt, int cross, uint16_t* out3, float* out32, hipStream_t s);
 

@@ -93,6 +93,7 @@ int e2emv_create(e2emv_ctx** out, int device) {
     ctx->device = device;
     ctx->num_cus = p.multiProcessorCount;
     if (const char* e = getenv("E2EMV_NO_FUSE_MERGE")) ctx->fuse_merge = !(e[0] == '1');
+    if (const char* e = getenv("E2EMV_B3_PLANES")) ctx->b3_planes = e[0] == '1';
     if (const char* e = getenv("E2EMV_PRECISION")) ctx->precision = (strcmp(e, "bf16x3") == 0) ? E2EMV_PRECISION_BF16X3 : E2EMV_PRECISION_F32;
     *out = ctx;
     return E2EMV_OK;

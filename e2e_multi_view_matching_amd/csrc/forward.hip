@@ -234,8 +234,19 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         const LayerWeights& L = ctx->layers[l];
         GemmArgs g;
         if (b3) {
-            // q|k|v by the fp32 GEMM, emitted as bf16x3 planes (q|k as S3 with the softmax scale folded into q,
-            // V transposed for the P.V MFMA); attention itself runs on the bf16 pipe with 6-term split products
+            // q|k|v on the split-operand GEMM with a plain fp32 output; the attention kernel splits Q / K / V^T into
+            // bf16 planes on the way in (E2EMV_B3_PLANES=1 selects the first-generation hand-over: fp32-pipe GEMM whose
+            // epilogue emits the planes, 3.2x the bytes)
+            if (!ctx->b3_planes) {
+                g = GemmArgs();
+                g.M = (int)Mtot; g.N = 3 * D; g.K = D; g.K1 = D; g.A = x; g.lda = D; g.bias = L.b_qkv; g.C = qkv; g.ldc = 3 * D;
+                prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_x3(ctx, g, L.w3_qkv, D, s); prof_end(ctx, s);
+                if (rc) return rc;
+                prof_begin(ctx, PS_ATTN, s);
+                rc = launch_attention3f(ctx, B, T, n_rows, Nt, D, H, qkv, L.type, att, s);
+                prof_end(ctx, s);
+                if (rc) return rc;
+            } else {
             g = GemmArgs();
             g.M = (int)Mtot; g.N = 3 * D; g.K = D; g.K1 = D; g.A = x; g.lda = D; g.W = L.w_qkv; g.ldw = D; g.bias = L.b_qkv;
             g.C3 = qk3; g.ldc3 = 2 * D; g.Vt = vt3; g.vt_n0 = 2 * D; g.n_rows = n_rows;
@@ -246,6 +257,7 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
             rc = launch_attention3(ctx, B, T, n_rows, Nt, D, H, qk3, vt3, L.type, nullptr, att, s);
             prof_end(ctx, s);
             if (rc) return rc;
+            }
         } else {
         // q|k|v = x Wqkv^T + b
         g = GemmArgs();
