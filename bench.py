@@ -399,14 +399,21 @@ def run(args):
     if not args.no_profile and not stub:
         bare = timed_steps(args.steps)
 
-    # ---- second measurement: the same workload in the other arithmetic mode (reported separately)
+    # ---- second measurement: the same workload in the other arithmetic mode (reported separately, with its own kernel
+    # family times and roofline)
     alt = None
+    alt_prof = None
     if not args.no_alt and not stub:
         other = "bf16x3" if mode == "f32" else "f32"
         wl.set_precision(other)
         for _ in range(2):
             wl.step()
+        wl.sync()
+        if not args.no_profile:
+            wl.profile(True)
         alt_elapsed = timed_steps(args.steps)
+        if not args.no_profile:
+            alt_prof = wl.profile(False)
         wl.set_precision(mode)
         alt = {"mode": other, "ms_per_step": round(1000.0 * alt_elapsed / args.steps, 3),
                "value": round(B * P * world * args.steps / alt_elapsed, 2), "unit": "pairs/s"}
@@ -494,53 +501,61 @@ def run(args):
         out["batch1_latency"] = latency
 
     # ---- roofline of the dominant kernel family, from HIP events recorded in the timed region
-    if prof:
+    def roofline_of(prof_, mode_):
         fl = algorithmic_flops(B, T, N, D, args.layers, True)
-        fam = max(("gemm", "attention"), key=lambda k: prof[k]["ms"])
+        fam = max(("gemm", "attention"), key=lambda k: prof_[k]["ms"])
         kname = {"f32": {"gemm": "gemm_nt_kernel", "attention": "attention_kernel"},
-                 "bf16x3": {"gemm": "gemm_x3_kernel", "attention": "attention3_kernel"}}[mode][fam]
+                 "bf16x3": {"gemm": "gemm_x3_kernel", "attention": "attention3f_kernel"}}[mode_][fam]
         # f32 mode: exact fp32 MFMA.  bf16x3 mode: every algorithmic flop is 6 bf16-MFMA flops, so the ceiling for
         # ALGORITHMIC flops is the dense bf16 peak / 6.
-        peak = PEAK_F32_MFMA_TFLOPS if mode == "f32" else PEAK_BF16_MFMA_TFLOPS / 6.0
+        peak = PEAK_F32_MFMA_TFLOPS if mode_ == "f32" else PEAK_BF16_MFMA_TFLOPS / 6.0
 
         def family(f):
-            ms, n = prof[f]["ms"], prof[f]["launches"]
+            ms, n = prof_[f]["ms"], prof_[f]["launches"]
             return fl[f] * args.steps / (ms * 1e-3) / 1e12, ms, n
         achieved, ms, n = family(fam)
         # HBM bytes per launch of that kernel from the rocprofv3 --pmc passes of this same command (FETCH_SIZE x 2 per
-        # MI355X_MICROARCH.md, calibrated on the Sinkhorn sweep's known byte count) - profiles/summarize_pmc.py
+        # MI355X_MICROARCH.md, calibrated on a kernel with a known byte count) - profiles/summarize_pmc.py
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 pj = json.load(fh)
-            if pj.get("workload_key", "c2") == args.config and pj.get("mode", "f32") == mode:
-                k = pj["kernels"][kname]
-                traffic = int(k["read_bytes"] + k["write_bytes"])
+            k = pj["workloads"][args.config][mode_]["kernels"][kname]
+            traffic = int(k["read_bytes"] + k["write_bytes"])
         except Exception:
             traffic = None
-        out["roofline"] = {"bound": "mfma", "kernel": kname,
-                           "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                           "frac": round(achieved / peak, 4), "traffic": traffic,
-                           "note": ("algorithmic flops of the family / HIP-event time; " +
-                                    ("exact fp32 MFMA (v_mfma_f32_32x32x2_f32)" if mode == "f32" else
-                                     "peak = dense bf16 MFMA 2500 TFLOP/s / 6 products per algorithmic flop")) +
-                                   "; traffic = HBM bytes per launch (read + write) from the PMC passes under profiles/",
-                           "avg_launch_ms": round(ms / max(n, 1), 4), "launches_per_step": n // args.steps}
+        main = {"bound": "mfma", "kernel": kname, "mode": mode_,
+                "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "note": ("algorithmic flops of the family / HIP-event time; " +
+                         ("exact fp32 MFMA (v_mfma_f32_32x32x2_f32)" if mode_ == "f32" else
+                          "peak = dense bf16 MFMA 2500 TFLOP/s / 6 MFMA products per algorithmic flop (3-way split operands)")) +
+                        "; traffic = HBM bytes per launch (read + write) from the PMC passes under profiles/",
+                "avg_launch_ms": round(ms / max(n, 1), 4), "launches_per_step": n // args.steps}
         fam2 = "attention" if fam == "gemm" else "gemm"
         a2, _, _ = family(fam2)
-        out["roofline_second"] = {"kernel": fam2, "achieved": round(a2, 2), "unit": "TFLOP/s", "frac": round(a2 / peak, 4)}
-        out["families"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["launches"] // args.steps}
-                           for k, v in prof.items() if v["launches"]}
+        second = {"kernel": fam2, "achieved": round(a2, 2), "unit": "TFLOP/s", "frac": round(a2 / peak, 4)}
+        fams = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["launches"] // args.steps}
+                for k, v in prof_.items() if v["launches"]}
+        return main, second, fams
+
+    if prof:
+        out["roofline"], out["roofline_second"], out["families"] = roofline_of(prof, mode)
         sk = prof["sinkhorn"]
         if sk["ms"] > 0:
             model_bytes = B * P * (2 * args.sinkhorn_iters + 2) * (N + 1) ** 2 * 4
             gbs = model_bytes * args.steps / (sk["ms"] * 1e-3) / 1e9
-            out["sinkhorn_roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                        "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                        "note": "SURVEY 8(d) byte model (2 sweeps of the couplings per iteration) / time; the "
-                                                "resident kernel reads the scores once per CALL (they stay in registers for "
-                                                "all iterations), the streaming fallback once per iteration - physical HBM "
-                                                "bytes are in profiles/"}
+            physical = B * P * 2 * N * N * 4 + B * P * (N + 1) ** 2 * 4  # scores read by the resident kernel and by the final sweep, logZ written
+            out["sinkhorn_roofline"] = {"bound": "hbm (model) / on-chip exchange latency (resident kernel)", "achieved": round(gbs, 1),
+                                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                        "physical_hbm_gbs": round(physical * args.steps / (sk["ms"] * 1e-3) / 1e9, 1),
+                                        "note": "achieved = SURVEY 8(d) byte model (2 sweeps of the couplings per iteration) / time - "
+                                                "above the HBM peak by construction: the resident kernel keeps exp(S - rowmax) in "
+                                                "registers for all iterations and reads the scores from HBM once (plus once in the "
+                                                "final sweep that writes logZ): physical_hbm_gbs is that traffic / time; the kernel is "
+                                                "bound by the per-iteration exchange between the workgroups of a problem (profiles/)"}
+    if alt and alt_prof:
+        alt["roofline"], alt["roofline_second"], alt["families"] = roofline_of(alt_prof, alt["mode"])
 
     # ---- CPU baseline: the oracle (torch CPU, same unfused op sequence as the reference) on a bounded sample
     if world == 1 and args.cpu_pairs > 0 and not stub:

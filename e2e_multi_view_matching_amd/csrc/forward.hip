@@ -155,7 +155,10 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
     const size_t sz_S = al((size_t)P * B * N * ldS * 4);
     const size_t sz_sk = sinkhorn_ws_bytes(P * B, N, N);
     const size_t sz_match = full ? (size_t)P * (al((size_t)B * N * 8) + al((size_t)B * N * 4)) : 0;
-    const bool b3 = ctx->precision == E2EMV_PRECISION_BF16X3 && ctx->fuse_merge;
+    // bf16x3 (split operands on the bf16 pipe) pays once the 128-row GEMM tiles fill the chip; calls below half a tile per
+    // CU (a pair or two - the eval_pairs.py loop) run the fp32-MFMA kernels, whose 64 x 64 tile shape and key-split
+    // attention are the latency-tuned forms.  Both arithmetic modes meet the same parity bar.
+    const bool b3 = ctx->precision == E2EMV_PRECISION_BF16X3 && ctx->fuse_merge && Mtot / 128 >= ctx->num_cus / 2;
     // bf16x3 attention path: x as S3 planes (6D bytes/row) and V^T planes (6D bytes/row); the q|k planes
     // (S3, 2D wide = 12D bytes/row) live in the fp32 q|k|v buffer, which has exactly that size
     const size_t sz_x3 = b3 ? al((size_t)Mtot * 3 * D * 2) : 0;

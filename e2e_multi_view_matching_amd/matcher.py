@@ -39,9 +39,9 @@ DEFAULT_CONFIG = {
     "tuple_size": 2,
     "conf_mlp": False,
     "full_output": False,
-    # arithmetic of the dense q|k|v + attention contractions: "f32" (fp32 MFMA) or "bf16x3" (fp32 operands
-    # split into three bf16 planes, 6 bf16-MFMA products, fp32 accumulate - fp32-class accuracy).  None = the
-    # library default (environment variable E2EMV_PRECISION, else "f32").
+    # arithmetic of the dense GNN contractions: "f32" (exact fp32 MFMA) or "bf16x3" (fp32 operands split into three
+    # bf16 planes, 6 bf16-MFMA products, fp32 accumulate - fp32-class accuracy).  None = the library default
+    # (environment variable E2EMV_PRECISION, else "bf16x3").
     "mfma_precision": None,
 }
 

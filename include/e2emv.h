@@ -295,11 +295,11 @@ int e2emv_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D
                     int cross, float* d_out, void* stream);
 
 /* ---- arithmetic of the dense GNN contractions -----------------------------------------
- * E2EMV_PRECISION_F32    : v_mfma_f32_32x32x2_f32, exact fp32 products (default).
+ * E2EMV_PRECISION_F32    : v_mfma_f32_32x32x2_f32, exact fp32 products (the audit mode).
  * E2EMV_PRECISION_BF16X3 : fp32 operands split into three bf16 planes, six bf16 MFMA products per
  *                          block accumulated in fp32 - fp32-class rounding (|err| ~ 2^-24 per
  *                          product) at 2.67x the fp32-MFMA ceiling.  Same API, same outputs within
- *                          the 1e-4 parity bar (tests/test_gpu_matcher.py runs both).
+ *                          the 1e-4 parity bar (tests/test_gpu_matcher.py runs both).  DEFAULT since round 2.
  * Also selectable with the environment variable E2EMV_PRECISION=f32|bf16x3 read at e2emv_create. */
 #define E2EMV_PRECISION_F32 0
 #define E2EMV_PRECISION_BF16X3 1

@@ -23,14 +23,15 @@ def per_kernel(db_path, counters):
     return out
 
 
-def main(sq_db, fetch_db, write_db, out_md, out_json):
+def main(sq_db, fetch_db, write_db, out_md, out_json, config="c2", mode="f32", pairs=32, n_kpts=1024):
+    pairs, n_kpts = int(pairs), int(n_kpts)
     sq = per_kernel(sq_db, {"SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY",
                             "SQ_ACTIVE_INST_ANY"})
     fe = per_kernel(fetch_db, {"FETCH_SIZE"})
     wr = per_kernel(write_db, {"WRITE_SIZE"})
     lines = ["| kernel | launches | avg us (PMC run) | FETCH_SIZE KiB (raw) | HBM read MB (x2) | HBM write MB | MFMA busy % | clock GHz |",
              "|---|---|---|---|---|---|---|---|"]
-    js = {"unit": "bytes per launch (average over the launches of one bench.py run)", "kernels": {}}
+    js = {"kernels": {}}
     for k in sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, {}).get("FETCH_SIZE", (0, 0, 0))[1])):
         n, f, dur = fe.get(k, {}).get("FETCH_SIZE", (0, 0.0, 0.0))
         _, w, _ = wr.get(k, {}).get("WRITE_SIZE", (0, 0.0, 0.0))
@@ -48,11 +49,19 @@ def main(sq_db, fetch_db, write_db, out_md, out_json):
     open(out_md, "w").write("# rocprofv3 --pmc passes (separate runs: SQ+GRBM, FETCH_SIZE, WRITE_SIZE), bench.py --steps 2 --warmup 1\n\n"
                             + text + "\n")
     sw = js["kernels"].get("sinkhorn_sweep")
-    if sw:
-        known = 32 * 1024 * 1024 * 4 + 32 * 1028 * 4
-        js["calibration"] = {"kernel": "sinkhorn_sweep<4,false,true>", "known_read_bytes": known,
+    if sw:  # round 2: the only sweep left on the resident path is the FINAL one, which reads every score exactly once
+        known = pairs * n_kpts * n_kpts * 4 + pairs * (2 * n_kpts + 8) * 4
+        js["calibration"] = {"kernel": "sinkhorn_sweep<FINAL>", "known_read_bytes": known,
                              "measured_read_bytes_x2": sw["read_bytes"], "ratio": sw["read_bytes"] / known}
-    json.dump(js, open(out_json, "w"), indent=1)
+    try:
+        allj = json.load(open(out_json))
+        if "workloads" not in allj:
+            allj = {}
+    except Exception:
+        allj = {}
+    allj.setdefault("unit", "HBM bytes per launch (average over the launches of one bench.py run); FETCH_SIZE x 2 per MI355X_MICROARCH.md")
+    allj.setdefault("workloads", {}).setdefault(config, {})[mode] = js
+    json.dump(allj, open(out_json, "w"), indent=1)
     print(text)
 
 

@@ -20,14 +20,15 @@ def test_two_models_alternating_on_one_device_keep_their_own_weights(gpu):
     torch.manual_seed(1)
     A = MultiViewMatcher(cfg).eval().to(gpu)
     torch.manual_seed(2)
-    B = MultiViewMatcher({**cfg, "mfma_precision": "bf16x3"}).eval().to(gpu)
-    data = _dev(make_tuples(batch=1, tuple_size=2, n_kpts=128, seed=0), gpu)
     ctx = _lib.context(gpu)
+    other = _lib.PRECISION_F32 if ctx.default_precision == _lib.PRECISION_BF16X3 else _lib.PRECISION_BF16X3
+    B = MultiViewMatcher({**cfg, "mfma_precision": {_lib.PRECISION_F32: "f32", _lib.PRECISION_BF16X3: "bf16x3"}[other]}).eval().to(gpu)
+    data = _dev(make_tuples(batch=1, tuple_size=2, n_kpts=128, seed=0), gpu)
     with torch.no_grad():
         a1 = A(data)["scores_0_1"].clone()
         assert ctx.precision() == ctx.default_precision
         b1 = B(data)["scores_0_1"].clone()
-        assert ctx.precision() == _lib.PRECISION_BF16X3
+        assert ctx.precision() == other
         a2 = A(data)["scores_0_1"].clone()
         assert ctx.precision() == ctx.default_precision          # A did not inherit B's mode
         b2 = B(data)["scores_0_1"].clone()
