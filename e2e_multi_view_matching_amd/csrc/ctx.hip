@@ -164,7 +164,8 @@ int e2emv_sync(e2emv_ctx* ctx, void* stream) {
         if (f[1]) {
             unsigned zero = 0;
             (void)hipMemcpy(ctx->d_flags + 1, &zero, sizeof(zero), hipMemcpyHostToDevice);
-            return set_err(ctx, E2EMV_EHIP, "sinkhorn: %u inter-workgroup waits gave up (outputs of that call are NaN)", f[1]);
+            return set_err(ctx, E2EMV_EHIP, "sinkhorn (resident kernel): %u problems left fp32's range or gave up an inter-workgroup "
+                           "wait - their outputs are NaN/inf; E2EMV_SINKHORN=stream runs the log-domain launch chain", f[1]);
         }
     }
     return E2EMV_OK;

@@ -467,17 +467,21 @@ __global__ __launch_bounds__(kMvThreads) void mvba_kernel(MvbaArgs a) {
                     s_state[0] = 1; s_state[2] = kTermParameter;
                 } else {
                     const double change = cost - cand_cost, rho = change / model;
-                    if (rho > 1e-3) {
-                        s_ctl[6] = 1.0;
-                        s_ctl[2] = cand_cost;
-                        s_ctl[0] = fmin(1e16, s_ctl[0] / fmax(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) * (2.0 * rho - 1.0) * (2.0 * rho - 1.0)));
-                        s_ctl[1] = 2.0;
+                    if (fabs(change) <= 1e-6 * cost) {
+                        // Ceres checks the function tolerance before the accept test: the iterate stays where it was
+                        s_state[0] = 1; s_state[2] = kTermFunction;
                     } else {
-                        s_ctl[0] /= s_ctl[1];
-                        s_ctl[1] *= 2.0;
+                        if (rho > 1e-3) {
+                            s_ctl[6] = 1.0;
+                            s_ctl[2] = cand_cost;
+                            s_ctl[0] = fmin(1e16, s_ctl[0] / fmax(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) * (2.0 * rho - 1.0) * (2.0 * rho - 1.0)));
+                            s_ctl[1] = 2.0;
+                        } else {
+                            s_ctl[0] /= s_ctl[1];
+                            s_ctl[1] *= 2.0;
+                        }
+                        if (s_ctl[0] < 1e-32) { s_state[0] = 1; s_state[2] = kTermRadius; }
                     }
-                    if (fabs(change) <= 1e-6 * cost) { s_state[0] = 1; s_state[2] = kTermFunction; }
-                    else if (s_ctl[0] < 1e-32) { s_state[0] = 1; s_state[2] = kTermRadius; }
                 }
             }
         }

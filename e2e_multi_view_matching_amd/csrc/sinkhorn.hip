@@ -405,8 +405,23 @@ __global__ __launch_bounds__(256) void match_finalize(MatchParams p) {
             const int64_t o = (int64_t)b * p.chunks * p.ldS + j;
             float bm = p.pv[o];
             int bi = p.pi[o];
-            for (int ch = 1; ch < p.chunks; ++ch) {  // chunks own increasing rows: strict > keeps the first
-                float m = p.pv[o + (int64_t)ch * p.ldS];
+            // chunks own increasing rows: strict > keeps the first.  Both arrays are read unconditionally, 8 chunks at a
+            // time, so the loads of a group are in flight together (the loop used to be one dependent L2 round trip per chunk)
+            int ch = 1;
+            for (; ch + 8 <= p.chunks; ch += 8) {
+                float m[8];
+                int ix[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    m[q] = p.pv[o + (int64_t)(ch + q) * p.ldS];
+                    ix[q] = p.pi[o + (int64_t)(ch + q) * p.ldS];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (m[q] > bm) { bm = m[q]; bi = ix[q]; }
+            }
+            for (; ch < p.chunks; ++ch) {
+                const float m = p.pv[o + (int64_t)ch * p.ldS];
                 if (m > bm) { bm = m; bi = p.pi[o + (int64_t)ch * p.ldS]; }
             }
             i1[j] = bi;

@@ -234,7 +234,11 @@ def solve(prob, max_iterations=50, function_tolerance=1e-6, gradient_tolerance=1
         r2, Jc2, Jp2 = linearise(prob, cand_c, cand_p)
         cand_cost = 0.5 * float((r2 * r2).sum())
         change = cost - cand_cost
-        small = abs(change) <= function_tolerance * cost
+        # Ceres tests the function tolerance BEFORE it accepts the step (TrustRegionMinimizer::Minimize: ParameterTolerance-
+        # Reached, FunctionToleranceReached, then IsStepSuccessful): the iterate stays at the previous point
+        if abs(change) <= function_tolerance * cost:
+            summary["termination"] = "function_tolerance"
+            break
         rho = change / model_change
         if rho > 1e-3:
             cams, pts, r, Jc, Jp, cost = cand_c, cand_p, r2, Jc2, Jp2, cand_cost
@@ -243,9 +247,6 @@ def solve(prob, max_iterations=50, function_tolerance=1e-6, gradient_tolerance=1
         else:
             radius /= decrease
             decrease *= 2.0
-        if small:
-            summary["termination"] = "function_tolerance"
-            break
         if radius < 1e-32:
             summary["termination"] = "radius"
             break

@@ -98,3 +98,36 @@ def test_exchange_under_uneven_load(gpu):
         out = E.log_optimal_transport(s, 1.0, 40)
         assert torch.equal(out, quiet), rep
     torch.cuda.synchronize()
+
+
+def test_dynamic_range_of_the_exponential_domain(gpu):
+    """The resident kernel iterates a = exp(u + rowmax), b = exp(v) instead of log-sum-exps.  Measured against an fp64
+    oracle it is MORE accurate than the fp32 log-domain forms up to |logZ| ~ 700 (scores spread over hundreds of nats);
+    when a scaling finally leaves fp32's range the outputs turn non-finite and e2emv_sync reports it - and the streaming
+    chain (E2EMV_SINKHORN=stream) still solves such inputs."""
+    import e2e_multi_view_matching_amd as E
+    from e2e_multi_view_matching_amd import _lib
+    from oracle.sinkhorn import log_optimal_transport
+    ctx = _lib.context(gpu)
+    for scale, bar in ((10.0, 1e-4), (40.0, 1e-4)):
+        s = _scores(2, 300, 280, int(scale), scale=scale)
+        ref = log_optimal_transport(s.double(), 1.0, 100).float()
+        out = E.log_optimal_transport(s.to(gpu), 1.0, 100).cpu()
+        assert float((out - ref).abs().max()) < bar, scale
+        assert torch.equal(out[:, :-1, :-1].argmax(2), ref[:, :-1, :-1].argmax(2))
+        assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK
+    s = _scores(2, 300, 280, 160, scale=160.0)  # |logZ| > 1200: far outside anything a descriptor network produces
+    out = E.log_optimal_transport(s.to(gpu), 1.0, 100)
+    rc = ctx.lib.e2emv_sync(ctx.h, None)
+    if bool(torch.isfinite(out).all()):
+        assert rc == _lib.OK
+    else:
+        assert rc == _lib.EHIP and b"range" in ctx.lib.e2emv_last_error(ctx.h)   # loud, not silent
+        assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK                         # the report is consumed once
+    try:
+        _stream_mode(True)
+        out = E.log_optimal_transport(s.to(gpu), 1.0, 100).cpu()
+    finally:
+        _stream_mode(False)
+    ref = log_optimal_transport(s.double(), 1.0, 100).float()
+    assert bool(torch.isfinite(out).all()) and float((out - ref).abs().max()) < 5e-3  # fp32 log domain at |logZ| ~ 1200
