@@ -61,7 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--desc", choices=["f32", "f16"], default=None, help="descriptor dtype handed to the matcher")
     ap.add_argument("--gnn", default="9x1", help="GNN schedule gxc = (['self'] + ['cross']*c) * g (train.py:263-268): "
                     "9x1 two-view / MegaDepth, 7x3 multi-view ScanNet")
-    ap.add_argument("--precision", choices=["default", "f32", "bf16x3"], default="default",
+    ap.add_argument("--precision", choices=["default", "f32", "bf16x3", "f16x2"], default="default",
                     help="arithmetic of the dense contractions for the timed region (default = the library default)")
     ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs of the workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernel families with HIP events")
@@ -175,7 +175,7 @@ class HipWorkload:
         self.ctx.set_precision(name)  # explicit override for every model on this device that does not pin its own
 
     def precision(self):
-        return {self._lib.PRECISION_F32: "f32", self._lib.PRECISION_BF16X3: "bf16x3"}[self.ctx.precision()]
+        return {v: k for k, v in self._lib.PRECISION_NAMES.items()}[self.ctx.precision()]
 
     def step(self, model=None, data=None):
         E, torch = self.E, self.torch
@@ -481,7 +481,8 @@ def run(args):
     pairs_per_step = B * P * world
     value = pairs_per_step * args.steps / elapsed
     dtype = {"f32": "f32", "bf16x3": "bf16x3 (fp32 operands split into 3 bf16 planes, 6 bf16-MFMA products, fp32 accumulate: "
-             "fp32-class accuracy, same 1e-4 / bit-exact-index parity bar)", "stub": "stub"}[mode]
+             "fp32-class accuracy, same 1e-4 / bit-exact-index parity bar)", "f16x2": "f16x2 (fp32 operands carried as 2 fp16 planes hi + 2^-11 lo', 22 significant bits, 3 fp16-MFMA products, "
+             "fp32 accumulate; same 1e-4 / bit-exact-index parity bar)", "stub": "stub"}[mode]
     out = {
         "metric": "image-pairs/sec @1024 kpts + pose AUC@5/10/20deg vs reference",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -505,10 +506,13 @@ def run(args):
         fl = algorithmic_flops(B, T, N, D, args.layers, True)
         fam = max(("gemm", "attention"), key=lambda k: prof_[k]["ms"])
         kname = {"f32": {"gemm": "gemm_nt_kernel", "attention": "attention_kernel"},
-                 "bf16x3": {"gemm": "gemm_x3_kernel", "attention": "attention3f_kernel"}}[mode_][fam]
+                 "bf16x3": {"gemm": "gemm_x3_kernel", "attention": "attention3f_kernel"},
+                 "f16x2": {"gemm": "gemm_x3_kernel", "attention": "attention_h2f_kernel"}}[mode_][fam]
         # f32 mode: exact fp32 MFMA.  bf16x3 mode: every algorithmic flop is 6 bf16-MFMA flops, so the ceiling for
         # ALGORITHMIC flops is the dense bf16 peak / 6.
-        peak = PEAK_F32_MFMA_TFLOPS if mode_ == "f32" else PEAK_BF16_MFMA_TFLOPS / 6.0
+        # f16x2 mode: 3 fp16-MFMA flops per algorithmic flop.
+        products = {"f32": 1, "bf16x3": 6, "f16x2": 3}[mode_]
+        peak = PEAK_F32_MFMA_TFLOPS if mode_ == "f32" else PEAK_BF16_MFMA_TFLOPS / products
 
         def family(f):
             ms, n = prof_[f]["ms"], prof_[f]["launches"]
@@ -529,7 +533,7 @@ def run(args):
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "note": ("algorithmic flops of the family / HIP-event time; " +
                          ("exact fp32 MFMA (v_mfma_f32_32x32x2_f32)" if mode_ == "f32" else
-                          "peak = dense bf16 MFMA 2500 TFLOP/s / 6 MFMA products per algorithmic flop (3-way split operands)")) +
+                          f"peak = dense 16-bit MFMA 2500 TFLOP/s / {products} MFMA products per algorithmic flop (split operands)")) +
                         "; traffic = HBM bytes per launch (read + write) from the PMC passes under profiles/",
                 "avg_launch_ms": round(ms / max(n, 1), 4), "launches_per_step": n // args.steps}
         fam2 = "attention" if fam == "gemm" else "gemm"

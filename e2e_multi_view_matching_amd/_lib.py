@@ -16,7 +16,8 @@ MAX_TUPLE, MAX_LAYERS, MAX_KENC, PROF_SLOTS = 8, 64, 8, 16
 FLAG_FULL_OUTPUT, FLAG_MULTI_FRAME = 1, 2
 DESC_F32, DESC_F16 = 0, 1
 OK, EINVAL, ENOMEM, EHIP, ESHAPE, ESTATE = 0, -1, -2, -3, -4, -5
-PRECISION_F32, PRECISION_BF16X3 = 0, 1
+PRECISION_F32, PRECISION_BF16X3, PRECISION_F16X2 = 0, 1, 2
+PRECISION_NAMES = {"f32": PRECISION_F32, "bf16x3": PRECISION_BF16X3, "f16x2": PRECISION_F16X2}
 
 c_void_p, c_int, c_float, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_char_p
 c_int64, c_size_t = ctypes.c_int64, ctypes.c_size_t
@@ -97,6 +98,7 @@ SIGNATURES = {
     "e2emv_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "e2emv_set_precision": (c_int, [c_void_p, c_int]),
     "e2emv_get_precision": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "e2emv_set_split_min_rows": (c_int, [c_void_p, c_int64]),
     "e2emv_gemm_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "e2emv_attention_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                        c_void_p]),
@@ -171,11 +173,16 @@ class Context:
 
     def set_precision(self, precision):
         """Arithmetic of the dense GNN contractions for every model on this device that does not pin its own
-        (``config["mfma_precision"]``): PRECISION_F32, PRECISION_BF16X3, "f32", "bf16x3", or None = library default."""
+        (``config["mfma_precision"]``): PRECISION_F32 / _BF16X3 / _F16X2, "f32", "bf16x3", "f16x2", or None = library default."""
         if isinstance(precision, str):
-            precision = {"f32": PRECISION_F32, "bf16x3": PRECISION_BF16X3}[precision]
+            precision = PRECISION_NAMES[precision]
         self.forced_precision = precision
         self.call("e2emv_set_precision", self.default_precision if precision is None else precision)
+
+    def set_split_min_rows(self, min_rows=-1):
+        """Calls with fewer keypoint rows than this run the fp32-MFMA kernels even in a split-operand mode
+        (-1 = library default, 0 = never)."""
+        self.call("e2emv_set_split_min_rows", int(min_rows))
 
     def check(self, rc):
         if rc != OK:

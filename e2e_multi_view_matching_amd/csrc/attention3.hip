@@ -448,8 +448,229 @@ __global__ __launch_bounds__(256, 2) void attention3f_kernel(Attn3fParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel in the "f16x2" arithmetic mode (see gemm_x3.hip): every operand is carried as two fp16 planes,
+// x = x_hi + x_lo, x_hi = fp16(x), x_lo = fp16(x - x_hi) - 22 significant bits - and a contraction is the 3 products
+// hi hi + hi lo + lo hi (v_mfma_f32_32x32x16_f16, fp32 accumulate): half the MFMAs, two thirds of the LDS planes and of
+// the split VALU work of the bf16x3 form.  Unlike the GEMM, where the weight planes are static, every operand here is
+// made on the fly, so the low planes are kept in fp16's normal range by power-of-two pre-scales that cancel exactly:
+//   q x 2^6 (on top of log2(e)/sqrt(d)), k x 2^4  -> logits in units of 2^-10; the exponent is formed as fma(S, 2^-10, c)
+//   p x 2^10 (p in (0, 1] -> (0, 1024]), v x 2^4  -> O = (sum p v) / (l 2^4), l summed from the same scaled p
+// Range: |q| < 5.6e3, |k|, |v| < 4.0e3 (beyond: +-inf -> non-finite scores -> the sticky error of e2emv_sync); the
+// absolute floor of a low plane (half an fp16 subnormal step, 3e-8) sits at 5e-10 / 2e-9 / 3e-11 of the unscaled q / k,v / p.
+constexpr float H2_QS = 64.f, H2_KVS = 16.f, H2_SINV = 1.f / 1024.f, H2_PLOG = 10.f;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+// (x c) -> hi + lo.  The product is made opaque before it is converted: hipcc 7.2 otherwise selects the high plane
+// twice - v_cvt_pk_f16_f32 of the rounded fp32 product for the stored plane, v_fma_mixlo_f16(x, c, 0) for the copy the
+// residual is taken against - and on gfx950 the two differ by an fp16 ulp when x c lies within an fp32 rounding of an
+// fp16 tie (the mix instruction rounds the exact product once): hi + lo is then off by 2^-11 of that element.  Found as
+// one query row in 512 with 1.4e-4 error; pinned by test_attention_split_kernels_near_fp16_ties.
+__device__ __forceinline__ void split2h(float x, float c, _Float16& a, _Float16& b) {
+    float v = x * c;
+    asm("" : "+v"(v));
+    a = (_Float16)v;
+    b = (_Float16)(v - (float)a);
+}
+
+__global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[2 * A3_PLANE];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[2 * A3_PLANE];
+
+    const int lin = blockIdx.x;
+    const int xcd = lin & 7, idx = lin >> 3;
+    const int g = xcd * p.gper + idx / p.nq;
+    if (g >= p.groups) return;
+    const int qt = idx % p.nq;
+    const int img = g / p.H, head = g % p.H;
+    const int b = img / p.T, t = img % p.T;
+    if (qt * A3_Q >= p.nv[t]) return;  // shorter image of a ragged tuple: no queries in this tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int64_t ld = 3 * (int64_t)p.D;  // floats per q|k|v row
+
+    // ---- Q fragments (B operand): lane (q, lh) holds Q_pl[q][16 s + 8 lh .. +7]
+    const int q_row = qt * A3_Q + wave * 32 + l31;
+    f16x8 Qf[2][4];
+    {
+        const float* qp = p.qkv + ((int64_t)img * p.n_rows + q_row) * ld + head * A3_HD + lh * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(qp + s * 16), hi = *reinterpret_cast<const f32x4*>(qp + s * 16 + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 a, bb;
+                split2h(e < 4 ? lo[e] : hi[e - 4], p.q_scale * H2_QS, a, bb);
+                Qf[0][s][e] = a; Qf[1][s][e] = bb;
+            }
+        }
+    }
+
+    f32x16 O0, O1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int n_src = p.cross ? p.T - 1 : 1;
+    auto src_t = [&](int si) { return !p.cross ? t : (si < t ? si : si + 1); };
+    int n_tiles = 0;
+    for (int si = 0; si < n_src; ++si) n_tiles += (p.nv[src_t(si)] + A3_KV - 1) / A3_KV;
+    auto locate = [&](int tile, int& tt, int& kt) {
+        int si = 0;
+        for (;; ++si) {
+            const int n = (p.nv[src_t(si)] + A3_KV - 1) / A3_KV;
+            if (tile < n || si + 1 == n_src) break;
+            tile -= n;
+        }
+        tt = src_t(si);
+        kt = tile;
+    };
+
+    // staging.  K tile (64 keys x 64 dims fp32): thread -> key row tid/4, 16 dims (tid&3)*16: 4 x 16 B, 64 B contiguous.
+    // V tile: thread -> a 4 keys x 4 dims block: key block kb = (lane>>2) (16 blocks), dims 16*wave + 4*(lane&3): 4 x 16 B
+    // from 4 consecutive key rows; after the split it owns, per dim, 4 consecutive keys = one 8-byte V^T write per plane.
+    const int k_row = tid >> 2, k_c16 = (tid & 3) * 16;
+    const int v_kb = lane >> 2, v_d0 = 16 * wave + 4 * (lane & 3);
+    // V^T LDS position of keys 4 kb .. 4 kb + 3 inside their 16-key group (permuted order, see the header)
+    const int v_lds = 16 * (v_kb >> 2) + 4 * ((v_kb & 3) >> 1) + 8 * (v_kb & 1);
+    f32x4 rk[4], rv[4];
+    auto gload = [&](int tile) {
+        int tt, kt;
+        locate(tile, tt, kt);
+        const float* base = p.qkv + ((int64_t)(b * p.T + tt) * p.n_rows + kt * A3_KV) * ld + head * A3_HD;
+        const float* kp = base + p.D + (int64_t)k_row * ld + k_c16;
+        const float* vp = base + 2 * p.D + (int64_t)(4 * v_kb) * ld + v_d0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rk[i] = *reinterpret_cast<const f32x4*>(kp + 4 * i);
+            rv[i] = *reinterpret_cast<const f32x4*>(vp + (int64_t)i * ld);
+        }
+    };
+    auto lstore = [&]() {
+        // K: 16 values -> 2 planes x 32 B
+        f16x8 kh[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, bb;
+                split2h(rk[i][e], H2_KVS, a, bb);
+                kh[0][i >> 1][(i & 1) * 4 + e] = a; kh[1][i >> 1][(i & 1) * 4 + e] = bb;
+            }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            uint16_t* kd = &Ks[pl * A3_PLANE + k_row * A3_LD + k_c16];
+            *reinterpret_cast<f16x8*>(kd) = kh[pl][0];
+            *reinterpret_cast<f16x8*>(kd + 8) = kh[pl][1];
+        }
+        // V^T: rv[i][e] = V[key 4 kb + i][dim d0 + e]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f16x4 vh[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                _Float16 a, bb;
+                split2h(rv[i][e], H2_KVS, a, bb);
+                vh[0][i] = a; vh[1][i] = bb;
+            }
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                *reinterpret_cast<f16x4*>(&Vs[pl * A3_PLANE + (v_d0 + e) * A3_LD + v_lds]) = vh[pl];
+        }
+    };
+
+    constexpr int PA[3] = {1, 0, 0};  // plane of the A operand (K or V^T), smallest terms first
+    constexpr int PB[3] = {0, 1, 0};  // plane of the B operand (Q or P)
+
+    gload(0);
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (tile + 1 < n_tiles) gload(tile + 1);
+
+        int tt_cur, kt;
+        locate(tile, tt_cur, kt);
+        const int valid_in_tile = p.nv[tt_cur] - kt * A3_KV;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (sub * 32 >= valid_in_tile) break;
+            f32x16 S;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[r] = 0.f;
+            const uint16_t* kp = &Ks[(sub * 32 + l31) * A3_LD + lh * 8];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f16x8 kf[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) kf[pl] = *reinterpret_cast<const f16x8*>(kp + pl * A3_PLANE + s * 16);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[PA[q]], Qf[PB[q]][s], S, 0, 0, 0);
+            }
+            if (valid_in_tile < sub * 32 + 32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= valid_in_tile) S[r] = -INFINITY;
+                }
+            }
+            float mx = S[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            // S (and m) are in units of 1 / (H2_QS H2_KVS) of a base-2 logit; P carries the factor H2_PS (cancels in O / l)
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * H2_SINV);
+            const float e0 = H2_PLOG - m_new * H2_SINV;
+            float ps = 0.f;
+            f16x8 Pf[2][2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], H2_SINV, e0));
+                ps += pv;
+                _Float16 a, bb;
+                split2h(pv, 1.f, a, bb);
+                Pf[0][r >> 3][r & 7] = a;
+                Pf[1][r >> 3][r & 7] = bb;
+            }
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { O0[r] *= alpha; O1[r] *= alpha; }
+            const uint16_t* vp = &Vs[l31 * A3_LD + lh * 8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f16x8 v0[2], v1[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    v0[pl] = *reinterpret_cast<const f16x8*>(vp + pl * A3_PLANE + 16 * (2 * sub + u));
+                    v1[pl] = *reinterpret_cast<const f16x8*>(vp + pl * A3_PLANE + 32 * A3_LD + 16 * (2 * sub + u));
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0[PA[q]], Pf[PB[q]][u], O0, 0, 0, 0);
+                    O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1[PA[q]], Pf[PB[q]][u], O1, 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / (l_tot * H2_KVS);
+    float* op = p.out32 + ((int64_t)img * p.n_rows + q_row) * p.D + head * A3_HD + 4 * lh;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        f32x4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = O0[gq * 4 + e] * inv; c[e] = O1[gq * 4 + e] * inv; }
+        *reinterpret_cast<f32x4*>(op + 8 * gq) = a;
+        *reinterpret_cast<f32x4*>(op + 32 + 8 * gq) = c;
+    }
+}
+
 int launch_attention3f(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, int D, int H, const float* qkv, int cross,
-                       float* out32, hipStream_t s) {
+                       float* out32, hipStream_t s, bool h2) {
     int n_valid = 0;
     for (int t = 0; t < T; ++t) {
         if (nv[t] <= 0 || nv[t] > n_rows) return set_err(ctx, E2EMV_ESHAPE, "attention3f: image %d has %d keypoints (n_rows %d)", t, nv[t], n_rows);
@@ -468,7 +689,8 @@ int launch_attention3f(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, 
     p.groups = B * T * H;
     p.gper = (p.groups + 7) / 8;
     p.q_scale = 0.125f * 1.4426950408889634f;  // log2(e) / sqrt(64)
-    hipLaunchKernelGGL(attention3f_kernel, dim3(8 * p.gper * p.nq), dim3(256), 0, s, p);
+    if (h2) hipLaunchKernelGGL(attention_h2f_kernel, dim3(8 * p.gper * p.nq), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attention3f_kernel, dim3(8 * p.gper * p.nq), dim3(256), 0, s, p);
     E2EMV_CHECK_LAUNCH(ctx, "attention3f_kernel");
     return E2EMV_OK;
 }

@@ -49,6 +49,11 @@ struct LayerWeights {
     uint16_t* w3_qkv = nullptr;
     uint16_t* w3_mlp0 = nullptr;
     uint16_t* w3_mlp1 = nullptr;
+    // f16x2 planes ([out][{hi, lo, hi 2^-11}][in] of 2^s W, gemm_x3.hip) of the same GEMMs and their 2^-s
+    uint16_t* wh_qkv = nullptr;
+    uint16_t* wh_mlp0 = nullptr;
+    uint16_t* wh_mlp1 = nullptr;
+    float hs_qkv = 0.f, hs_mlp0 = 0.f, hs_mlp1 = 0.f;
 };
 
 struct ProfEvent {
@@ -72,7 +77,8 @@ struct e2emv_ctx {
     size_t warena_floats = 0;
     uint16_t* d_w3arena = nullptr;
     size_t w3arena_elems = 0;
-    int precision = 0;  // E2EMV_PRECISION_F32 | E2EMV_PRECISION_BF16X3 (dense GNN contractions)
+    int precision = 0;  // E2EMV_PRECISION_F32 | _BF16X3 | _F16X2 (dense GNN contractions)
+    int64_t split_min_rows = -1;  // split-operand kernels from this many keypoint rows per call (-1: half a 128-row tile per CU)
     bool b3_planes = false;  // bf16x3 mode: q|k|v handed to the attention as planes from the GEMM epilogue (E2EMV_B3_PLANES=1)
     // keypoint encoder: layer 0 (3->c0) used by the ingest kernel, the rest through the GEMM
     float* kenc_w0 = nullptr;  // [c0][3] folded
@@ -212,12 +218,15 @@ struct Gemm3Args {
 };
 int launch_gemm3(e2emv_ctx* ctx, const Gemm3Args& a, hipStream_t s);
 // gemm_x3.hip: fp32 activations (a.A / a.A2, a.bias, a.R, a.C, a.relu as for launch_gemm_nt) x pre-split weights W3 (S3 [N][3][ldw3])
-int launch_gemm_x3(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* W3, int64_t ldw3, hipStream_t s);
+// host: fp32 weights -> the f16x2 planes appended to `out` (offset returned), *out_scale = 2^-s (ctx.hip)
+size_t add_split_h2(std::vector<uint16_t>& out, const std::vector<float>& w, int rows, int cols, float* out_scale);
+// h2_out_scale != 0 selects the fp16 x 2 form: W3 = fp16 planes [N][{hi, lo, hi 2^-11}][ldw3] of 2^s W, h2_out_scale = 2^-s
+int launch_gemm_x3(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* W3, int64_t ldw3, hipStream_t s, float h2_out_scale = 0.f);
 int launch_split3(e2emv_ctx* ctx, const float* src, int64_t rows, int C, int64_t ld_src, uint16_t* dst, int64_t ld,
                   hipStream_t s);
 // the same attention fed with the fp32 q|k|v matrix (planes produced inside the kernel)
 int launch_attention3f(e2emv_ctx* ctx, int B, int T, int n_rows, const int* n_valid_img, int D, int H, const float* qkv,
-                       int cross, float* out32, hipStream_t s);
+                       int cross, float* out32, hipStream_t s, bool h2 = false);
 int launch_attention3(e2emv_ctx* ctx, int B, int T, int n_rows, const int* n_valid_img, int D, int H, const uint16_t* qk,
                       const uint16_t* vt, int cross, uint16_t* out3, float* out32, hipStream_t s);
 

@@ -64,6 +64,44 @@ void prof_end(e2emv_ctx* ctx, hipStream_t s) {
     (void)hipEventRecord(ctx->prof_events.back().b, s);
 }
 
+namespace {
+inline uint16_t f2h(float f) {
+    const _Float16 h = (_Float16)f;  // round to nearest even
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+inline float h2f(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
+}  // namespace
+
+// weights [rows][cols] fp32 -> fp16 planes [rows][{hi, lo, hi 2^-11}][cols] of 2^s W appended to `out` (the "f16x2" weight
+// format of gemm_x3.hip); s = the power of two that brings max |w| into [2^13, 2^14), *out_scale = 2^-s.  With that scale
+// hi 2^-11 and lo stay normal fp16 numbers for every |w| >= 2^-16 max |w|.
+size_t add_split_h2(std::vector<uint16_t>& out, const std::vector<float>& w, int rows, int cols, float* out_scale) {
+    float mx = 0.f;
+    for (float v : w) mx = std::max(mx, std::fabs(v));
+    int e = 0;
+    if (mx > 0.f && std::isfinite(mx)) (void)std::frexp(mx, &e);  // mx = m 2^e, m in [0.5, 1)
+    const int sh = 14 - e;
+    const float sc = std::ldexp(1.f, sh);
+    *out_scale = std::ldexp(1.f, -sh);
+    size_t off = (out.size() + 127) & ~size_t(127);
+    out.resize(off + (size_t)rows * 3 * cols);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            const float v = w[(size_t)r * cols + c] * sc;
+            const uint16_t hi = f2h(v);
+            const float fh = h2f(hi);
+            uint16_t* o = &out[off + (size_t)r * 3 * cols];
+            o[c] = hi; o[cols + c] = f2h(v - fh); o[2 * cols + c] = f2h(fh * (1.f / 2048.f));
+        }
+    return off;
+}
+
 }  // namespace e2emv
 
 using namespace e2emv;
@@ -97,7 +135,11 @@ int e2emv_create(e2emv_ctx** out, int device) {
     // default arithmetic of the dense GNN contractions: the split-operand bf16 path (fp32-class accuracy, every parity
     // test runs in both modes at the same bar); E2EMV_PRECISION=f32 selects the exact fp32-MFMA kernels
     ctx->precision = ctx->fuse_merge ? E2EMV_PRECISION_BF16X3 : E2EMV_PRECISION_F32;
-    if (const char* e = getenv("E2EMV_PRECISION")) ctx->precision = (strcmp(e, "bf16x3") == 0 && ctx->fuse_merge) ? E2EMV_PRECISION_BF16X3 : E2EMV_PRECISION_F32;
+    if (const char* e = getenv("E2EMV_PRECISION")) {
+        ctx->precision = E2EMV_PRECISION_F32;
+        if (ctx->fuse_merge && strcmp(e, "bf16x3") == 0) ctx->precision = E2EMV_PRECISION_BF16X3;
+        if (ctx->fuse_merge && strcmp(e, "f16x2") == 0) ctx->precision = E2EMV_PRECISION_F16X2;
+    }
     *out = ctx;
     return E2EMV_OK;
 }
@@ -308,7 +350,8 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     // ---- GNN layers ----
     struct LOff {
         size_t wqkv, bqkv, wm, bm, w0, b0, w1, b1;
-        size_t w3qkv, w3m0, w3m1;
+        size_t w3qkv, w3m0, w3m1, whqkv, whm0, whm1;
+        float hsqkv, hsm0, hsm1;
     };
     std::vector<uint16_t> pk3;  // bf16x3 planes of the big GEMM weights
     std::vector<LOff> loff(m->n_layers);
@@ -327,6 +370,7 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         loff[l].wqkv = pk.add(wqkv);
         loff[l].bqkv = pk.add(bqkv);
         loff[l].w3qkv = add_split3(pk3, wqkv, 3 * D, D);
+        loff[l].whqkv = add_split_h2(pk3, wqkv, 3 * D, D, &loff[l].hsqkv);
         if ((rc = get_conv(ctx, base + ".attn.merge", D, D, w, b))) return rc;
         std::vector<float> wm((size_t)D * D);
         for (int o = 0; o < D; ++o)
@@ -360,10 +404,12 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         loff[l].w0 = pk.add(w);
         loff[l].b0 = pk.add(b);
         loff[l].w3m0 = add_split3(pk3, w, 2 * D, 2 * D);
+        loff[l].whm0 = add_split_h2(pk3, w, 2 * D, 2 * D, &loff[l].hsm0);
         if ((rc = get_conv(ctx, base + ".mlp.3", D, 2 * D, w, b))) return rc;
         loff[l].w1 = pk.add(w);
         loff[l].b1 = pk.add(b);
         loff[l].w3m1 = add_split3(pk3, w, D, 2 * D);
+        loff[l].whm1 = add_split_h2(pk3, w, D, 2 * D, &loff[l].hsm1);
     }
     if ((rc = get_conv(ctx, "final_proj", D, D, w, b))) return rc;
     size_t wf = pk.add(w), bf = pk.add(b);
@@ -436,6 +482,9 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         L.w3_qkv = ctx->d_w3arena + loff[l].w3qkv;
         L.w3_mlp0 = ctx->d_w3arena + loff[l].w3m0;
         L.w3_mlp1 = ctx->d_w3arena + loff[l].w3m1;
+        L.wh_qkv = ctx->d_w3arena + loff[l].whqkv; L.hs_qkv = loff[l].hsqkv;
+        L.wh_mlp0 = ctx->d_w3arena + loff[l].whm0; L.hs_mlp0 = loff[l].hsm0;
+        L.wh_mlp1 = ctx->d_w3arena + loff[l].whm1; L.hs_mlp1 = loff[l].hsm1;
     }
     ctx->w_final = base + wf;
     ctx->b_final = base + bf;
@@ -458,11 +507,18 @@ extern "C" {
 int e2emv_set_precision(e2emv_ctx* ctx, int precision) {
     if (!ctx) return E2EMV_EINVAL;
     E2EMV_LOCK(ctx);
-    if (precision != E2EMV_PRECISION_F32 && precision != E2EMV_PRECISION_BF16X3)
+    if (precision != E2EMV_PRECISION_F32 && precision != E2EMV_PRECISION_BF16X3 && precision != E2EMV_PRECISION_F16X2)
         return set_err(ctx, E2EMV_EINVAL, "unknown precision %d", precision);
-    if (precision == E2EMV_PRECISION_BF16X3 && !ctx->fuse_merge)
+    if (precision != E2EMV_PRECISION_F32 && !ctx->fuse_merge)
         return set_err(ctx, E2EMV_ESTATE, "bf16x3 needs the merge conv folded into MLP0 (unset E2EMV_NO_FUSE_MERGE)");
     ctx->precision = precision;
+    return E2EMV_OK;
+}
+
+int e2emv_set_split_min_rows(e2emv_ctx* ctx, int64_t min_rows) {
+    if (!ctx) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
+    ctx->split_min_rows = min_rows < 0 ? -1 : min_rows;
     return E2EMV_OK;
 }
 

@@ -158,7 +158,9 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
     // bf16x3 (split operands on the bf16 pipe) pays once the 128-row GEMM tiles fill the chip; calls below half a tile per
     // CU (a pair or two - the eval_pairs.py loop) run the fp32-MFMA kernels, whose 64 x 64 tile shape and key-split
     // attention are the latency-tuned forms.  Both arithmetic modes meet the same parity bar.
-    const bool b3 = ctx->precision == E2EMV_PRECISION_BF16X3 && ctx->fuse_merge && Mtot / 128 >= ctx->num_cus / 2;
+    const int64_t split_min = ctx->split_min_rows >= 0 ? ctx->split_min_rows : (int64_t)128 * (ctx->num_cus / 2);
+    const bool b3 = ctx->precision != E2EMV_PRECISION_F32 && ctx->fuse_merge && Mtot >= split_min;
+    const bool h2 = b3 && ctx->precision == E2EMV_PRECISION_F16X2;  // fp16 x 2 planes instead of bf16 x 3 (gemm_x3.hip)
     // bf16x3 attention path: x as S3 planes (6D bytes/row) and V^T planes (6D bytes/row); the q|k planes
     // (S3, 2D wide = 12D bytes/row) live in the fp32 q|k|v buffer, which has exactly that size
     const size_t sz_x3 = b3 ? al((size_t)Mtot * 3 * D * 2) : 0;
@@ -240,13 +242,13 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
             // q|k|v on the split-operand GEMM with a plain fp32 output; the attention kernel splits Q / K / V^T into
             // bf16 planes on the way in (E2EMV_B3_PLANES=1 selects the first-generation hand-over: fp32-pipe GEMM whose
             // epilogue emits the planes, 3.2x the bytes)
-            if (!ctx->b3_planes) {
+            if (h2 || !ctx->b3_planes) {
                 g = GemmArgs();
                 g.M = (int)Mtot; g.N = 3 * D; g.K = D; g.K1 = D; g.A = x; g.lda = D; g.bias = L.b_qkv; g.C = qkv; g.ldc = 3 * D;
-                prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_x3(ctx, g, L.w3_qkv, D, s); prof_end(ctx, s);
+                prof_begin(ctx, PS_GEMM, s); rc = h2 ? launch_gemm_x3(ctx, g, L.wh_qkv, D, s, L.hs_qkv) : launch_gemm_x3(ctx, g, L.w3_qkv, D, s); prof_end(ctx, s);
                 if (rc) return rc;
                 prof_begin(ctx, PS_ATTN, s);
-                rc = launch_attention3f(ctx, B, T, n_rows, Nt, D, H, qkv, L.type, att, s);
+                rc = launch_attention3f(ctx, B, T, n_rows, Nt, D, H, qkv, L.type, att, s, h2);
                 prof_end(ctx, s);
                 if (rc) return rc;
             } else {
@@ -289,7 +291,7 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         g.W = L.w_mlp0; g.ldw = 2 * D; g.bias = L.b_mlp0; g.relu = true; g.C = hid; g.ldc = 2 * D;
         // bf16x3 mode: the two MLP GEMMs (2/3 of the layer's GEMM flops) run on the bf16 pipe with split operands
         prof_begin(ctx, PS_GEMM, s);
-        rc = b3 ? launch_gemm_x3(ctx, g, L.w3_mlp0, 2 * D, s) : launch_gemm_nt(ctx, g, s);
+        rc = h2 ? launch_gemm_x3(ctx, g, L.wh_mlp0, 2 * D, s, L.hs_mlp0) : b3 ? launch_gemm_x3(ctx, g, L.w3_mlp0, 2 * D, s) : launch_gemm_nt(ctx, g, s);
         prof_end(ctx, s);
         if (rc) return rc;
         // x += W1 hidden + b1
@@ -297,7 +299,7 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         g.M = (int)Mtot; g.N = D; g.K = 2 * D; g.K1 = 2 * D; g.A = hid; g.lda = 2 * D; g.W = L.w_mlp1; g.ldw = 2 * D;
         g.bias = L.b_mlp1; g.R = x; g.ldr = D; g.C = x; g.ldc = D;
         prof_begin(ctx, PS_GEMM, s);
-        rc = b3 ? launch_gemm_x3(ctx, g, L.w3_mlp1, 2 * D, s) : launch_gemm_nt(ctx, g, s);
+        rc = h2 ? launch_gemm_x3(ctx, g, L.wh_mlp1, 2 * D, s, L.hs_mlp1) : b3 ? launch_gemm_x3(ctx, g, L.w3_mlp1, 2 * D, s) : launch_gemm_nt(ctx, g, s);
         prof_end(ctx, s);
         if (rc) return rc;
     }

@@ -584,7 +584,7 @@ struct SkResParams {
     u64* bufU;          // [n_res][2][G]                            sum of r_i a_i over a workgroup's rows, by epoch parity
     unsigned* timeout;  // [1]
     unsigned long long* dbg;  // optional [16 iterations][G][8] 100 MHz timestamps of resident problem 0 (E2EMV_SKR_DEBUG)
-    int flags;          // experiment switches (E2EMV_SKR_FLAGS): 1 = no s_sleep in the polls, 2 = v_N on wave 7 ahead of stage A
+    int flags;          // experiment switch (E2EMV_SKR_FLAGS): 1 = no s_sleep in the polls
     float* u;           // [B][M+1]  out: row potentials (u[M] = dustbin row)
     float* v;           // [B][ldV]  out: column potentials (v[N] = dustbin column)
     int64_t ldV;
@@ -848,16 +848,6 @@ __global__ __launch_bounds__(512, 4) void sinkhorn_resident(SkResParams p) {
             if (__syncthreads_or(dead ? 1 : 0)) dead = true;
             if (dbg) dbg[6] = __builtin_amdgcn_s_memrealtime();
             bN = vbuf[W];
-            if ((p.flags & 4) && p.dbg && grp == 0 && round == 0 && it < 2) {  // development aid: dump a, K[.][0], m, b after iteration it
-                float* df = reinterpret_cast<float*>(p.dbg) + (size_t)it * (3 * M + N + 8);
-#pragma unroll
-                for (int r = 0; r < RW; ++r)
-                    if (row0 + r < M && lane == 0) { df[row0 + r] = a[r]; df[M + row0 + r] = K[r][0][0][0]; df[2 * M + row0 + r] = mrow[r]; }
-                if (w == 0) {
-                    for (int j = tid; j < N; j += 512) df[3 * M + j] = vbuf[j];
-                    if (tid == 0) { df[3 * M + N] = aM; df[3 * M + N + 1] = bN; }
-                }
-            }
         }
 
         // ---- hand the potentials to the final sweep (logZ, fused arg-max): u = log a - m of this workgroup's rows, and
@@ -1052,7 +1042,7 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
         rpar.timeout = ctx->d_flags;
         const char* dbg_path = getenv("E2EMV_SKR_DEBUG");
         unsigned long long* d_dbg = nullptr;
-        const size_t dbg_bytes = std::max((size_t)16 * rp.G * 8 * sizeof(unsigned long long), (size_t)2 * (3 * M + N + 8) * 4);
+        const size_t dbg_bytes = (size_t)16 * rp.G * 8 * sizeof(unsigned long long);
         if (dbg_path && hipMalloc((void**)&d_dbg, dbg_bytes) == hipSuccess) (void)hipMemsetAsync(d_dbg, 0, dbg_bytes, s);
         rpar.dbg = d_dbg;
         if (const char* e = getenv("E2EMV_SKR_FLAGS")) rpar.flags = atoi(e);
@@ -1067,12 +1057,7 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(h.data(), d_dbg, dbg_bytes, hipMemcpyDeviceToHost);
             (void)hipFree(d_dbg);
-            if (rpar.flags & 4) {
-                if (FILE* f = fopen(dbg_path, "wb")) {
-                    fwrite(h.data(), 1, (size_t)2 * (3 * M + N + 8) * 4, f);
-                    fclose(f);
-                }
-            } else if (FILE* f = fopen(dbg_path, "a")) {
+            if (FILE* f = fopen(dbg_path, "a")) {
                 fprintf(f, "# B=%d M=%d N=%d iters=%d G=%d n_res=%d flags=%d\n", B, M, N, iters, rp.G, rp.n_res, rpar.flags);
                 for (int it = 0; it < 16 && it < iters; ++it)
                     for (int g = 0; g < rp.G; ++g) {

@@ -167,7 +167,7 @@ class MultiViewMatcher(nn.Module):
         if mode is None:
             want = ctx.forced_precision if ctx.forced_precision is not None else ctx.default_precision
         else:
-            want = {"f32": _lib.PRECISION_F32, "bf16x3": _lib.PRECISION_BF16X3}[mode]
+            want = _lib.PRECISION_NAMES[mode]
         if ctx.precision() != want:
             ctx.call("e2emv_set_precision", want)
         kpts, scores, descs = [], [], []

@@ -72,9 +72,10 @@ def attention(qkv, B, T, n_valid, H, cross):
     return out
 
 
-def gemm_bf16x3(A, W, bias=None, relu=False, all_planes=False):
+def gemm_bf16x3(A, W, bias=None, relu=False, all_planes=False, f16x2=False):
     """bf16x3 split-operand GEMM building block on fp32 tensors: act(A W^T + bias).  Default: gemm_x3.hip (activations
-    split on the way into LDS); ``all_planes=True``: the first-generation kernel that reads pre-split planes (gemm3.hip)."""
+    split on the way into LDS); ``all_planes=True``: the first-generation kernel that reads pre-split planes (gemm3.hip); ``f16x2=True``: the
+    fp16 x 2 form of gemm_x3.hip (two activation planes, three products)."""
     ctx = _ctx(A)
     A_, W_ = A.contiguous().float(), W.contiguous().float()
     M, K = A_.shape
@@ -82,19 +83,21 @@ def gemm_bf16x3(A, W, bias=None, relu=False, all_planes=False):
     C = torch.empty((M, N), dtype=torch.float32, device=A.device)
     b = bias.contiguous().float() if bias is not None else None
     with torch.cuda.device(A.device):
-        ctx.call("e2emv_gemm_bf16x3", M, N, K, _lib.ptr(A_), _lib.ptr(W_), _lib.ptr(b), _lib.ptr(C), (1 if relu else 0) | (2 if all_planes else 0),
+        ctx.call("e2emv_gemm_bf16x3", M, N, K, _lib.ptr(A_), _lib.ptr(W_), _lib.ptr(b), _lib.ptr(C), (1 if relu else 0) | (2 if all_planes else 0) | (4 if f16x2 else 0),
                  _lib.stream_ptr(A.device))
     return C
 
 
-def attention_bf16x3(qkv, B, T, n_valid, H, cross):
-    """bf16x3 split-operand attention building block; same contract as `attention`."""
+def attention_bf16x3(qkv, B, T, n_valid, H, cross, kernel="planes"):
+    """Split-operand attention building block; same contract as `attention`.  kernel: "planes" (pre-split bf16x3 planes,
+    attention3_kernel), "fused" (the forward pass's bf16x3 kernel: fp32 q|k|v in, planes made in the kernel) or "f16x2"
+    (its fp16 x 2 form)."""
     ctx = _ctx(qkv)
     q = qkv.contiguous().float()
     n_img, n_rows, D3 = q.shape
     D = D3 // 3
     out = torch.empty((n_img, n_rows, D), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
-        ctx.call("e2emv_attention_bf16x3", B, T, n_rows, n_valid, D, H, _lib.ptr(q), 1 if cross else 0, _lib.ptr(out),
-                 _lib.stream_ptr(q.device))
+        ctx.call("e2emv_attention_bf16x3", B, T, n_rows, n_valid, D, H, _lib.ptr(q),
+                 (1 if cross else 0) | {"planes": 0, "fused": 2, "f16x2": 6}[kernel], _lib.ptr(out), _lib.stream_ptr(q.device))
     return out

@@ -300,17 +300,31 @@ int e2emv_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D
  *                          block accumulated in fp32 - fp32-class rounding (|err| ~ 2^-24 per
  *                          product) at 2.67x the fp32-MFMA ceiling.  Same API, same outputs within
  *                          the 1e-4 parity bar (tests/test_gpu_matcher.py runs both).  DEFAULT since round 2.
- * Also selectable with the environment variable E2EMV_PRECISION=f32|bf16x3 read at e2emv_create. */
+ * E2EMV_PRECISION_F16X2  : fp32 operands carried as two fp16 planes (hi + 2^-11 lo', 22 significant bits, the low plane
+ *                          kept at the exponent range of the high one; static weights pre-scaled by a power of two per
+ *                          matrix), three fp16 MFMA products per block accumulated in fp32: half the matrix-pipe work
+ *                          of bf16x3.  Operand representation error <= 2^-22 for 6e-5 <= |x| <= 65504 (a K=512
+ *                          contraction: 1e-7 rms, below fp32 accumulation noise); an activation beyond 65504 becomes
+ *                          +-inf and surfaces as the sticky non-finite error of e2emv_sync.
+ * Also selectable with the environment variable E2EMV_PRECISION=f32|bf16x3|f16x2 read at e2emv_create. */
 #define E2EMV_PRECISION_F32 0
 #define E2EMV_PRECISION_BF16X3 1
+#define E2EMV_PRECISION_F16X2 2
 int e2emv_set_precision(e2emv_ctx* ctx, int precision);
 int e2emv_get_precision(e2emv_ctx* ctx, int* precision);
+/* The split-operand modes use the fp32-MFMA kernels for calls with fewer than `min_rows` keypoint rows (images x
+ * keypoints; default -1 = half a 128-row tile per CU, i.e. 16384 on an MI355X): their 64 x 64 tiles and key-split
+ * attention are the latency-tuned forms for a pair or two.  0 = always the split kernels (how the parity tests reach
+ * them at small sizes). */
+int e2emv_set_split_min_rows(e2emv_ctx* ctx, int64_t min_rows);
 /* building blocks of the bf16x3 path on fp32 buffers (split / merge done internally; for tests):
  * C = act(A W^T + bias), A [M,K], W [N,K], C [M,N]; flags bit0 relu, bit1 = first-generation kernel reading pre-split
- * activation planes (gemm3.hip) instead of the default gemm_x3.hip (fp32 activations split on the way into LDS). */
+ * activation planes (gemm3.hip) instead of the default gemm_x3.hip (fp32 activations split on the way into LDS),
+ * bit2 = the f16x2 form of gemm_x3.hip (host-synchronising: the weight planes are made on the host). */
 int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const float* d_A, const float* d_W, const float* d_bias,
                       float* d_C, int flags, void* stream);
-/* same contract as e2emv_attention. */
+/* same contract as e2emv_attention; cross: bit0 = cross layer, bit1 = the forward pass's kernel (fp32 q|k|v in, the
+ * planes made inside the kernel) instead of the pre-split building block, bit2 = its f16x2 form. */
 int e2emv_attention_bf16x3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv,
                            int cross, float* d_out, void* stream);
 

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("split_always")]
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -80,7 +80,7 @@ def test_superglue_hf_golden_through_the_hip_path(gpu):
     dg = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in data.items()}
     matches = torch.from_numpy(z["matches"]).long()
     ms = torch.from_numpy(z["matching_scores"])
-    for precision in ("f32", "bf16x3"):
+    for precision in ("f32", "bf16x3", "f16x2"):
         model.config["mfma_precision"] = precision
         with torch.no_grad():
             out = model(dg)

@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("split_always")]
 
 TOL = 1e-4  # north-star: scores within 1e-4 fp32, assignment indices bit-exact
 
@@ -57,7 +57,7 @@ def _compare(out, ref, pairs):
         assert c.shape == cr.shape and float((c - cr).abs().max()) < TOL
 
 
-PRECISIONS = ["f32", "bf16x3"]
+PRECISIONS = ["f32", "bf16x3", "f16x2"]
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("split_always")]
 
 
 def _rng(seed):
@@ -104,7 +104,7 @@ def test_matcher_random_configs(gpu, seed):
     model = model.to(gpu)
     dev = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in data.items()}
     pairs = [(i, j) for j in range(T) for i in range(j)]
-    for precision in ("f32", "bf16x3"):
+    for precision in ("f32", "bf16x3", "f16x2"):
         model.config["mfma_precision"] = precision
         with torch.no_grad():
             out = model(dev)

@@ -231,10 +231,10 @@ def _full_size(gpu, n_kpts, desc_dtype, precisions):
 def test_config4_full_size_t5_1024_batch8_18_layers(gpu):
     """BASELINE configs[3]: tuple_size 5 (10 pairwise matches per tuple), 1024 keypoints, batch 8 tuples, 18 layers
     (eval_multi_view.py:122-132,154-162), both arithmetic modes."""
-    _full_size(gpu, 1024, torch.float32, ["f32", "bf16x3"])
+    _full_size(gpu, 1024, torch.float32, ["f32", "bf16x3", "f16x2"])
 
 
 def test_config5_per_gpu_shape_t5_2048_fp16_batch8(gpu):
     """BASELINE configs[4] per-GPU share: tuple_size 5, 2048 keypoints (MegaDepth shape), fp16 descriptors, batch 8 tuples,
     18 layers; the oracle is fed the same fp16-rounded descriptors."""
-    _full_size(gpu, 2048, torch.float16, ["f32", "bf16x3"])
+    _full_size(gpu, 2048, torch.float16, ["f32", "bf16x3", "f16x2"])

@@ -51,17 +51,18 @@ def main():
         for (M, N, K) in [(65536, 256, 256), (65536, 256, 512), (65536, 512, 512), (65536, 768, 256), (65536, 256, 2048), (32768, 256, 8192)]:
             A = torch.randn(M, K, device=dev)
             W = torch.randn(N, K, device=dev)
-            for v1 in ((False,) if os.environ.get('E2EMV_X3_DEBUG') else (False, True)):
+            for v1 in ((0, 4) if os.environ.get('E2EMV_X3_DEBUG') else (0, 4, 2)):
+                kw = dict(all_planes=v1 == 2, f16x2=v1 == 4)
                 for _ in range(2):
-                    E.gemm_bf16x3(A, W, all_planes=v1)
+                    E.gemm_bf16x3(A, W, **kw)
                 ctx.call("e2emv_profile", 1)
                 _lib.profile_read(ctx, reset=True)
                 for _ in range(10):
-                    E.gemm_bf16x3(A, W, all_planes=v1)
+                    E.gemm_bf16x3(A, W, **kw)
                 pr = _lib.profile_read(ctx, reset=True)["gemm"]
                 ctx.call("e2emv_profile", 0)
                 ms = pr["ms"] / pr["launches"]
-                print(f"  {M:7d} {N:5d} {K:5d}  {ms * 1e3:9.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF  ({'gemm3 all-planes' if v1 else 'gemm_x3'})")
+                print(f"  {M:7d} {N:5d} {K:5d}  {ms * 1e3:9.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TF  ({ {0: 'gemm_x3 bf16x3', 4: 'gemm_x3 f16x2', 2: 'gemm3 all-planes'}[v1]})")
     if "a3" in args.what:
         print("== attention_bf16x3 kernel alone (B pairs, N) -> us, TFLOP/s fp32-equivalent")
         from e2e_multi_view_matching_amd import _lib
@@ -69,16 +70,17 @@ def main():
         for (B, N) in [(32, 1024), (8, 2048)]:
             qkv = torch.randn(B * 2, N, 768, device=dev)
             for cross in (0, 1):
+              for kernel in ("planes", "fused", "f16x2"):
                 for _ in range(2):
-                    E.attention_bf16x3(qkv, B, 2, N, 4, cross)
+                    E.attention_bf16x3(qkv, B, 2, N, 4, cross, kernel=kernel)
                 ctx.call("e2emv_profile", 1)
                 _lib.profile_read(ctx, reset=True)
                 for _ in range(5):
-                    E.attention_bf16x3(qkv, B, 2, N, 4, cross)
+                    E.attention_bf16x3(qkv, B, 2, N, 4, cross, kernel=kernel)
                 pr = _lib.profile_read(ctx, reset=True)["attention"]
                 ctx.call("e2emv_profile", 0)
                 ms = pr["ms"] / pr["launches"]
-                print(f"  B={B:3d} N={N:5d} cross={cross}  {ms * 1e3:9.1f} us  {B * 2 * 4.0 * N * N * 256 / ms / 1e9:7.1f} TF")
+                print(f"  B={B:3d} N={N:5d} cross={cross}  {ms * 1e3:9.1f} us  {B * 2 * 4.0 * N * N * 256 / ms / 1e9:7.1f} TF  ({kernel})")
     if "attn" in args.what:
         print("== attention (B pairs, N) -> us, TFLOP/s")
         for (B, N) in [(32, 1024), (8, 1024), (32, 512), (8, 2048)]:
