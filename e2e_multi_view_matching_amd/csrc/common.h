@@ -49,7 +49,7 @@ struct LayerWeights {
     uint16_t* w3_qkv = nullptr;
     uint16_t* w3_mlp0 = nullptr;
     uint16_t* w3_mlp1 = nullptr;
-    // f16x2 planes ([out][{hi, lo, hi 2^-11}][in] of 2^s W, gemm_x3.hip) of the same GEMMs and their 2^-s
+    // f16x2 planes ([out][{hi, lo}][in] of 2^s W, gemm_h2.hip) of the same GEMMs and their 2^-s
     uint16_t* wh_qkv = nullptr;
     uint16_t* wh_mlp0 = nullptr;
     uint16_t* wh_mlp1 = nullptr;
@@ -220,7 +220,8 @@ int launch_gemm3(e2emv_ctx* ctx, const Gemm3Args& a, hipStream_t s);
 // gemm_x3.hip: fp32 activations (a.A / a.A2, a.bias, a.R, a.C, a.relu as for launch_gemm_nt) x pre-split weights W3 (S3 [N][3][ldw3])
 // host: fp32 weights -> the f16x2 planes appended to `out` (offset returned), *out_scale = 2^-s (ctx.hip)
 size_t add_split_h2(std::vector<uint16_t>& out, const std::vector<float>& w, int rows, int cols, float* out_scale);
-// h2_out_scale != 0 selects the fp16 x 2 form: W3 = fp16 planes [N][{hi, lo, hi 2^-11}][ldw3] of 2^s W, h2_out_scale = 2^-s
+// h2_out_scale != 0 selects the fp16 x 2 form (gemm_h2.hip): W3 = fp16 planes [N][{hi, lo}][ldw3] of 2^s W, h2_out_scale = 2^-s
+int launch_gemm_h2(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* WH, int64_t ldw, float out_scale, hipStream_t s);
 int launch_gemm_x3(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* W3, int64_t ldw3, hipStream_t s, float h2_out_scale = 0.f);
 int launch_split3(e2emv_ctx* ctx, const float* src, int64_t rows, int C, int64_t ld_src, uint16_t* dst, int64_t ld,
                   hipStream_t s);

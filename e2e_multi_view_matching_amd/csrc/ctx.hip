@@ -78,9 +78,9 @@ inline float h2f(uint16_t u) {
 }
 }  // namespace
 
-// weights [rows][cols] fp32 -> fp16 planes [rows][{hi, lo, hi 2^-11}][cols] of 2^s W appended to `out` (the "f16x2" weight
-// format of gemm_x3.hip); s = the power of two that brings max |w| into [2^13, 2^14), *out_scale = 2^-s.  With that scale
-// hi 2^-11 and lo stay normal fp16 numbers for every |w| >= 2^-16 max |w|.
+// weights [rows][cols] fp32 -> fp16 planes [rows][{hi, lo}][cols] of 2^s W appended to `out` (the "f16x2" weight format
+// of gemm_h2.hip); s = the power of two that brings max |w| into [2^13, 2^14), *out_scale = 2^-s.  With that scale lo
+// (and the 2^-11 hi the kernel derives) stay normal fp16 numbers for every |w| >= 2^-16 max |w|.
 size_t add_split_h2(std::vector<uint16_t>& out, const std::vector<float>& w, int rows, int cols, float* out_scale) {
     float mx = 0.f;
     for (float v : w) mx = std::max(mx, std::fabs(v));
@@ -90,14 +90,13 @@ size_t add_split_h2(std::vector<uint16_t>& out, const std::vector<float>& w, int
     const float sc = std::ldexp(1.f, sh);
     *out_scale = std::ldexp(1.f, -sh);
     size_t off = (out.size() + 127) & ~size_t(127);
-    out.resize(off + (size_t)rows * 3 * cols);
+    out.resize(off + (size_t)rows * 2 * cols);
     for (int r = 0; r < rows; ++r)
         for (int c = 0; c < cols; ++c) {
             const float v = w[(size_t)r * cols + c] * sc;
             const uint16_t hi = f2h(v);
-            const float fh = h2f(hi);
-            uint16_t* o = &out[off + (size_t)r * 3 * cols];
-            o[c] = hi; o[cols + c] = f2h(v - fh); o[2 * cols + c] = f2h(fh * (1.f / 2048.f));
+            uint16_t* o = &out[off + (size_t)r * 2 * cols];
+            o[c] = hi; o[cols + c] = f2h(v - h2f(hi));
         }
     return off;
 }

@@ -25,8 +25,6 @@ typedef __attribute__((ext_vector_type(4))) float x3_f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 x3_bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 x3_bf16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int x3_u32x4;
-typedef __attribute__((ext_vector_type(8))) _Float16 x3_f16x8;
-typedef __attribute__((ext_vector_type(4))) _Float16 x3_f16x4;
 
 constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 32, X3_LD = 40;
 constexpr int X3_PLANE = 128 * X3_LD;  // bf16 elements of one plane of one operand tile
@@ -34,8 +32,7 @@ constexpr int X3_PLANE = 128 * X3_LD;  // bf16 elements of one plane of one oper
 struct GemmX3Params {
     const float* A;
     const float* A2;
-    const uint16_t* W3;  // S3 [N][3][ldw3] bf16 planes, or (H2) the fp16 planes [N][{hi, lo, hi 2^-11}][ldw3] of 2^s W
-    float out_scale;     // H2: 2^-s, undoes the per-matrix power-of-two scale of the weight planes (exact)
+    const uint16_t* W3;  // S3 [N][3][ldw3]
     const float* bias;
     const float* R;
     float* C;
@@ -45,23 +42,11 @@ struct GemmX3Params {
     int relu;
 };
 
-// H2 = the fp16 x 2 form of the same kernel ("f16x2" arithmetic mode): an fp32 operand is carried as two fp16 planes,
-//   x = x_hi + 2^-11 x_lo',  x_hi = fp16(x),  x_lo' = fp16(2^11 (x - x_hi))      (|x - x_hi - 2^-11 x_lo'| <= 2^-22 |x|)
-// the low plane is kept scaled by 2^11 so that it has the exponent range of the high plane (no fp16 underflow for
-// 6e-5 <= |x| <= 65504; below that the representation degrades gracefully to an absolute 2^-36).  The weights are static:
-// their planes are made once at commit time from 2^s W (s per matrix: max |2^s w| in [2^13, 2^14)) as hi, lo (unscaled)
-// and hi 2^-11, so that the three products that matter
-//   x_hi w_hi + x_hi w_lo + x_lo' (2^-11 w_hi)        (dropped: lo x lo <= 2^-22 |xw|)
-// all land in ONE fp32 accumulator with their true weight; every product of two 11-bit significands is exact in fp32.
-// 24 MFMAs (v_mfma_f32_32x32x16_f16, same rate as bf16) per wave and K tile instead of 48, two activation planes in LDS
-// instead of three.  Measured representation error of a K=512 contraction: 1.0e-7 rms of mean |C| for activations of
-// typical magnitude 1e-4 ... 65504 (fp32 sequential accumulation: 3.6e-7; bf16x3: 7e-9) - tests/test_gpu_kernels.py.
-template <int DBG, bool H2>
+template <int DBG>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmX3Params p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem3[];
-    constexpr int XP = H2 ? 2 : 3;         // activation planes
-    uint16_t* As = smem3;                  // [XP][128][40] activations (planes)
-    uint16_t* Bs = smem3 + XP * X3_PLANE;  // [3][128][40] weights
+    uint16_t* As = smem3;                 // [3][128][40] activations (planes)
+    uint16_t* Bs = smem3 + 3 * X3_PLANE;  // [3][128][40] weights
 
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int per_xcd = (p.total + 7) / 8;
@@ -116,31 +101,19 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmX3Params p) {
     auto lstore = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            uint16_t* dst = &As[(a_row + 32 * i) * X3_LD + a_c4];
-            if constexpr (H2) {
-                x3_f16x4 h0, h1;
+            x3_bf16x4 h0, h1, h2;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = ra[i][e];
-                    const _Float16 a = (_Float16)v;
-                    h0[e] = a; h1[e] = (_Float16)((v - (float)a) * 2048.f);
-                }
-                *reinterpret_cast<x3_f16x4*>(dst) = h0;
-                *reinterpret_cast<x3_f16x4*>(dst + X3_PLANE) = h1;
-            } else {
-                x3_bf16x4 h0, h1, h2;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = ra[i][e];
-                    const __bf16 a = (__bf16)v;
-                    const float r1 = v - (float)a;
-                    const __bf16 b = (__bf16)r1;
-                    h0[e] = a; h1[e] = b; h2[e] = (__bf16)(r1 - (float)b);
-                }
-                *reinterpret_cast<x3_bf16x4*>(dst) = h0;
-                *reinterpret_cast<x3_bf16x4*>(dst + X3_PLANE) = h1;
-                *reinterpret_cast<x3_bf16x4*>(dst + 2 * X3_PLANE) = h2;
+            for (int e = 0; e < 4; ++e) {
+                const float v = ra[i][e];
+                const __bf16 a = (__bf16)v;
+                const float r1 = v - (float)a;
+                const __bf16 b = (__bf16)r1;
+                h0[e] = a; h1[e] = b; h2[e] = (__bf16)(r1 - (float)b);
             }
+            uint16_t* dst = &As[(a_row + 32 * i) * X3_LD + a_c4];
+            *reinterpret_cast<x3_bf16x4*>(dst) = h0;
+            *reinterpret_cast<x3_bf16x4*>(dst + X3_PLANE) = h1;
+            *reinterpret_cast<x3_bf16x4*>(dst + 2 * X3_PLANE) = h2;
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) *reinterpret_cast<x3_u32x4*>(&Bs[w_lds[i]]) = rw[i];
@@ -160,49 +133,31 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmX3Params p) {
         const uint16_t* bs = &Bs[(wc * 64 + l31) * X3_LD + lh * 8];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            x3_u32x4 x[2][XP], w[2][3];  // 8 16-bit elements each (bf16 or fp16 planes)
+            x3_bf16x8 x[2][3], w[2][3];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int pl = 0; pl < XP; ++pl)
-                    x[t][pl] = *reinterpret_cast<const x3_u32x4*>(as + pl * X3_PLANE + t * 32 * X3_LD + ks * 16);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    w[t][pl] = *reinterpret_cast<const x3_u32x4*>(bs + pl * X3_PLANE + t * 32 * X3_LD + ks * 16);
-            }
+                for (int pl = 0; pl < 3; ++pl) {
+                    x[t][pl] = *reinterpret_cast<const x3_bf16x8*>(as + pl * X3_PLANE + t * 32 * X3_LD + ks * 16);
+                    w[t][pl] = *reinterpret_cast<const x3_bf16x8*>(bs + pl * X3_PLANE + t * 32 * X3_LD + ks * 16);
+                }
             if (DBG & 1) {  // profiling: operand pipeline only
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int pl = 0; pl < XP; ++pl) acc[0][0][t] += __uint_as_float(x[t][pl][0]);
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) acc[0][0][t] += __uint_as_float(w[t][pl][0]);
-                }
+                    for (int pl = 0; pl < 3; ++pl) acc[0][0][t] += (float)x[t][pl][0] + (float)w[t][pl][0];
                 continue;
             }
             // smallest terms first; weights are the MFMA A operand (rows -> registers), activations B (rows -> lanes).
             // Consecutive MFMAs go to DIFFERENT accumulators: no back-to-back dependency on one accumulator tile.
-            if constexpr (H2) {
-                constexpr int PW[3] = {1, 2, 0}, PX[3] = {0, 1, 0};  // x_hi w_lo, x_lo' (2^-11 w_hi), x_hi w_hi
+            constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < 6; ++q)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x3_f16x8, w[j][PW[q]]),
-                                                                               __builtin_bit_cast(x3_f16x8, x[i][PX[q]]), acc[j][i], 0, 0, 0);
-            } else {
-                constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int q = 0; q < 6; ++q)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x3_bf16x8, w[j][PW[q]]),
-                                                                                __builtin_bit_cast(x3_bf16x8, x[i][PX[q]]), acc[j][i], 0, 0, 0);
-            }
+                    for (int i = 0; i < 2; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[j][PW[q]], x[i][PX[q]], acc[j][i], 0, 0, 0);
         }
     };
     auto epilogue = [&](int t) {
@@ -220,7 +175,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmX3Params p) {
                     x3_f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
-                    if constexpr (H2) v *= p.out_scale;
                     if (p.bias) v += *reinterpret_cast<const x3_f32x4*>(p.bias + n);
                     if (p.relu) {
 #pragma unroll
@@ -263,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmX3Params p) {
 }
 
 int launch_gemm_x3(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* W3, int64_t ldw3, hipStream_t s, float h2_out_scale) {
-    const bool h2 = h2_out_scale != 0.f;  // W3 = fp16 planes of 2^s W (hi, lo, hi 2^-11), h2_out_scale = 2^-s
+    if (h2_out_scale != 0.f) return launch_gemm_h2(ctx, a, W3, ldw3, h2_out_scale, s);  // f16x2 planes: gemm_h2.hip
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.batch != 1) return set_err(ctx, E2EMV_ESHAPE, "gemm_x3: empty problem or batch != 1");
     const int K1 = a.A2 ? a.K1 : a.K;
     if (a.K % 32 || K1 % 32 || K1 > a.K || (K1 < a.K && !a.A2)) return set_err(ctx, E2EMV_ESHAPE, "gemm_x3: K=%d K1=%d must be multiples of 32", a.K, K1);
@@ -278,20 +232,15 @@ int launch_gemm_x3(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* W3, int64_
     p.tiles_n = (a.N + X3_BN - 1) / X3_BN;
     p.total = p.tiles_m * p.tiles_n;
     p.relu = a.relu ? 1 : 0;
-    p.out_scale = h2_out_scale;
     const int per_xcd = (p.total + 7) / 8;
     const int sl = std::min(per_xcd, std::max(1, ctx->num_cus * 2 / 8));
-    const size_t lds = sizeof(uint16_t) * (h2 ? 5 : 6) * X3_PLANE;
+    const size_t lds = sizeof(uint16_t) * 6 * X3_PLANE;
     static int dbg = -1;  // profiling knob E2EMV_X3_DEBUG: bit0 no MFMA, bit1 no operand loads after the first K tile
     if (dbg < 0) { const char* e = getenv("E2EMV_X3_DEBUG"); dbg = e ? atoi(e) : 0; }
-    if (h2) {
-        if (dbg == 1) hipLaunchKernelGGL((gemm_x3_kernel<1, true>), dim3(8 * sl), dim3(256), lds, s, p);
-        else if (dbg == 2) hipLaunchKernelGGL((gemm_x3_kernel<2, true>), dim3(8 * sl), dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((gemm_x3_kernel<0, true>), dim3(8 * sl), dim3(256), lds, s, p);
-    } else if (dbg == 1) hipLaunchKernelGGL((gemm_x3_kernel<1, false>), dim3(8 * sl), dim3(256), lds, s, p);
-    else if (dbg == 2) hipLaunchKernelGGL((gemm_x3_kernel<2, false>), dim3(8 * sl), dim3(256), lds, s, p);
-    else if (dbg == 6) hipLaunchKernelGGL((gemm_x3_kernel<6, false>), dim3(8 * sl), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((gemm_x3_kernel<0, false>), dim3(8 * sl), dim3(256), lds, s, p);
+    if (dbg == 1) hipLaunchKernelGGL(gemm_x3_kernel<1>, dim3(8 * sl), dim3(256), lds, s, p);
+    else if (dbg == 2) hipLaunchKernelGGL(gemm_x3_kernel<2>, dim3(8 * sl), dim3(256), lds, s, p);
+    else if (dbg == 6) hipLaunchKernelGGL(gemm_x3_kernel<6>, dim3(8 * sl), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(gemm_x3_kernel<0>, dim3(8 * sl), dim3(256), lds, s, p);
     E2EMV_CHECK_LAUNCH(ctx, "gemm_x3_kernel");
     return E2EMV_OK;
 }

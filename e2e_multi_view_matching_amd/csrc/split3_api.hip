@@ -60,14 +60,14 @@ extern "C" int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const f
     if (rc) return rc;
     uint16_t* A3 = (uint16_t*)ctx->d_ws;
     uint16_t* W3 = (uint16_t*)(ctx->d_ws + szA);
-    if (flags & 4) {  // f16x2 form of gemm_x3.hip; the weight planes are made on the host as e2emv_commit_weights makes them
+    if (flags & 4) {  // f16x2 GEMM (gemm_h2.hip); the weight planes are made on the host as e2emv_commit_weights makes them
         std::vector<float> hw((size_t)Nout * K);
         E2EMV_HIP(ctx, hipStreamSynchronize(s));
         E2EMV_HIP(ctx, hipMemcpy(hw.data(), d_W, hw.size() * sizeof(float), hipMemcpyDeviceToHost));
         std::vector<uint16_t> planes;
         float out_scale = 0.f;
         const size_t off = add_split_h2(planes, hw, Nout, K, &out_scale);
-        E2EMV_HIP(ctx, hipMemcpy(W3, planes.data() + off, (size_t)Nout * 3 * K * 2, hipMemcpyHostToDevice));
+        E2EMV_HIP(ctx, hipMemcpy(W3, planes.data() + off, (size_t)Nout * 2 * K * 2, hipMemcpyHostToDevice));
         GemmArgs g;
         g.M = M; g.N = Nout; g.K = K; g.K1 = K; g.A = d_A; g.lda = K; g.bias = d_bias; g.C = d_C; g.ldc = Nout; g.relu = (flags & 1) != 0;
         prof_begin(ctx, PS_GEMM, s);

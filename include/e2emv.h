@@ -320,7 +320,7 @@ int e2emv_set_split_min_rows(e2emv_ctx* ctx, int64_t min_rows);
 /* building blocks of the bf16x3 path on fp32 buffers (split / merge done internally; for tests):
  * C = act(A W^T + bias), A [M,K], W [N,K], C [M,N]; flags bit0 relu, bit1 = first-generation kernel reading pre-split
  * activation planes (gemm3.hip) instead of the default gemm_x3.hip (fp32 activations split on the way into LDS),
- * bit2 = the f16x2 form of gemm_x3.hip (host-synchronising: the weight planes are made on the host). */
+ * bit2 = the f16x2 GEMM, gemm_h2.hip (host-synchronising: the weight planes are made on the host). */
 int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const float* d_A, const float* d_W, const float* d_bias,
                       float* d_C, int flags, void* stream);
 /* same contract as e2emv_attention; cross: bit0 = cross layer, bit1 = the forward pass's kernel (fp32 q|k|v in, the
