@@ -461,16 +461,25 @@ __global__ __launch_bounds__(256, 2) void attention3f_kernel(Attn3fParams p) {
 constexpr float H2_QS = 64.f, H2_KVS = 16.f, H2_SINV = 1.f / 1024.f, H2_PLOG = 10.f;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
-// (x c) -> hi + lo.  The product is made opaque before it is converted: hipcc 7.2 otherwise selects the high plane
-// twice - v_cvt_pk_f16_f32 of the rounded fp32 product for the stored plane, v_fma_mixlo_f16(x, c, 0) for the copy the
-// residual is taken against - and on gfx950 the two differ by an fp16 ulp when x c lies within an fp32 rounding of an
-// fp16 tie (the mix instruction rounds the exact product once): hi + lo is then off by 2^-11 of that element.  Found as
-// one query row in 512 with 1.4e-4 error; pinned by test_attention_split_kernels_near_fp16_ties.
-__device__ __forceinline__ void split2h(float x, float c, _Float16& a, _Float16& b) {
-    float v = x * c;
-    asm("" : "+v"(v));
-    a = (_Float16)v;
-    b = (_Float16)(v - (float)a);
+// (x0 c, x1 c) -> packed fp16 pairs hi, lo with hi + lo = x c to 2^-22.  hi = one v_cvt_pk_f16_f32; lo = v - hi by
+// v_fma_mix{lo,hi}_f16, which read hi as fp16 and round the exact fp32 residual once (1.5 VALU per element instead of 3).
+// The products are made opaque before they are converted: left to itself hipcc 7.2 selects the high plane twice -
+// v_cvt_pk_f16_f32 of the rounded fp32 product for the stored plane, v_fma_mixlo_f16(x, c, 0) for the copy the residual is
+// taken against - and on gfx950 the two differ by an fp16 ulp when x c lies within an fp32 rounding of an fp16 tie (the mix
+// instruction rounds the exact product once): hi + lo was then off by 2^-11 of that element.  Found as one query row in
+// 512 with 1.4e-4 error; pinned by test_attention_split_kernels_near_fp16_ties.
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+struct H2Pair { unsigned hi, lo; };
+__device__ __forceinline__ H2Pair split2h_pair(float x0, float x1, float c) {
+    unsigned hi, lo;
+    float v0 = x0 * c, v1 = x1 * c;
+    asm("" : "+v"(v0), "+v"(v1));
+    const f32x2 vv = {v0, v1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(vv, f16x2));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo) : "v"(hi), "v"(v0), "v"(v1));
+    return {hi, lo};
 }
 
 __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
@@ -492,17 +501,17 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
 
     // ---- Q fragments (B operand): lane (q, lh) holds Q_pl[q][16 s + 8 lh .. +7]
     const int q_row = qt * A3_Q + wave * 32 + l31;
-    f16x8 Qf[2][4];
+    u32x4 Qf[2][4];  // 8 fp16 each
     {
         const float* qp = p.qkv + ((int64_t)img * p.n_rows + q_row) * ld + head * A3_HD + lh * 8;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(qp + s * 16), hi = *reinterpret_cast<const f32x4*>(qp + s * 16 + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                _Float16 a, bb;
-                split2h(e < 4 ? lo[e] : hi[e - 4], p.q_scale * H2_QS, a, bb);
-                Qf[0][s][e] = a; Qf[1][s][e] = bb;
+            for (int e = 0; e < 4; ++e)
+            {
+                const H2Pair pr = split2h_pair(e < 2 ? lo[2 * e] : hi[2 * e - 4], e < 2 ? lo[2 * e + 1] : hi[2 * e - 3], p.q_scale * H2_QS);
+                Qf[0][s][e] = pr.hi; Qf[1][s][e] = pr.lo;
             }
         }
     }
@@ -549,34 +558,33 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
     };
     auto lstore = [&]() {
         // K: 16 values -> 2 planes x 32 B
-        f16x8 kh[2][2];
+        u32x4 kh[2][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 a, bb;
-                split2h(rk[i][e], H2_KVS, a, bb);
-                kh[0][i >> 1][(i & 1) * 4 + e] = a; kh[1][i >> 1][(i & 1) * 4 + e] = bb;
+            for (int e = 0; e < 2; ++e)
+            {
+                const H2Pair pr = split2h_pair(rk[i][2 * e], rk[i][2 * e + 1], H2_KVS);
+                kh[0][i >> 1][(i & 1) * 2 + e] = pr.hi; kh[1][i >> 1][(i & 1) * 2 + e] = pr.lo;
             }
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
             uint16_t* kd = &Ks[pl * A3_PLANE + k_row * A3_LD + k_c16];
-            *reinterpret_cast<f16x8*>(kd) = kh[pl][0];
-            *reinterpret_cast<f16x8*>(kd + 8) = kh[pl][1];
+            *reinterpret_cast<u32x4*>(kd) = kh[pl][0];
+            *reinterpret_cast<u32x4*>(kd + 8) = kh[pl][1];
         }
         // V^T: rv[i][e] = V[key 4 kb + i][dim d0 + e]
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            f16x4 vh[2];
+            u32x2 vh[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                _Float16 a, bb;
-                split2h(rv[i][e], H2_KVS, a, bb);
-                vh[0][i] = a; vh[1][i] = bb;
+            for (int i = 0; i < 2; ++i) {
+                const H2Pair pr = split2h_pair(rv[2 * i][e], rv[2 * i + 1][e], H2_KVS);
+                vh[0][i] = pr.hi; vh[1][i] = pr.lo;
             }
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
-                *reinterpret_cast<f16x4*>(&Vs[pl * A3_PLANE + (v_d0 + e) * A3_LD + v_lds]) = vh[pl];
+                *reinterpret_cast<u32x2*>(&Vs[pl * A3_PLANE + (v_d0 + e) * A3_LD + v_lds]) = vh[pl];
         }
     };
 
@@ -606,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) kf[pl] = *reinterpret_cast<const f16x8*>(kp + pl * A3_PLANE + s * 16);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[PA[q]], Qf[PB[q]][s], S, 0, 0, 0);
+                for (int q = 0; q < 3; ++q) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[PA[q]], __builtin_bit_cast(f16x8, Qf[PB[q]][s]), S, 0, 0, 0);
             }
             if (valid_in_tile < sub * 32 + 32) {
 #pragma unroll
@@ -624,15 +632,14 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * H2_SINV);
             const float e0 = H2_PLOG - m_new * H2_SINV;
             float ps = 0.f;
-            f16x8 Pf[2][2];
+            u32x4 Pf[2][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], H2_SINV, e0));
-                ps += pv;
-                _Float16 a, bb;
-                split2h(pv, 1.f, a, bb);
-                Pf[0][r >> 3][r & 7] = a;
-                Pf[1][r >> 3][r & 7] = bb;
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], H2_SINV, e0));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r + 1], H2_SINV, e0));
+                ps += p0 + p1;
+                const H2Pair pr = split2h_pair(p0, p1, 1.f);
+                Pf[0][r >> 3][(r & 7) >> 1] = pr.hi; Pf[1][r >> 3][(r & 7) >> 1] = pr.lo;
             }
             l_run = l_run * alpha + ps;
             m_run = m_new;
@@ -649,8 +656,8 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
                 }
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0[PA[q]], Pf[PB[q]][u], O0, 0, 0, 0);
-                    O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1[PA[q]], Pf[PB[q]][u], O1, 0, 0, 0);
+                    O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0[PA[q]], __builtin_bit_cast(f16x8, Pf[PB[q]][u]), O0, 0, 0, 0);
+                    O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1[PA[q]], __builtin_bit_cast(f16x8, Pf[PB[q]][u]), O1, 0, 0, 0);
                 }
             }
         }

@@ -131,9 +131,10 @@ int e2emv_create(e2emv_ctx** out, int device) {
     ctx->num_cus = p.multiProcessorCount;
     if (const char* e = getenv("E2EMV_NO_FUSE_MERGE")) ctx->fuse_merge = !(e[0] == '1');
     if (const char* e = getenv("E2EMV_B3_PLANES")) ctx->b3_planes = e[0] == '1';
-    // default arithmetic of the dense GNN contractions: the split-operand bf16 path (fp32-class accuracy, every parity
-    // test runs in both modes at the same bar); E2EMV_PRECISION=f32 selects the exact fp32-MFMA kernels
-    ctx->precision = ctx->fuse_merge ? E2EMV_PRECISION_BF16X3 : E2EMV_PRECISION_F32;
+    // default arithmetic of the dense GNN contractions: the split-operand fp16 x 2 path (22-bit operands, fp32 accumulate;
+    // every parity test runs in all three modes at the same bar); E2EMV_PRECISION=bf16x3 selects the 24-bit bf16 x 3
+    // split, =f32 the exact fp32-MFMA kernels
+    ctx->precision = ctx->fuse_merge ? E2EMV_PRECISION_F16X2 : E2EMV_PRECISION_F32;
     if (const char* e = getenv("E2EMV_PRECISION")) {
         ctx->precision = E2EMV_PRECISION_F32;
         if (ctx->fuse_merge && strcmp(e, "bf16x3") == 0) ctx->precision = E2EMV_PRECISION_BF16X3;

@@ -37,9 +37,10 @@ typedef __attribute__((ext_vector_type(8))) _Float16 h2_f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 h2_f16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int h2_u32x4;
 
-constexpr int H2_BM = 256, H2_BN = 128, H2_BK = 32, H2_LD = 40;  // LDS rows: 32 halves + 8 pad = 80 B (conflict-free b128)
-constexpr int H2_APLANE = H2_BM * H2_LD, H2_WPLANE = H2_BN * H2_LD;
-constexpr int H2_BUF = 2 * H2_APLANE + 2 * H2_WPLANE;  // halves per LDS buffer (61 440 B)
+constexpr int H2_BM = 256, H2_BK = 32, H2_LD = 40;  // LDS rows: 32 halves + 8 pad = 80 B (conflict-free b128)
+constexpr int H2_APLANE = H2_BM * H2_LD;
+// NJ = 32-column blocks per wave: 2 -> 256 x 128 tile, LDS double-buffered (2 x 60 KB), one barrier per K step;
+//                                 4 -> 256 x 256 tile, one 80 KB buffer, two barriers per K step, 128 accumulator registers
 
 struct GemmH2Params {
     const float* A;
@@ -57,9 +58,12 @@ struct GemmH2Params {
     long long* dbg;   // E2EMV_X3_DEBUG=8: phase timestamps of two workgroups
 };
 
-template <int DBG>
+template <int DBG, int NJ>
 __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_h2[];
+    constexpr int H2_BN = 64 * NJ, H2_WPLANE = H2_BN * H2_LD, H2_BUF = 2 * H2_APLANE + 2 * H2_WPLANE;
+    constexpr bool DB = NJ == 2;   // LDS double-buffered
+    constexpr int WR = H2_BN / 128;  // weight rows per thread and plane
 
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int per_xcd = (p.total + 7) / 8;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
 
     // operand addresses as 32-bit element offsets from the uniform base pointers (the launcher checks the spans); they
     // belong to the load position (ld_tile, ld_kt), which runs two K steps ahead of the compute position across tiles
-    unsigned a_off[4], a2_off[4], w_off;
+    unsigned a_off[4], a2_off[4], w_off[WR];
     auto setup = [&](int t) {
         const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
 #pragma unroll
@@ -89,11 +93,12 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
             a_off[i] = ra * p.lda + a_c4;
             a2_off[i] = ra * p.lda2 + a_c4;
         }
-        w_off = (unsigned)min(tn * H2_BN + w_row, p.N - 1) * 2u * p.ldw + w_k8;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) w_off[r] = (unsigned)min(tn * H2_BN + w_row + 128 * r, p.N - 1) * 2u * p.ldw + w_k8;
     };
 
     h2_f32x4 ra[4];
-    h2_u32x4 rw[2];
+    h2_u32x4 rw[WR][2];
     int ld_tile = tile, ld_kt = 0;
     // straight-line: issue the loads of the current load position (no control flow - this sits in the MFMA block)
     auto gload = [&]() {
@@ -103,8 +108,11 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
         const unsigned kk = first ? k : k - p.K1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const h2_f32x4*>(base + ((first ? a_off[i] : a2_off[i]) + kk));
-        rw[0] = *reinterpret_cast<const h2_u32x4*>(p.WH + (w_off + k));
-        rw[1] = *reinterpret_cast<const h2_u32x4*>(p.WH + (w_off + p.ldw + k));
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+            rw[r][0] = *reinterpret_cast<const h2_u32x4*>(p.WH + (w_off[r] + k));
+            rw[r][1] = *reinterpret_cast<const h2_u32x4*>(p.WH + (w_off[r] + p.ldw + k));
+        }
     };
     // move the load position one K step on; past the last step of the last tile it stays put (the loads then re-fetch
     // that step, harmlessly, and nothing stores them)
@@ -122,25 +130,38 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
         uint16_t* Ws = As + 2 * H2_APLANE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            h2_f16x4 h0, h1;
+            // hi = fp16(v): one v_cvt_pk_f16_f32 per pair; lo' = 2^11 (v - hi): v_fma_mix{lo,hi}_f16(hi as fp16, -2048, 2048 v),
+            // the exact fp32 residual rounded once to fp16 - 2.5 VALU per element
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            u32x2 h0, h1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = ra[i][e];
-                const _Float16 a = (_Float16)v;
-                h0[e] = a; h1[e] = (_Float16)((v - (float)a) * 2048.f);
+            for (int e = 0; e < 2; ++e) {
+                const float v0 = ra[i][2 * e], v1 = ra[i][2 * e + 1];
+                const f32x2 vv = {v0, v1};
+                const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(vv, f16x2));
+                const float s0 = v0 * 2048.f, s1 = v1 * 2048.f;
+                unsigned lo;
+                asm("v_fma_mixlo_f16 %0, %1, %4, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %4, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                    : "=&v"(lo) : "v"(hi), "v"(s0), "v"(s1), "s"(-2048.f));
+                h0[e] = hi; h1[e] = lo;
             }
             uint16_t* dst = &As[(a_row + 64 * i) * H2_LD + a_c4];
-            *reinterpret_cast<h2_f16x4*>(dst) = h0;
-            *reinterpret_cast<h2_f16x4*>(dst + H2_APLANE) = h1;
+            *reinterpret_cast<u32x2*>(dst) = h0;
+            *reinterpret_cast<u32x2*>(dst + H2_APLANE) = h1;
         }
-        *reinterpret_cast<h2_u32x4*>(&Ws[w_row * H2_LD + w_k8]) = rw[0];
-        *reinterpret_cast<h2_u32x4*>(&Ws[H2_WPLANE + w_row * H2_LD + w_k8]) = rw[1];
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+            *reinterpret_cast<h2_u32x4*>(&Ws[(w_row + 128 * r) * H2_LD + w_k8]) = rw[r][0];
+            *reinterpret_cast<h2_u32x4*>(&Ws[H2_WPLANE + (w_row + 128 * r) * H2_LD + w_k8]) = rw[r][1];
+        }
     };
 
-    h2_f32x16 acc[2][2];
+    h2_f32x16 acc[NJ][2];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -148,36 +169,33 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
     };
     auto compute = [&](int buf) {
         const uint16_t* as = smem_h2 + buf * H2_BUF + (wr * 64 + l31) * H2_LD + lh * 8;
-        const uint16_t* bs = smem_h2 + buf * H2_BUF + 2 * H2_APLANE + (wc * 64 + l31) * H2_LD + lh * 8;
+        const uint16_t* bs = smem_h2 + buf * H2_BUF + 2 * H2_APLANE + (wc * 32 * NJ + l31) * H2_LD + lh * 8;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            h2_f16x8 x[2][2], w[2][3];
+            h2_f16x8 x[2][2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    x[t][pl] = *reinterpret_cast<const h2_f16x8*>(as + pl * H2_APLANE + t * 32 * H2_LD + ks * 16);
-                    w[t][pl] = *reinterpret_cast<const h2_f16x8*>(bs + pl * H2_WPLANE + t * 32 * H2_LD + ks * 16);
+                for (int pl = 0; pl < 2; ++pl) x[t][pl] = *reinterpret_cast<const h2_f16x8*>(as + pl * H2_APLANE + t * 32 * H2_LD + ks * 16);
+            // weights are the MFMA A operand (rows -> registers), activations B (rows -> lanes); per 32-column block the
+            // two accumulators alternate, smallest terms first
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                h2_f16x8 w[3];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) w[pl] = *reinterpret_cast<const h2_f16x8*>(bs + pl * H2_WPLANE + j * 32 * H2_LD + ks * 16);
+                w[2] = w[0] * (_Float16)(1.f / 2048.f);  // 2^-11 w_hi: exact (w_hi is >= 2^-3 wherever it matters)
+                if (DBG & 1) {  // profiling: operand pipeline only
+                    acc[j][0][ks] += (float)x[0][0][0] + (float)x[0][1][0] + (float)x[1][0][0] + (float)x[1][1][0] + (float)w[0][0] + (float)w[1][0];
+                    continue;
                 }
-                w[t][2] = w[t][0] * (_Float16)(1.f / 2048.f);  // 2^-11 w_hi: exact (w_hi is >= 2^-3 wherever it matters)
-            }
-            if (DBG & 1) {  // profiling: operand pipeline only
+                constexpr int PW[3] = {1, 2, 0}, PX[3] = {0, 1, 0};  // x_hi w_lo, x_lo' (2^-11 w_hi), x_hi w_hi
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) acc[0][0][t] += (float)x[t][pl][0] + (float)w[t][pl][0];
-                continue;
-            }
-            // smallest terms first; weights are the MFMA A operand (rows -> registers), activations B (rows -> lanes).
-            // Consecutive MFMAs go to DIFFERENT accumulators: no back-to-back dependency on one accumulator tile.
-            constexpr int PW[3] = {1, 2, 0}, PX[3] = {0, 1, 0};  // x_hi w_lo, x_lo' (2^-11 w_hi), x_hi w_hi
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int q = 0; q < 3; ++q)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j][PW[q]], x[i][PX[q]], acc[j][i], 0, 0, 0);
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[PW[q]], x[i][PX[q]], acc[j][i], 0, 0, 0);
+            }
         }
     };
     auto epilogue = [&](int t) {
@@ -187,10 +205,10 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
             const int m = tm * H2_BM + wr * 64 + i * 32 + l31;
             if (m >= p.M) continue;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = tn * H2_BN + wc * 64 + j * 32 + 8 * g + 4 * lh;
+                    const int n = tn * H2_BN + wc * 32 * NJ + j * 32 + 8 * g + 4 * lh;
                     if (n >= p.N) continue;
                     h2_f32x4 v;
 #pragma unroll
@@ -228,14 +246,26 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
         for (int kt = 0; kt < nk; ++kt) {
             long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
             if (DBG & 8) t0 = clock64();
-            lstore(buf ^ 1);  // step g + 1 into the other buffer (its readers passed the barrier of step g - 1)
-            if (DBG & 8) t1 = clock64();
-            gload();          // step g + 2
-            if (DBG & 8) t2 = clock64();
-            compute(buf);
-            if (DBG & 8) t3 = clock64();
-            advance();
-            __syncthreads();
+            if constexpr (DB) {
+                lstore(buf ^ 1);  // step g + 1 into the other buffer (its readers passed the barrier of step g - 1)
+                if (DBG & 8) t1 = clock64();
+                gload();          // step g + 2
+                if (DBG & 8) t2 = clock64();
+                compute(buf);
+                if (DBG & 8) t3 = clock64();
+                advance();
+                __syncthreads();
+            } else {
+                compute(0);
+                if (DBG & 8) t1 = clock64();
+                __syncthreads();  // every wave is done reading step g
+                lstore(0);        // step g + 1 (after the last step: stale registers nobody reads)
+                if (DBG & 8) t2 = clock64();
+                gload();          // step g + 2
+                if (DBG & 8) t3 = clock64();
+                advance();
+                __syncthreads();
+            }
             if (DBG & 8) {
                 const long long t4 = clock64();
                 if (p.dbg && lane == 0 && dbg_n < 48 && (blockIdx.x == 0 || blockIdx.x == 101)) {
@@ -244,7 +274,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
                     ++dbg_n;
                 }
             }
-            buf ^= 1;
+            if constexpr (DB) buf ^= 1;
         }
         epilogue(tile);
         tile += slots;
@@ -266,32 +296,53 @@ int launch_gemm_h2(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* WH, int64_
     p.A = a.A; p.A2 = a.A2 ? a.A2 : a.A; p.WH = WH; p.bias = a.bias; p.R = a.R; p.C = a.C;
     p.lda = (unsigned)a.lda; p.lda2 = (unsigned)(a.A2 ? a.lda2 : a.lda); p.ldw = (unsigned)ldw; p.ldr = a.ldr; p.ldc = a.ldc;
     p.M = a.M; p.N = a.N; p.K = a.K; p.K1 = K1;
+    // tile shape: 256 x 256 when N fills it (per MAC 4/256 + 4/256 B cross L2 instead of 4/128 + 4/256), else 256 x 128
+    static int nj_env = -1;  // E2EMV_H2_NJ=2|4 forces a shape
+    static int dbg = -1;     // profiling knob E2EMV_X3_DEBUG: 1 no MFMA, 2 L2-resident operands only, 8 phase timestamps
+    if (nj_env < 0) { const char* e = getenv("E2EMV_H2_NJ"); nj_env = e ? atoi(e) : 0; }
+    if (dbg < 0) { const char* e = getenv("E2EMV_X3_DEBUG"); dbg = e ? atoi(e) : 0; }
+    const int nj = nj_env == 2 || nj_env == 4 ? nj_env : (a.N % 256 == 0 ? 4 : 2);
+    const int bn = 64 * nj;
     const int tiles_m = (a.M + H2_BM - 1) / H2_BM;
-    p.tiles_n = (a.N + H2_BN - 1) / H2_BN;
+    p.tiles_n = (a.N + bn - 1) / bn;
     p.total = tiles_m * p.tiles_n;
     p.relu = a.relu ? 1 : 0;
     p.out_scale = out_scale;
     p.dbg = nullptr;
     const int per_xcd = (p.total + 7) / 8;
     const int sl = std::min(per_xcd, std::max(1, ctx->num_cus / 8));
-    const size_t lds = sizeof(uint16_t) * 2 * H2_BUF;
-    static bool attr_set = false;
-    static int dbg = -1;  // profiling knob E2EMV_X3_DEBUG: bit0 no MFMA, bit1 no operand loads after the first K tile
-    if (dbg < 0) { const char* e = getenv("E2EMV_X3_DEBUG"); dbg = e ? atoi(e) : 0; }
-    if (!attr_set) {
-        E2EMV_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        E2EMV_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        E2EMV_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    const size_t lds = sizeof(uint16_t) * (nj == 2 ? 2 : 1) * (2 * H2_APLANE + 2 * bn * H2_LD);
+    const void* fn = nullptr;
+    switch (dbg * 10 + nj) {
+        case 12: fn = reinterpret_cast<const void*>(gemm_h2_kernel<1, 2>); break;
+        case 14: fn = reinterpret_cast<const void*>(gemm_h2_kernel<1, 4>); break;
+        case 22: fn = reinterpret_cast<const void*>(gemm_h2_kernel<2, 2>); break;
+        case 24: fn = reinterpret_cast<const void*>(gemm_h2_kernel<2, 4>); break;
+        case 82: fn = reinterpret_cast<const void*>(gemm_h2_kernel<8, 2>); break;
+        case 84: fn = reinterpret_cast<const void*>(gemm_h2_kernel<8, 4>); break;
+        default: fn = nj == 2 ? reinterpret_cast<const void*>(gemm_h2_kernel<0, 2>) : reinterpret_cast<const void*>(gemm_h2_kernel<0, 4>);
     }
+    static const void* attr_done[8] = {};
+    bool seen = false;
+    for (const void* f : attr_done) seen |= f == fn;
+    if (!seen) {
+        E2EMV_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (auto& f : attr_done)
+            if (!f) { f = fn; break; }
+    }
+    long long* d_dbg = nullptr;
+    const size_t nb = sizeof(long long) * 2 * 8 * 48 * 5;
     if (dbg == 8) {  // phase timestamps of workgroups 0 and 101, printed after the launch (host-synchronising; profiling only)
-        static long long* d_dbg = nullptr;
-        const size_t nb = sizeof(long long) * 2 * 8 * 48 * 5;
-        if (!d_dbg) E2EMV_HIP(ctx, hipMalloc((void**)&d_dbg, nb));
+        static long long* d_buf = nullptr;
+        if (!d_buf) E2EMV_HIP(ctx, hipMalloc((void**)&d_buf, nb));
+        d_dbg = d_buf;
         E2EMV_HIP(ctx, hipMemsetAsync(d_dbg, 0, nb, s));
         p.dbg = d_dbg;
-        E2EMV_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(gemm_h2_kernel<8>, dim3(8 * sl), dim3(512), lds, s, p);
+    }
+    void* args[] = {&p};
+    E2EMV_HIP(ctx, hipLaunchKernel(fn, dim3(8 * sl), dim3(512), args, lds, s));
+    E2EMV_CHECK_LAUNCH(ctx, "gemm_h2_kernel");
+    if (dbg == 8) {
         E2EMV_HIP(ctx, hipStreamSynchronize(s));
         std::vector<long long> h(2 * 8 * 48 * 5);
         E2EMV_HIP(ctx, hipMemcpy(h.data(), d_dbg, nb, hipMemcpyDeviceToHost));
@@ -300,7 +351,7 @@ int launch_gemm_h2(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* WH, int64_
             for (int wg = 0; wg < 2; ++wg)
                 for (int w = 0; w < 8; w += 3) {
                     const long long* o = &h[((size_t)wg * 8 + w) * 48 * 5];
-                    fprintf(stderr, "gemm_h2 M=%d N=%d K=%d wg %d wave %d: step: split+store  load issue  fragments+mfma  barrier | total\n", p.M, p.N, p.K, wg ? 101 : 0, w);
+                    fprintf(stderr, "gemm_h2 M=%d N=%d K=%d tile 256x%d wg %d wave %d: cycles between the stamps of a step | total\n", p.M, p.N, p.K, bn, wg ? 101 : 0, w);
                     for (int i = 0; i < 40; ++i) {
                         const long long* t = o + i * 5;
                         if (!t[0]) break;
@@ -308,12 +359,7 @@ int launch_gemm_h2(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* WH, int64_
                                 t[4] - t[0], i + 1 < 48 && t[5] ? t[5] - t[4] : 0);
                     }
                 }
-        return E2EMV_OK;
     }
-    if (dbg == 1) hipLaunchKernelGGL(gemm_h2_kernel<1>, dim3(8 * sl), dim3(512), lds, s, p);
-    else if (dbg == 2) hipLaunchKernelGGL(gemm_h2_kernel<2>, dim3(8 * sl), dim3(512), lds, s, p);
-    else hipLaunchKernelGGL(gemm_h2_kernel<0>, dim3(8 * sl), dim3(512), lds, s, p);
-    E2EMV_CHECK_LAUNCH(ctx, "gemm_h2_kernel");
     return E2EMV_OK;
 }
 

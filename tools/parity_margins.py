@@ -1,0 +1,59 @@
+"""Prints the score / index margins of the three arithmetic modes against the CPU oracle (fp32 and fp64) on one 18-layer
+problem - the numbers quoted in DESIGN.md.  GPU box only (the oracle is used as the checker)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    from e2e_multi_view_matching_amd import MultiViewMatcher, _lib
+    from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
+    from oracle.matcher import matcher_forward
+    from test_gpu_matcher import _randomize_bn
+    gpu = torch.device("cuda", 0)
+    _lib.context(gpu).set_split_min_rows(0)
+    for name, w_id, n in (("random weights", False, 512), ("identity-like weights (matches found)", True, 512)):
+        torch.manual_seed(5)
+        cfg = {"sinkhorn_iterations": 100, "conf_mlp": True, "match_threshold": 0.0}
+        model = MultiViewMatcher(cfg).eval()
+        _randomize_bn(model, 5)
+        if w_id:
+            identity_like_state(model)
+        data = make_tuples(seed=5, batch=2, tuple_size=2, n_kpts=n)
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        ocfg = dict(model.config, full_output=True)
+        ref32 = matcher_forward(data, sd, ocfg)
+        d64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in data.items()}
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        try:
+            ref64 = matcher_forward(d64, sd64, ocfg)
+        except Exception as e:  # the oracle may be fp32-only
+            print("fp64 oracle unavailable:", e)
+            ref64 = None
+        model = model.to(gpu)
+        dg = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in data.items()}
+        print(f"== {name}, 18 layers, B=2, N={n}, 100 Sinkhorn iterations")
+        if ref64 is not None:
+            z32, z64 = ref32["scores_0_1"], ref64["scores_0_1"]
+            print(f"   oracle fp32 vs fp64: max |dZ| {float((z32.double() - z64).abs().max()):.2e}  index mismatches "
+                  f"{int((ref32['matches0_0_1'] != ref64['matches0_0_1']).sum())}")
+        for precision in ("f32", "bf16x3", "f16x2"):
+            model.config["mfma_precision"] = precision
+            with torch.no_grad():
+                out = model(dg)
+            z = out["scores_0_1"].cpu()
+            line = f"   {precision:7s} vs oracle fp32: max |dZ| {float((z - ref32['scores_0_1']).abs().max()):.2e}  index mismatches " \
+                   f"{int((out['matches0_0_1'].cpu() != ref32['matches0_0_1']).sum())}"
+            if ref64 is not None:
+                line += f" | vs fp64: max |dZ| {float((z.double() - ref64['scores_0_1']).abs().max()):.2e}  index mismatches " \
+                        f"{int((out['matches0_0_1'].cpu() != ref64['matches0_0_1']).sum())}"
+            print(line + f"  matched {int((out['matches0_0_1'] >= 0).sum())}")
+
+
+if __name__ == "__main__":
+    main()
