@@ -525,17 +525,11 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
     auto src_t = [&](int si) { return !p.cross ? t : (si < t ? si : si + 1); };
     int n_tiles = 0;
     for (int si = 0; si < n_src; ++si) n_tiles += (p.nv[src_t(si)] + A3_KV - 1) / A3_KV;
-    auto locate = [&](int tile, int& tt, int& kt) {
-        int si = 0;
-        for (;; ++si) {
-            const int n = (p.nv[src_t(si)] + A3_KV - 1) / A3_KV;
-            if (tile < n || si + 1 == n_src) break;
-            tile -= n;
-        }
-        tt = src_t(si);
-        kt = tile;
+    // walk over the key tiles of the source images: (source index, tile inside it), advanced one tile at a time
+    struct TilePos { int si, kt; };
+    auto advance_pos = [&](TilePos& tp) {
+        if (++tp.kt * A3_KV >= p.nv[src_t(tp.si)] && tp.si + 1 < n_src) { ++tp.si; tp.kt = 0; }
     };
-
     // staging.  K tile (64 keys x 64 dims fp32): thread -> key row tid/4, 16 dims (tid&3)*16: 4 x 16 B, 64 B contiguous.
     // V tile: thread -> a 4 keys x 4 dims block: key block kb = (lane>>2) (16 blocks), dims 16*wave + 4*(lane&3): 4 x 16 B
     // from 4 consecutive key rows; after the split it owns, per dim, 4 consecutive keys = one 8-byte V^T write per plane.
@@ -544,9 +538,8 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
     // V^T LDS position of keys 4 kb .. 4 kb + 3 inside their 16-key group (permuted order, see the header)
     const int v_lds = 16 * (v_kb >> 2) + 4 * ((v_kb & 3) >> 1) + 8 * (v_kb & 1);
     f32x4 rk[4], rv[4];
-    auto gload = [&](int tile) {
-        int tt, kt;
-        locate(tile, tt, kt);
+    auto gload = [&](const TilePos& tp) {
+        const int tt = src_t(tp.si), kt = tp.kt;
         const float* base = p.qkv + ((int64_t)(b * p.T + tt) * p.n_rows + kt * A3_KV) * ld + head * A3_HD;
         const float* kp = base + p.D + (int64_t)k_row * ld + k_c16;
         const float* vp = base + 2 * p.D + (int64_t)(4 * v_kb) * ld + v_d0;
@@ -591,16 +584,18 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
     constexpr int PA[3] = {1, 0, 0};  // plane of the A operand (K or V^T), smallest terms first
     constexpr int PB[3] = {0, 1, 0};  // plane of the B operand (Q or P)
 
-    gload(0);
+    TilePos cur{0, 0}, nxt{0, 0};
+    gload(nxt);
     for (int tile = 0; tile < n_tiles; ++tile) {
         __syncthreads();
         lstore();
         __syncthreads();
-        if (tile + 1 < n_tiles) gload(tile + 1);
-
-        int tt_cur, kt;
-        locate(tile, tt_cur, kt);
-        const int valid_in_tile = p.nv[tt_cur] - kt * A3_KV;
+        cur = nxt;
+        if (tile + 1 < n_tiles) {
+            advance_pos(nxt);
+            gload(nxt);
+        }
+        const int valid_in_tile = p.nv[src_t(cur.si)] - cur.kt * A3_KV;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             if (sub * 32 >= valid_in_tile) break;

@@ -568,7 +568,7 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 }
 
 // rows per workgroup: 8 waves x 4 rows up to 1024 columns, 8 x 2 rows up to 2048 (64 matrix values per lane either way)
-static inline int skr_rows(int64_t ldS) { return ldS <= 1024 ? 32 : 16; }
+static inline int skr_rows(int64_t) { return 32; }
 constexpr unsigned SKR_SPIN_LIMIT = 1u << 21;
 
 struct SkResParams {
@@ -640,9 +640,10 @@ __device__ __forceinline__ float exp_accurate(float x) {
 }
 
 template <int KT, bool FULL>
-__global__ __launch_bounds__(512, 4) void sinkhorn_resident(SkResParams p) {
+__global__ __launch_bounds__(512, KT <= 4 ? 4 : 2) void sinkhorn_resident(SkResParams p) {
     constexpr int W = KT * 256;                       // padded column count held by a wave
-    constexpr int RW = KT <= 4 ? 4 : 2;               // rows per wave: 64 matrix values per lane either way
+    constexpr int RW = 4;                             // rows per wave: 64 matrix values per lane (KT <= 4: two workgroups per
+                                                      // CU), 128 at KT = 8 (one per CU - half as many workgroups exchange)
     constexpr int ROWS = 8 * RW;                      // rows per workgroup
     constexpr int CPT = (W + 511) / 512;              // columns a thread folds / publishes
     extern __shared__ __attribute__((aligned(16))) float lds[];

@@ -307,7 +307,8 @@ def tuple_pose_errors(extrinsics, cam_to_world):
     pred = E[j_idx] @ np.linalg.inv(E[i_idx])
     cos_r = np.clip((np.einsum("pab,pab->p", gt[:, :3, :3], pred[:, :3, :3]) - 1.0) / 2.0, -1.0, 1.0)
     tg, tp = gt[:, :3, 3], pred[:, :3, 3]
-    cos_t = np.clip(np.einsum("pa,pa->p", tg, tp) / (np.linalg.norm(tg, axis=1) * np.linalg.norm(tp, axis=1)), -1.0, 1.0)
+    with np.errstate(invalid="ignore", divide="ignore"):  # a zero translation (image without matches) gives nan, as upstream
+        cos_t = np.clip(np.einsum("pa,pa->p", tg, tp) / (np.linalg.norm(tg, axis=1) * np.linalg.norm(tp, axis=1)), -1.0, 1.0)
     err_t = np.rad2deg(np.arccos(cos_t))
     return np.minimum(err_t, 180.0 - err_t), np.rad2deg(np.abs(np.arccos(cos_r)))
 

@@ -21,6 +21,6 @@ run_set() {  # config mode pairs kpts
   head -8 $OUT/r2_pmc_${cfg}_${mode}.md
 }
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null
-run_set c2 bf16x3 32 1024
-run_set c2 f32 32 1024
-run_set c4 bf16x3 80 1024
+run_set c2 f16x2 32 1024
+run_set c4 f16x2 80 1024
+
