@@ -15,6 +15,12 @@
 
 namespace e2emv {
 
+// ReLU with torch.relu's NaN behaviour: relu(NaN) = NaN.  fmaxf(NaN, 0) = 0 would turn a non-finite activation (an fp16
+// overflow in the f16x2 mode, a NaN in the inputs) into a silent zero instead of letting it reach the scores, where
+// e2emv_sync reports it.
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+
+
 // profile slots (kernel families)
 enum ProfSlot {
     PS_INGEST = 0,

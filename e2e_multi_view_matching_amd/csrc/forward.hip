@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void ingest_kenc0(IngestParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float* w = p.w0 + (c + e) * 3;
-            o[e] = fmaxf(w[0] * kx + w[1] * ky + w[2] * ks + p.b0[c + e], 0.f);
+            o[e] = relu_nan(w[0] * kx + w[1] * ky + w[2] * ks + p.b0[c + e]);
         }
         *reinterpret_cast<f32x4*>(out + c) = o;
     }

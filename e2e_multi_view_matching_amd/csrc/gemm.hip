@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, (EXT || BK == 64 || TN == 1) ? 2 : 3) void gem
                         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                         if (p.relu) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                            for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
                         }
                         if (R) v += *reinterpret_cast<const f32x4*>(R + (int64_t)m * p.ldr + n);
                         if (EXT && n < p.q_cols) v *= p.q_scale;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, (EXT || BK == 64 || TN == 1) ? 2 : 3) void gem
                         for (int e = 0; e < 4; ++e) {
                             if (n + e < p.N) {
                                 float x = v[e] + (p.bias ? p.bias[n + e] : 0.f);
-                                if (p.relu) x = fmaxf(x, 0.f);
+                                if (p.relu) x = relu_nan(x);
                                 if (R) x += R[(int64_t)m * p.ldr + n + e];
                                 C[(int64_t)m * p.ldc + n + e] = x;
                             }

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512, 4) void gemm3_kernel(Gemm3Params p) {
                 if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                 if (p.relu) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
                 }
                 if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + (int64_t)m * p.ldr + n);
                 if (n < p.q_cols) v *= p.q_scale;

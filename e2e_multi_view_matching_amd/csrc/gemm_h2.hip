@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
                     if (p.bias) v += *reinterpret_cast<const h2_f32x4*>(p.bias + n);
                     if (p.relu) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
                     }
                     if (p.R) v += *reinterpret_cast<const h2_f32x4*>(p.R + (int64_t)m * p.ldr + n);
                     *reinterpret_cast<h2_f32x4*>(p.C + (int64_t)m * p.ldc + n) = v;

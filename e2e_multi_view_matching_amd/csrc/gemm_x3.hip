@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmX3Params p) {
                     if (p.bias) v += *reinterpret_cast<const x3_f32x4*>(p.bias + n);
                     if (p.relu) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
                     }
                     if (p.R) v += *reinterpret_cast<const x3_f32x4*>(p.R + (int64_t)m * p.ldr + n);
                     *reinterpret_cast<x3_f32x4*>(p.C + (int64_t)m * p.ldc + n) = v;

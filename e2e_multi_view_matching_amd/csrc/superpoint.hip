@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void sp_conv1a_kernel(const float* __restrict_
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc = fmaf(v[t], sw[(c0 + e) * 9 + t], acc);
-        o[e] = fmaxf(acc + sw[576 + c0 + e], 0.f);
+        o[e] = relu_nan(acc + sw[576 + c0 + e]);
     }
     *reinterpret_cast<sp_f4*>(out + pix * 64 + c0) = o;
 }

@@ -238,3 +238,31 @@ def test_config5_per_gpu_shape_t5_2048_fp16_batch8(gpu):
     """BASELINE configs[4] per-GPU share: tuple_size 5, 2048 keypoints (MegaDepth shape), fp16 descriptors, batch 8 tuples,
     18 layers; the oracle is fed the same fp16-rounded descriptors."""
     _full_size(gpu, 2048, torch.float16, ["f32", "bf16x3", "f16x2"])
+
+
+def test_f16x2_out_of_range_activations_are_reported_not_silent(gpu, split_always):
+    """The f16x2 mode carries operands as fp16 planes: an activation beyond fp16's range (|x| > 65504 in a GEMM input)
+    becomes +-inf.  That must be loud: the scores turn non-finite and e2emv_sync reports it (like a Sinkhorn overflow);
+    bf16x3 - fp32's exponent range - solves the same input."""
+    from e2e_multi_view_matching_amd import MultiViewMatcher, _lib
+    from e2e_multi_view_matching_amd.synthetic import make_tuples
+    ctx = _lib.context(gpu)
+    torch.manual_seed(3)
+    cfg = {"GNN_layers": ["self", "cross"], "sinkhorn_iterations": 10}
+    model = MultiViewMatcher(cfg).eval().to(gpu)
+    data = make_tuples(batch=1, tuple_size=2, n_kpts=256, seed=4)
+    for m in range(2):
+        data[f"descriptors{m}"] = data[f"descriptors{m}"] * 3e6     # far outside anything a descriptor network produces
+    dg = _dev(data, gpu)
+    assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK
+    model.config["mfma_precision"] = "f16x2"
+    with torch.no_grad():
+        out = model(dg)
+    assert not bool(torch.isfinite(out["scores_0_1"]).all())
+    assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.EHIP and b"range" in ctx.lib.e2emv_last_error(ctx.h)
+    assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK                # the report is consumed once
+    model.config["mfma_precision"] = "bf16x3"
+    with torch.no_grad():
+        out = model(dg)
+    assert bool(torch.isfinite(out["scores_0_1"]).all())
+    assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK
