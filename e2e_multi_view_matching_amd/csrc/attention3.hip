@@ -482,7 +482,11 @@ __device__ __forceinline__ H2Pair split2h_pair(float x0, float x1, float c) {
     return {hi, lo};
 }
 
-__global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
+// NW = waves per workgroup = 32-query blocks per workgroup: 4 (128 queries, two workgroups per CU) or 8 (256 queries, one
+// per CU - the K / V tile is fetched, split and stored half as often per query; waves 0-3 stage K, waves 4-7 stage V)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_h2f_kernel(Attn3fParams p) {
+    constexpr int QT = 32 * NW;
     __shared__ __attribute__((aligned(16))) uint16_t Ks[2 * A3_PLANE];
     __shared__ __attribute__((aligned(16))) uint16_t Vs[2 * A3_PLANE];
 
@@ -493,17 +497,18 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
     const int qt = idx % p.nq;
     const int img = g / p.H, head = g % p.H;
     const int b = img / p.T, t = img % p.T;
-    if (qt * A3_Q >= p.nv[t]) return;  // shorter image of a ragged tuple: no queries in this tile
+    if (qt * QT >= p.nv[t]) return;  // shorter image of a ragged tuple: no queries in this tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int64_t ld = 3 * (int64_t)p.D;  // floats per q|k|v row
 
     // ---- Q fragments (B operand): lane (q, lh) holds Q_pl[q][16 s + 8 lh .. +7]
-    const int q_row = qt * A3_Q + wave * 32 + l31;
+    const int q_row = qt * QT + wave * 32 + l31;
+    const bool q_ok = q_row < p.n_rows;  // (n_rows is a multiple of 128: the last 256-query tile may be half empty)
     u32x4 Qf[2][4];  // 8 fp16 each
     {
-        const float* qp = p.qkv + ((int64_t)img * p.n_rows + q_row) * ld + head * A3_HD + lh * 8;
+        const float* qp = p.qkv + ((int64_t)img * p.n_rows + (q_ok ? q_row : p.n_rows - 1)) * ld + head * A3_HD + lh * 8;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(qp + s * 16), hi = *reinterpret_cast<const f32x4*>(qp + s * 16 + 4);
@@ -533,8 +538,10 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
     // staging.  K tile (64 keys x 64 dims fp32): thread -> key row tid/4, 16 dims (tid&3)*16: 4 x 16 B, 64 B contiguous.
     // V tile: thread -> a 4 keys x 4 dims block: key block kb = (lane>>2) (16 blocks), dims 16*wave + 4*(lane&3): 4 x 16 B
     // from 4 consecutive key rows; after the split it owns, per dim, 4 consecutive keys = one 8-byte V^T write per plane.
-    const int k_row = tid >> 2, k_c16 = (tid & 3) * 16;
-    const int v_kb = lane >> 2, v_d0 = 16 * wave + 4 * (lane & 3);
+    const bool stage_k = NW == 4 || wave < 4, stage_v = NW == 4 || wave >= 4;
+    const int stid = tid & 255, swave = wave & 3;
+    const int k_row = stid >> 2, k_c16 = (stid & 3) * 16;
+    const int v_kb = lane >> 2, v_d0 = 16 * swave + 4 * (lane & 3);
     // V^T LDS position of keys 4 kb .. 4 kb + 3 inside their 16-key group (permuted order, see the header)
     const int v_lds = 16 * (v_kb >> 2) + 4 * ((v_kb & 3) >> 1) + 8 * (v_kb & 1);
     f32x4 rk[4], rv[4];
@@ -543,14 +550,18 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
         const float* base = p.qkv + ((int64_t)(b * p.T + tt) * p.n_rows + kt * A3_KV) * ld + head * A3_HD;
         const float* kp = base + p.D + (int64_t)k_row * ld + k_c16;
         const float* vp = base + 2 * p.D + (int64_t)(4 * v_kb) * ld + v_d0;
+        if (stage_k) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            rk[i] = *reinterpret_cast<const f32x4*>(kp + 4 * i);
-            rv[i] = *reinterpret_cast<const f32x4*>(vp + (int64_t)i * ld);
+            for (int i = 0; i < 4; ++i) rk[i] = *reinterpret_cast<const f32x4*>(kp + 4 * i);
+        }
+        if (stage_v) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rv[i] = *reinterpret_cast<const f32x4*>(vp + (int64_t)i * ld);
         }
     };
     auto lstore = [&]() {
         // K: 16 values -> 2 planes x 32 B
+        if (stage_k) {
         u32x4 kh[2][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -566,7 +577,9 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
             *reinterpret_cast<u32x4*>(kd) = kh[pl][0];
             *reinterpret_cast<u32x4*>(kd + 8) = kh[pl][1];
         }
+        }
         // V^T: rv[i][e] = V[key 4 kb + i][dim d0 + e]
+        if (stage_v)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             u32x2 vh[2];
@@ -660,6 +673,7 @@ __global__ __launch_bounds__(256, 2) void attention_h2f_kernel(Attn3fParams p) {
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / (l_tot * H2_KVS);
+    if (!q_ok) return;
     float* op = p.out32 + ((int64_t)img * p.n_rows + q_row) * p.D + head * A3_HD + 4 * lh;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
@@ -691,7 +705,17 @@ int launch_attention3f(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, 
     p.groups = B * T * H;
     p.gper = (p.groups + 7) / 8;
     p.q_scale = 0.125f * 1.4426950408889634f;  // log2(e) / sqrt(64)
-    if (h2) hipLaunchKernelGGL(attention_h2f_kernel, dim3(8 * p.gper * p.nq), dim3(256), 0, s, p);
+    if (h2) {
+        static int nw_env = -1;  // E2EMV_A3_NW=4|8 forces the workgroup size
+        if (nw_env < 0) { const char* e = getenv("E2EMV_A3_NW"); nw_env = e ? atoi(e) : 0; }
+        const int nw = nw_env == 4 || nw_env == 8 ? nw_env : (n_valid > 1024 ? 8 : 4);  // measured: equal at 1024 keys, 4-5 % at 2048
+        if (nw == 8) {
+            p.nq = (n_valid + 255) / 256;
+            hipLaunchKernelGGL(attention_h2f_kernel<8>, dim3(8 * p.gper * p.nq), dim3(512), 0, s, p);
+        } else {
+            hipLaunchKernelGGL(attention_h2f_kernel<4>, dim3(8 * p.gper * p.nq), dim3(256), 0, s, p);
+        }
+    }
     else hipLaunchKernelGGL(attention3f_kernel, dim3(8 * p.gper * p.nq), dim3(256), 0, s, p);
     E2EMV_CHECK_LAUNCH(ctx, "attention3f_kernel");
     return E2EMV_OK;

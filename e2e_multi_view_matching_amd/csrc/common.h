@@ -163,6 +163,9 @@ struct CallGuard {
 // workspace: makes ctx->d_ws at least `bytes` large, growing the arena (synchronising) when needed; each
 // top-level entry point carves it with 256-byte aligned offsets.
 int ws_reserve(e2emv_ctx* ctx, size_t bytes);
+// hipFuncAttributeMaxDynamicSharedMemorySize for kernels that use more than the default dynamic LDS: once per
+// (device, kernel), thread-safe (ctx.hip)
+int ensure_dynamic_lds(e2emv_ctx* ctx, const void* kernel, size_t bytes);
 
 // RAII-less profiling bracket
 void prof_begin(e2emv_ctx* ctx, int slot, hipStream_t s);

@@ -4,6 +4,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "common.h"
 
@@ -17,6 +19,17 @@ int set_err(e2emv_ctx* ctx, int code, const char* fmt, ...) {
     va_end(ap);
     if (ctx) ctx->err = buf;
     return code;
+}
+
+int ensure_dynamic_lds(e2emv_ctx* ctx, const void* kernel, size_t bytes) {
+    static std::map<std::pair<int, const void*>, size_t> done;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& have = done[{ctx->device, kernel}];
+    if (have >= bytes) return E2EMV_OK;
+    E2EMV_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+    return E2EMV_OK;
 }
 
 int ws_reserve(e2emv_ctx* ctx, size_t bytes) {

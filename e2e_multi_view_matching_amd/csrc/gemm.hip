@@ -431,11 +431,7 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
     } else if (conv) {
         hipLaunchKernelGGL((gemm_nt_kernel<false, 32, 0, true>), dim3(8 * sl), dim3(256), lds, s, p);
     } else if (bk == 64) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            E2EMV_HIP(ctx, hipFuncSetAttribute((const void*)gemm_nt_kernel<false, 64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        if (int rc = ensure_dynamic_lds(ctx, (const void*)gemm_nt_kernel<false, 64, 0>, lds)) return rc;
         hipLaunchKernelGGL((gemm_nt_kernel<false, 64, 0>), dim3(8 * sl), dim3(256), lds, s, p);
     } else if (ext) {
         hipLaunchKernelGGL((gemm_nt_kernel<true, 32, 0>), dim3(8 * sl), dim3(256), lds, s, p);

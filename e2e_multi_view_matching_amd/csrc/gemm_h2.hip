@@ -322,14 +322,7 @@ int launch_gemm_h2(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* WH, int64_
         case 84: fn = reinterpret_cast<const void*>(gemm_h2_kernel<8, 4>); break;
         default: fn = nj == 2 ? reinterpret_cast<const void*>(gemm_h2_kernel<0, 2>) : reinterpret_cast<const void*>(gemm_h2_kernel<0, 4>);
     }
-    static const void* attr_done[8] = {};
-    bool seen = false;
-    for (const void* f : attr_done) seen |= f == fn;
-    if (!seen) {
-        E2EMV_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        for (auto& f : attr_done)
-            if (!f) { f = fn; break; }
-    }
+    if (int rc = ensure_dynamic_lds(ctx, fn, lds)) return rc;
     long long* d_dbg = nullptr;
     const size_t nb = sizeof(long long) * 2 * 8 * 48 * 5;
     if (dbg == 8) {  // phase timestamps of workgroups 0 and 101, printed after the launch (host-synchronising; profiling only)

@@ -1013,7 +1013,7 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
             auto it = occupancy.find({ctx->device, kfn});
             if (it == occupancy.end()) {
                 if (res_lds > 48 * 1024)
-                    E2EMV_HIP(ctx, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds));
+                    if (int rc = ensure_dynamic_lds(ctx, kfn, res_lds)) return rc;
                 int nb = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 512, res_lds) != hipSuccess) {
                     (void)hipGetLastError();

@@ -1,7 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_sinkhorn_resident.py tests/test_gpu_kernels.py -q -x 2>&1 | tail -2
-timeout 300 python bench.py --config c5 --cpu-pairs 0 --no-alt --no-latency --steps 5 --warmup 2 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c5', d['value'], d['ms_per_step'], {k:round(v['ms_per_step'],3) for k,v in d.get('families',{}).items()})"
+for nw in 4 8; do echo NW=$nw; E2EMV_A3_NW=$nw timeout 200 python tools/microbench.py --what a3 2>&1 | grep f16x2; done
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_matcher.py tests/test_gpu_golden_direct.py tests/test_gpu_random_shapes.py tests/test_gpu_round2.py -q -x 2>&1 | tail -2
+E2EMV_A3_NW=8 timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_matcher.py -q -x 2>&1 | tail -2
