@@ -198,22 +198,44 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
             }
         }
     };
-    auto epilogue = [&](int t) {
+    // Epilogue through LDS.  In the accumulator layout a lane owns a ROW (4 consecutive columns per register group), so a
+    // direct store instruction touches 64 different cache lines with 16 bytes each: 32 such instructions per lane and tile
+    // cost ~14 k cycles per 256 x 256 tile (measured; line processing, not bandwidth) - 23 % of a K = 256 GEMM.  Each wave
+    // therefore transposes its tile through a private LDS slab of 32 rows x (32 JC + 4) floats: 4 JC ds_write_b128 per pass,
+    // read back row-contiguous (a store instruction then covers whole 128 / 256-byte row segments: 8 lines instead of 64;
+    // the residual read R becomes coalesced the same way).  Slab region: behind the tile buffer (NJ = 4), or the tile
+    // buffer that is idle during the epilogue (NJ = 2: the other one already holds the next tile's first K step).
+    constexpr int JC = NJ == 4 ? 2 : 1;            // 32-column blocks per pass
+    constexpr int SLD = 32 * JC + 4;               // slab row stride in floats (68 / 36: conflict-free b128 writes)
+    constexpr int LPR = 8 * JC;                    // lanes per slab row on the way out (float4 each)
+    constexpr int RPI = 64 / LPR;                  // rows per store instruction
+    auto epilogue = [&](int t, int free_buf) {
+        float* slab = reinterpret_cast<float*>(smem_h2 + (DB ? free_buf * H2_BUF : H2_BUF)) + wave * 32 * SLD;
         const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+        const int o_row = lane / LPR, o_col = (lane % LPR) * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = tm * H2_BM + wr * 64 + i * 32 + l31;
-            if (m >= p.M) continue;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+            for (int jc = 0; jc < NJ / JC; ++jc) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = tn * H2_BN + wc * 32 * NJ + j * 32 + 8 * g + 4 * lh;
-                    if (n >= p.N) continue;
-                    h2_f32x4 v;
+                for (int jj = 0; jj < JC; ++jj)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e] * p.out_scale;
-                    if (p.bias) v += *reinterpret_cast<const h2_f32x4*>(p.bias + n);
+                    for (int g = 0; g < 4; ++g) {
+                        h2_f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[jc * JC + jj][i][4 * g + e] * p.out_scale;
+                        *reinterpret_cast<h2_f32x4*>(&slab[l31 * SLD + jj * 32 + 8 * g + 4 * lh]) = v;
+                    }
+                const int n = tn * H2_BN + wc * 32 * NJ + jc * 32 * JC + o_col;
+                h2_f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias && n < p.N) bias4 = *reinterpret_cast<const h2_f32x4*>(p.bias + n);
+#pragma unroll
+                for (int k = 0; k < 32 / RPI; ++k) {
+                    const int r = o_row + RPI * k;
+                    h2_f32x4 v = *reinterpret_cast<const h2_f32x4*>(&slab[r * SLD + o_col]);
+                    const int m = tm * H2_BM + wr * 64 + i * 32 + r;
+                    if (m >= p.M || n >= p.N) continue;
+                    v += bias4;
                     if (p.relu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = relu_nan(v[e]);
@@ -221,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
                     if (p.R) v += *reinterpret_cast<const h2_f32x4*>(p.R + (int64_t)m * p.ldr + n);
                     *reinterpret_cast<h2_f32x4*>(p.C + (int64_t)m * p.ldc + n) = v;
                 }
-        }
+            }
     };
 
     // pipeline: step g = (tile, kt) in execution order; LDS buffer g & 1 holds step g while registers hold step g + 1.
@@ -276,9 +298,10 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
             }
             if constexpr (DB) buf ^= 1;
         }
-        epilogue(tile);
+        epilogue(tile, buf ^ 1);  // (DB: `buf` now names the buffer of the NEXT step; the other one was just computed from)
         tile += slots;
         if (tile >= t_end) break;
+        if constexpr (DB) __syncthreads();  // the slabs live in the buffer the next step's lstore fills
         zero_acc();
     }
 }
@@ -311,7 +334,9 @@ int launch_gemm_h2(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* WH, int64_
     p.dbg = nullptr;
     const int per_xcd = (p.total + 7) / 8;
     const int sl = std::min(per_xcd, std::max(1, ctx->num_cus / 8));
-    const size_t lds = sizeof(uint16_t) * (nj == 2 ? 2 : 1) * (2 * H2_APLANE + 2 * bn * H2_LD);
+    // NJ = 2: two tile buffers (the idle one carries the epilogue slabs); NJ = 4: one tile buffer + 8 slabs of 32 x 68 floats
+    const size_t lds = nj == 2 ? sizeof(uint16_t) * 2 * (2 * H2_APLANE + 2 * bn * H2_LD)
+                               : sizeof(uint16_t) * (2 * H2_APLANE + 2 * bn * H2_LD) + sizeof(float) * 8 * 32 * 68;
     const void* fn = nullptr;
     switch (dbg * 10 + nj) {
         case 12: fn = reinterpret_cast<const void*>(gemm_h2_kernel<1, 2>); break;
