@@ -64,18 +64,30 @@ static hipEvent_t take_event(e2emv_ctx* ctx) {
 
 void prof_begin(e2emv_ctx* ctx, int slot, hipStream_t s) {
     if (!ctx->prof) return;
+    if (!ctx->prof_events.empty() && ctx->prof_events.back().slot == slot && ctx->prof_stream == s) {
+        ++ctx->prof_events.back().launches;  // same family as the launch before: the interval goes on
+        return;
+    }
     ProfEvent pe;
-    pe.a = take_event(ctx);
-    pe.b = take_event(ctx);
+    pe.ev = take_event(ctx);
     pe.slot = slot;
-    (void)hipEventRecord(pe.a, s);
+    pe.launches = 1;
+    (void)hipEventRecord(pe.ev, s);
+    ctx->prof_stream = s;
     ctx->prof_events.push_back(pe);
 }
 
-void prof_end(e2emv_ctx* ctx, hipStream_t s) {
-    if (!ctx->prof || ctx->prof_events.empty()) return;
-    (void)hipEventRecord(ctx->prof_events.back().b, s);
+void prof_close(e2emv_ctx* ctx) {
+    if (!ctx->prof || ctx->prof_events.empty() || ctx->prof_events.back().slot < 0) return;
+    ProfEvent pe;
+    pe.ev = take_event(ctx);
+    pe.slot = -1;
+    pe.launches = 0;
+    (void)hipEventRecord(pe.ev, ctx->prof_stream);
+    ctx->prof_events.push_back(pe);
 }
+
+CallGuard::~CallGuard() { prof_close(c); }
 
 namespace {
 inline uint16_t f2h(float f) {
@@ -167,10 +179,7 @@ void e2emv_destroy(e2emv_ctx* ctx) {
     if (ctx->d_sparena) (void)hipFree(ctx->d_sparena);
     if (ctx->d_attn_part) (void)hipFree(ctx->d_attn_part);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
-    for (auto& pe : ctx->prof_events) {
-        (void)hipEventDestroy(pe.a);
-        (void)hipEventDestroy(pe.b);
-    }
+    for (auto& pe : ctx->prof_events) (void)hipEventDestroy(pe.ev);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -545,6 +554,7 @@ int e2emv_get_precision(e2emv_ctx* ctx, int* precision) {
 int e2emv_profile(e2emv_ctx* ctx, int enable) {
     if (!ctx) return E2EMV_EINVAL;
     E2EMV_LOCK(ctx);
+    if (!enable) prof_close(ctx);
     ctx->prof = enable != 0;
     return E2EMV_OK;
 }
@@ -552,17 +562,20 @@ int e2emv_profile(e2emv_ctx* ctx, int enable) {
 int e2emv_profile_read(e2emv_ctx* ctx, float* ms, int64_t* launches, int n_slots, int reset) {
     if (!ctx) return E2EMV_EINVAL;
     E2EMV_LOCK(ctx);
+    prof_close(ctx);
     E2EMV_HIP(ctx, hipDeviceSynchronize());
-    for (auto& pe : ctx->prof_events) {
+    for (size_t i = 0; i < ctx->prof_events.size(); ++i) {
+        const ProfEvent& pe = ctx->prof_events[i];
         float t = 0.f;
-        if (hipEventElapsedTime(&t, pe.a, pe.b) == hipSuccess && pe.slot >= 0 && pe.slot < E2EMV_PROF_SLOTS) {
-            ctx->prof_ms[pe.slot] += t;
-            ctx->prof_n[pe.slot] += 1;
-        } else {
-            (void)hipGetLastError();
+        if (pe.slot >= 0 && pe.slot < E2EMV_PROF_SLOTS && i + 1 < ctx->prof_events.size()) {
+            if (hipEventElapsedTime(&t, pe.ev, ctx->prof_events[i + 1].ev) == hipSuccess) {
+                ctx->prof_ms[pe.slot] += t;
+                ctx->prof_n[pe.slot] += pe.launches;
+            } else {
+                (void)hipGetLastError();
+            }
         }
-        ctx->event_pool.push_back(pe.a);
-        ctx->event_pool.push_back(pe.b);
+        ctx->event_pool.push_back(pe.ev);
     }
     ctx->prof_events.clear();
     for (int i = 0; i < n_slots && i < E2EMV_PROF_SLOTS; ++i) {
