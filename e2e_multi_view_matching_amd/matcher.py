@@ -39,9 +39,9 @@ DEFAULT_CONFIG = {
     "tuple_size": 2,
     "conf_mlp": False,
     "full_output": False,
-    # arithmetic of the dense GNN contractions: "f32" (exact fp32 MFMA) or "bf16x3" (fp32 operands split into three
-    # bf16 planes, 6 bf16-MFMA products, fp32 accumulate - fp32-class accuracy).  None = the library default
-    # (environment variable E2EMV_PRECISION, else "bf16x3").
+    # arithmetic of the dense GNN contractions: "f32" (exact fp32 MFMA), "bf16x3" (fp32 operands split into three bf16
+    # planes, 6 bf16-MFMA products) or "f16x2" (two fp16 planes, 3 fp16-MFMA products), all with fp32 accumulation and the
+    # same parity bar.  None = the library default (environment variable E2EMV_PRECISION, else "f16x2").
     "mfma_precision": None,
 }
 

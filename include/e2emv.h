@@ -299,13 +299,13 @@ int e2emv_attention(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D
  * E2EMV_PRECISION_BF16X3 : fp32 operands split into three bf16 planes, six bf16 MFMA products per
  *                          block accumulated in fp32 - fp32-class rounding (|err| ~ 2^-24 per
  *                          product) at 2.67x the fp32-MFMA ceiling.  Same API, same outputs within
- *                          the 1e-4 parity bar (tests/test_gpu_matcher.py runs both).  DEFAULT since round 2.
+ *                          the 1e-4 parity bar (tests/test_gpu_matcher.py runs every mode).
  * E2EMV_PRECISION_F16X2  : fp32 operands carried as two fp16 planes (hi + 2^-11 lo', 22 significant bits, the low plane
  *                          kept at the exponent range of the high one; static weights pre-scaled by a power of two per
  *                          matrix), three fp16 MFMA products per block accumulated in fp32: half the matrix-pipe work
  *                          of bf16x3.  Operand representation error <= 2^-22 for 6e-5 <= |x| <= 65504 (a K=512
  *                          contraction: 1e-7 rms, below fp32 accumulation noise); an activation beyond 65504 becomes
- *                          +-inf and surfaces as the sticky non-finite error of e2emv_sync.
+ *                          +-inf and surfaces as the sticky non-finite error of e2emv_sync.  DEFAULT.
  * Also selectable with the environment variable E2EMV_PRECISION=f32|bf16x3|f16x2 read at e2emv_create. */
 #define E2EMV_PRECISION_F32 0
 #define E2EMV_PRECISION_BF16X3 1
