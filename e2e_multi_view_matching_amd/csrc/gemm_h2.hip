@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -82,19 +83,20 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
     const int w_row = tid >> 2, w_k8 = (tid & 3) * 8;
     const int nk = p.K / H2_BK;
 
-    // operand addresses as 32-bit element offsets from the uniform base pointers (the launcher checks the spans); they
-    // belong to the load position (ld_tile, ld_kt), which runs two K steps ahead of the compute position across tiles
+    // operand addresses as 32-bit BYTE offsets from the uniform base pointers (SGPR base + VGPR offset loads, no 64-bit
+    // address arithmetic in the K loop; the launcher checks the spans); they belong to the load position (ld_tile, ld_kt),
+    // which runs two K steps ahead of the compute position across tiles
     unsigned a_off[4], a2_off[4], w_off[WR];
     auto setup = [&](int t) {
         const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned ra = (unsigned)min(tm * H2_BM + a_row + 64 * i, p.M - 1);
-            a_off[i] = ra * p.lda + a_c4;
-            a2_off[i] = ra * p.lda2 + a_c4;
+            a_off[i] = (ra * p.lda + a_c4) * 4u;
+            a2_off[i] = (ra * p.lda2 + a_c4) * 4u;
         }
 #pragma unroll
-        for (int r = 0; r < WR; ++r) w_off[r] = (unsigned)min(tn * H2_BN + w_row + 128 * r, p.N - 1) * 2u * p.ldw + w_k8;
+        for (int r = 0; r < WR; ++r) w_off[r] = ((unsigned)min(tn * H2_BN + w_row + 128 * r, p.N - 1) * 2u * p.ldw + w_k8) * 2u;
     };
 
     h2_f32x4 ra[4];
@@ -104,14 +106,15 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
     auto gload = [&]() {
         const int k = ld_kt * H2_BK;
         const bool first = k < p.K1;
-        const float* base = first ? p.A : p.A2;
-        const unsigned kk = first ? k : k - p.K1;
+        const char* base = reinterpret_cast<const char*>(first ? p.A : p.A2);
+        const unsigned kk = (unsigned)(first ? k : k - p.K1) * 4u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const h2_f32x4*>(base + ((first ? a_off[i] : a2_off[i]) + kk));
+        const char* wb = reinterpret_cast<const char*>(p.WH);
 #pragma unroll
         for (int r = 0; r < WR; ++r) {
-            rw[r][0] = *reinterpret_cast<const h2_u32x4*>(p.WH + (w_off[r] + k));
-            rw[r][1] = *reinterpret_cast<const h2_u32x4*>(p.WH + (w_off[r] + p.ldw + k));
+            rw[r][0] = *reinterpret_cast<const h2_u32x4*>(wb + (w_off[r] + 2u * k));
+            rw[r][1] = *reinterpret_cast<const h2_u32x4*>(wb + (w_off[r] + 2u * (p.ldw + k)));
         }
     };
     // move the load position one K step on; past the last step of the last tile it stays put (the loads then re-fetch
@@ -120,6 +123,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
         if ((DBG & 2)) return;  // (profiling: keep re-loading the first K tile - L2 hits only)
         if (ld_kt + 1 < nk) { ++ld_kt; return; }
         if (ld_tile + slots < t_end) {
+            asm volatile("" ::: "memory");  // keeps this a (uniform) branch: if-converted, setup's ~30 VALU ran in every K step
             ld_tile += slots;
             ld_kt = 0;
             setup(ld_tile);
@@ -167,7 +171,10 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
     };
-    auto compute = [&](int buf) {
+    // FIRST: first K step of an output tile - the accumulators start from the MFMA's zero C operand instead of being
+    // cleared by 128 v_mov per tile (a fifth of the per-tile VALU work at K = 256)
+    auto compute = [&](int buf, auto FIRST) {
+        constexpr bool first_step = decltype(FIRST)::value;
         const uint16_t* as = smem_h2 + buf * H2_BUF + (wr * 64 + l31) * H2_LD + lh * 8;
         const uint16_t* bs = smem_h2 + buf * H2_BUF + 2 * H2_APLANE + (wc * 32 * NJ + l31) * H2_LD + lh * 8;
 #pragma unroll
@@ -193,8 +200,14 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[PW[q]], x[i][PX[q]], acc[j][i], 0, 0, 0);
+                    for (int i = 0; i < 2; ++i) {
+                        if (first_step && ks == 0 && q == 0) {
+                            const h2_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[PW[q]], x[i][PX[q]], zero, 0, 0, 0);
+                        } else {
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[PW[q]], x[i][PX[q]], acc[j][i], 0, 0, 0);
+                        }
+                    }
             }
         }
     };
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
     //     for this block.
     // A step costs ~3600 cycles against 2 x 768 of matrix-pipe time per SIMD: issuing the 6 global loads alone stalls
     // 200-1000 cycles (the L2 -> CU path is saturated at ~8 TB/s, 14 B/clk/CU), the split + LDS stores take 450-850.
-    zero_acc();
+    if (DBG & 1) zero_acc();
     setup(tile);
     gload();      // step 0
     advance();
@@ -264,45 +277,49 @@ __global__ __launch_bounds__(512, 1) void gemm_h2_kernel(GemmH2Params p) {
     advance();
     __syncthreads();
     int buf = 0, dbg_n = 0;
-    for (;;) {
-        for (int kt = 0; kt < nk; ++kt) {
-            long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-            if (DBG & 8) t0 = clock64();
-            if constexpr (DB) {
-                lstore(buf ^ 1);  // step g + 1 into the other buffer (its readers passed the barrier of step g - 1)
-                if (DBG & 8) t1 = clock64();
-                gload();          // step g + 2
-                if (DBG & 8) t2 = clock64();
-                compute(buf);
-                if (DBG & 8) t3 = clock64();
-                advance();
-                __syncthreads();
-            } else {
-                compute(0);
-                if (DBG & 8) t1 = clock64();
-                __syncthreads();  // every wave is done reading step g
-                lstore(0);        // step g + 1 (after the last step: stale registers nobody reads)
-                if (DBG & 8) t2 = clock64();
-                gload();          // step g + 2
-                if (DBG & 8) t3 = clock64();
-                advance();
-                __syncthreads();
-            }
-            if (DBG & 8) {
-                const long long t4 = clock64();
-                if (p.dbg && lane == 0 && dbg_n < 48 && (blockIdx.x == 0 || blockIdx.x == 101)) {
-                    long long* o = p.dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 48 * 5 + dbg_n * 5;
-                    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4;
-                    ++dbg_n;
-                }
-            }
-            if constexpr (DB) buf ^= 1;
+    // one K step; FIRST = first step of an output tile (accumulators start from the MFMA's zero C operand).  The first step
+    // is peeled out of the K loop so that each copy of the body keeps the register footprint of a single one.
+    auto step = [&](auto FIRST) {
+        long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (DBG & 8) t0 = clock64();
+        if constexpr (DB) {
+            lstore(buf ^ 1);  // step g + 1 into the other buffer (its readers passed the barrier of step g - 1)
+            if (DBG & 8) t1 = clock64();
+            gload();          // step g + 2
+            if (DBG & 8) t2 = clock64();
+            compute(buf, FIRST);
+            if (DBG & 8) t3 = clock64();
+            advance();
+            __syncthreads();
+        } else {
+            compute(0, FIRST);
+            if (DBG & 8) t1 = clock64();
+            __syncthreads();  // every wave is done reading step g
+            lstore(0);        // step g + 1 (after the last step: stale registers nobody reads)
+            if (DBG & 8) t2 = clock64();
+            gload();          // step g + 2
+            if (DBG & 8) t3 = clock64();
+            advance();
+            __syncthreads();
         }
+        if (DBG & 8) {
+            const long long t4 = clock64();
+            if (p.dbg && lane == 0 && dbg_n < 48 && (blockIdx.x == 0 || blockIdx.x == 101)) {
+                long long* o = p.dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 48 * 5 + dbg_n * 5;
+                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4;
+                ++dbg_n;
+            }
+        }
+        if constexpr (DB) buf ^= 1;
+    };
+    for (;;) {
+        step(std::true_type{});
+        for (int kt = 1; kt < nk; ++kt) step(std::false_type{});
         epilogue(tile, buf ^ 1);  // (DB: `buf` now names the buffer of the NEXT step; the other one was just computed from)
         tile += slots;
         if (tile >= t_end) break;
         if constexpr (DB) __syncthreads();  // the slabs live in the buffer the next step's lstore fills
-        zero_acc();
+        if (DBG & 1) zero_acc();
     }
 }
 
@@ -313,8 +330,8 @@ int launch_gemm_h2(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* WH, int64_
     if (!WH || !a.C || a.N % 4 || a.ldc % 4 || (uintptr_t)a.C % 16 || (a.bias && (uintptr_t)a.bias % 16) ||
         (a.R && (a.ldr % 4 || (uintptr_t)a.R % 16)) || a.lda % 4 || (a.A2 && a.lda2 % 4) || ldw % 8 || a.scale != 1.f)
         return set_err(ctx, E2EMV_ESHAPE, "gemm_h2: needs 16-byte aligned rows (N %% 4, ld %% 4, ldw %% 8) and scale 1");
-    if ((int64_t)a.M * a.lda >= (int64_t)1 << 31 || (a.A2 && (int64_t)a.M * a.lda2 >= (int64_t)1 << 31) || (int64_t)a.N * 2 * ldw >= (int64_t)1 << 31)
-        return set_err(ctx, E2EMV_ESHAPE, "gemm_h2: operand larger than 2^31 elements (M=%d lda=%lld)", a.M, (long long)a.lda);
+    if ((int64_t)a.M * a.lda >= (int64_t)1 << 30 || (a.A2 && (int64_t)a.M * a.lda2 >= (int64_t)1 << 30) || (int64_t)a.N * 2 * ldw >= (int64_t)1 << 31)
+        return set_err(ctx, E2EMV_ESHAPE, "gemm_h2: operand larger than 4 GB (M=%d lda=%lld): 32-bit byte offsets", a.M, (long long)a.lda);
     GemmH2Params p;
     p.A = a.A; p.A2 = a.A2 ? a.A2 : a.A; p.WH = WH; p.bias = a.bias; p.R = a.R; p.C = a.C;
     p.lda = (unsigned)a.lda; p.lda2 = (unsigned)(a.A2 ? a.lda2 : a.lda); p.ldw = (unsigned)ldw; p.ldr = a.ldr; p.ldc = a.ldc;
