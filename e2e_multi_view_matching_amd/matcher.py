@@ -43,6 +43,9 @@ DEFAULT_CONFIG = {
     # planes, 6 bf16-MFMA products) or "f16x2" (two fp16 planes, 3 fp16-MFMA products), all with fp32 accumulation and the
     # same parity bar.  None = the library default (environment variable E2EMV_PRECISION, else "f16x2").
     "mfma_precision": None,
+    # True: forward() synchronises and raises if the device reported non-finite scores (off by default: the reference's
+    # forward is asynchronous too, and the NaN / inf is in the outputs either way)
+    "check_finite": False,
 }
 
 
@@ -231,6 +234,10 @@ class MultiViewMatcher(nn.Module):
             args.append(p)
         with torch.cuda.device(dev):
             ctx.call("e2emv_matcher_forward", ctypes.byref(fd), *args, _lib.stream_ptr(dev))
+            if cfg.get("check_finite"):
+                # host-synchronising: raises E2EMVError if a Sinkhorn problem left fp32's range or an activation left the
+                # range of the arithmetic mode (the scores of that call are NaN / inf either way)
+                ctx.call("e2emv_sync", _lib.stream_ptr(dev))
         for p, (i, j) in enumerate(pairs):
             out[f"scores_{i}_{j}"] = logZ[p]
             if full:
