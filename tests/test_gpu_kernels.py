@@ -212,3 +212,29 @@ def test_attention_split_kernels_over_operand_magnitudes(gpu, kernel, qs, ks, vs
     err = float((out.double() - ref).abs().max()) / vs
     err32 = float((out32.double() - ref).abs().max()) / vs
     assert err < 3 * err32 + 2e-6, (err, err32)
+
+
+def test_gemm_f16x2_random_shapes(gpu):
+    """gemm_h2 over ragged shapes: M not a multiple of the 256-row tile, N % 4 only (256 x 128 tile) and N % 256 == 0
+    (256 x 256 tile), K from one K step to 24, with bias / ReLU - against fp64."""
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(2024)
+    worst = 0.0
+    for case in range(24):
+        M = int(torch.randint(1, 1500, (1,), generator=g))
+        N = [4 * int(torch.randint(1, 200, (1,), generator=g)), 256 * int(torch.randint(1, 4, (1,), generator=g))][case % 2]
+        K = 32 * int(torch.randint(1, 25, (1,), generator=g))
+        relu = bool(case & 2)
+        A = torch.randn(M, K, generator=g) * float(torch.exp(torch.randn(1, generator=g) * 2))
+        W = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g) if case % 3 else None
+        ref = A.double() @ W.double().T + (b.double() if b is not None else 0.0)
+        if relu:
+            ref = ref.clamp_min(0)
+        out = E.gemm_bf16x3(A.to(gpu), W.to(gpu), bias=b.to(gpu) if b is not None else None, relu=relu, f16x2=True).cpu()
+        assert out.shape == (M, N)
+        scale = (A.double().abs() @ W.double().abs().T) + (b.double().abs() if b is not None else 0.0)
+        e = float(((out.double() - ref).abs() / scale).max())
+        worst = max(worst, e)
+        assert e < 5e-7, (case, M, N, K, relu, e)
+    assert worst > 0.0
