@@ -454,11 +454,12 @@ __global__ __launch_bounds__(256, 2) void attention3f_kernel(Attn3fParams p) {
 // hi hi + hi lo + lo hi (v_mfma_f32_32x32x16_f16, fp32 accumulate): half the MFMAs, two thirds of the LDS planes and of
 // the split VALU work of the bf16x3 form.  Unlike the GEMM, where the weight planes are static, every operand here is
 // made on the fly, so the low planes are kept in fp16's normal range by power-of-two pre-scales that cancel exactly:
-//   q x 2^6 (on top of log2(e)/sqrt(d)), k x 2^4  -> logits in units of 2^-10; the exponent is formed as fma(S, 2^-10, c)
+//   q x 2^6 (on top of log2(e)/sqrt(d)), k as it is -> logits in units of 2^-6; the exponent is formed as fma(S, 2^-6, c)
 //   p x 2^10 (p in (0, 1] -> (0, 1024]), v x 2^4  -> O = (sum p v) / (l 2^4), l summed from the same scaled p
-// Range: |q| < 5.6e3, |k|, |v| < 4.0e3 (beyond: +-inf -> non-finite scores -> the sticky error of e2emv_sync); the
-// absolute floor of a low plane (half an fp16 subnormal step, 3e-8) sits at 5e-10 / 2e-9 / 3e-11 of the unscaled q / k,v / p.
-constexpr float H2_QS = 64.f, H2_KVS = 16.f, H2_SINV = 1.f / 1024.f, H2_PLOG = 10.f;
+// Range: |q| < 5.6e3, |k| < 6.5e4, |v| < 4.0e3 (beyond: +-inf -> non-finite scores -> the sticky error of e2emv_sync); the
+// absolute floor of a low plane (half an fp16 subnormal step, 3e-8) sits at 5e-10 / 3e-8 / 2e-9 / 3e-11 of the unscaled
+// q / k / v / p (k needs no more: its floor enters the logit as 3e-8 |q| 0.18 sqrt(64) = 4e-8 |q| in base-2 units).
+constexpr float H2_QS = 64.f, H2_VS = 16.f, H2_SINV = 1.f / 64.f, H2_PLOG = 10.f, H2_LAZY = 5.f;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 // (x0 c, x1 c) -> packed fp16 pairs hi, lo with hi + lo = x c to 2^-22.  hi = one v_cvt_pk_f16_f32; lo = v - hi by
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_h2f_kernel
 #pragma unroll
             for (int e = 0; e < 2; ++e)
             {
-                const H2Pair pr = split2h_pair(rk[i][2 * e], rk[i][2 * e + 1], H2_KVS);
+                const H2Pair pr = split2h_pair(rk[i][2 * e], rk[i][2 * e + 1], 1.f);
                 kh[0][i >> 1][(i & 1) * 2 + e] = pr.hi; kh[1][i >> 1][(i & 1) * 2 + e] = pr.lo;
             }
 #pragma unroll
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_h2f_kernel
             u32x2 vh[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const H2Pair pr = split2h_pair(rv[2 * i][e], rv[2 * i + 1][e], H2_KVS);
+                const H2Pair pr = split2h_pair(rv[2 * i][e], rv[2 * i + 1][e], H2_VS);
                 vh[0][i] = pr.hi; vh[1][i] = pr.lo;
             }
 #pragma unroll
@@ -635,9 +636,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_h2f_kernel
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            // S (and m) are in units of 1 / (H2_QS H2_KVS) of a base-2 logit; P carries the factor H2_PS (cancels in O / l)
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * H2_SINV);
+            // S (and m) are in units of 1 / H2_QS of a base-2 logit; P carries the factor 2^H2_PLOG (cancels in O / l).
+            // Lazy running maximum: the reference maximum m_run moves (and O, l are rescaled) only when some row's new
+            // maximum exceeds it by more than 2^H2_LAZY - until then P just grows up to 2^(H2_PLOG + H2_LAZY) = 32768, inside
+            // fp16's range, and the tile costs no rescale of the 32 O registers (after the first tiles that is every tile)
+            float m_new = m_run, alpha = 1.f;
+            const bool grow = (mx - m_run) * H2_SINV > H2_LAZY;
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform
+                m_new = fmaxf(m_run, mx);
+                alpha = __builtin_amdgcn_exp2f((m_run - m_new) * H2_SINV);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { O0[r] *= alpha; O1[r] *= alpha; }
+            }
             const float e0 = H2_PLOG - m_new * H2_SINV;
             float ps = 0.f;
             u32x4 Pf[2][2];
@@ -651,8 +661,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_h2f_kernel
             }
             l_run = l_run * alpha + ps;
             m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { O0[r] *= alpha; O1[r] *= alpha; }
             const uint16_t* vp = &Vs[l31 * A3_LD + lh * 8];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_h2f_kernel
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.f / (l_tot * H2_KVS);
+    const float inv = 1.f / (l_tot * H2_VS);
     if (!q_ok) return;
     float* op = p.out32 + ((int64_t)img * p.n_rows + q_row) * p.D + head * A3_HD + 4 * lh;
 #pragma unroll
