@@ -7,8 +7,8 @@ Everything computes in libe2emv.so (hand-written HIP for gfx950) through ctypes.
 """
 from .matcher import MultiViewMatcher, SuperGlue  # noqa: F401
 from .metrics import compute_pose_error, pose_auc  # noqa: F401
-from .ops import (attention, attention_bf16x3, extract_matches, gemm_bf16x3, gemm_nt,  # noqa: F401
-                  log_optimal_transport)
+from .ops import (attention, attention_bf16x3, attention_p2, extract_matches, gemm_bf16x3, gemm_nt, gemm_p2,  # noqa: F401
+                  log_optimal_transport, qkv_p2)
 from .pose import (compute_rotation_error, compute_translation_error_as_angle, estimate_relative_pose_w8pt,  # noqa: F401
                    get_kpts, mask_confidence, normalize, pose_errors, run_bundle_adjust_2_view,
                    run_weighted_8_point, run_weighted_8_point_tuple)

@@ -17,7 +17,8 @@ FLAG_FULL_OUTPUT, FLAG_MULTI_FRAME = 1, 2
 DESC_F32, DESC_F16 = 0, 1
 OK, EINVAL, ENOMEM, EHIP, ESHAPE, ESTATE = 0, -1, -2, -3, -4, -5
 PRECISION_F32, PRECISION_BF16X3, PRECISION_F16X2 = 0, 1, 2
-PRECISION_NAMES = {"f32": PRECISION_F32, "bf16x3": PRECISION_BF16X3, "f16x2": PRECISION_F16X2}
+PRECISION_NAMES = {"f32": PRECISION_F32, "bf16x3": PRECISION_BF16X3, "f16x2": PRECISION_F16X2,
+                   "f16x2-r2": PRECISION_F16X2}  # "-r2": the same arithmetic on the round-2 kernels (fp32 activations)
 
 c_void_p, c_int, c_float, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_char_p
 c_int64, c_size_t = ctypes.c_int64, ctypes.c_size_t
@@ -102,6 +103,11 @@ SIGNATURES = {
     "e2emv_gemm_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "e2emv_attention_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                        c_void_p]),
+    "e2emv_set_f16x2_kernels": (c_int, [c_void_p, c_int]),
+    "e2emv_gemm_p2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                              c_void_p]),
+    "e2emv_qkv_p2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e2emv_attention_p2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "e2emv_profile": (c_int, [c_void_p, c_int]),
     "e2emv_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int64), c_int, c_int]),
     "e2emv_profile_name": (c_char_p, [c_int]),
@@ -163,6 +169,8 @@ class Context:
         self.weights_owner = None
         self.sp_weights_owner = None
         self.default_precision = self.precision()  # E2EMV_PRECISION at creation time (else f32)
+        self.f16x2_kernels = 2 if os.environ.get("E2EMV_F16X2_KERNELS") == "r2" else 3
+        self.default_f16x2_kernels = self.f16x2_kernels
         self.forced_precision = None               # set_precision(): explicit process-wide override for models with
         #                                            config["mfma_precision"] = None
 
@@ -178,6 +186,12 @@ class Context:
             precision = PRECISION_NAMES[precision]
         self.forced_precision = precision
         self.call("e2emv_set_precision", self.default_precision if precision is None else precision)
+
+    def set_f16x2_kernels(self, generation=3):
+        """f16x2 implementation: 3 = plane activations (gemm_p2 / attention_p2, the default), 2 = the round-2 kernels
+        (fp32 activations split inside the consuming kernel)."""
+        self.call("e2emv_set_f16x2_kernels", int(generation))
+        self.f16x2_kernels = int(generation)
 
     def set_split_min_rows(self, min_rows=-1):
         """Calls with fewer keypoint rows than this run the fp32-MFMA kernels even in a split-operand mode

@@ -60,6 +60,10 @@ struct LayerWeights {
     uint16_t* wh_mlp0 = nullptr;
     uint16_t* wh_mlp1 = nullptr;
     float hs_qkv = 0.f, hs_mlp0 = 0.f, hs_mlp1 = 0.f;
+    // the same 2^s W as P2 planes (p2.h: 32-column blocks of {hi, lo}) for gemm_p2.hip; the scales are hs_* above
+    uint16_t* wp_qkv = nullptr;
+    uint16_t* wp_mlp0 = nullptr;
+    uint16_t* wp_mlp1 = nullptr;
 };
 
 // Family timing as a CHAIN of events on the launch stream: one event where the family changes (it ends the previous
@@ -90,6 +94,8 @@ struct e2emv_ctx {
     size_t w3arena_elems = 0;
     int precision = 0;  // E2EMV_PRECISION_F32 | _BF16X3 | _F16X2 (dense GNN contractions)
     int64_t split_min_rows = -1;  // split-operand kernels from this many keypoint rows per call (-1: half a 128-row tile per CU)
+    bool h2_legacy = false;  // f16x2 mode on the round-2 kernels (fp32 activations split inside gemm_h2 / attention_h2f): the A/B arm of the plane path
+    int attn_p2_nw = 0;      // attention_p2 workgroup size: 0 = by key count, 4 | 8 waves (micro-benchmarks)
     bool b3_planes = false;  // bf16x3 mode: q|k|v handed to the attention as planes from the GEMM epilogue (E2EMV_B3_PLANES=1)
     // keypoint encoder: layer 0 (3->c0) used by the ingest kernel, the rest through the GEMM
     float* kenc_w0 = nullptr;  // [c0][3] folded

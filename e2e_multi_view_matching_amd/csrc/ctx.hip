@@ -8,6 +8,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "p2.h"
 
 namespace e2emv {
 
@@ -156,6 +157,7 @@ int e2emv_create(e2emv_ctx** out, int device) {
     ctx->num_cus = p.multiProcessorCount;
     if (const char* e = getenv("E2EMV_NO_FUSE_MERGE")) ctx->fuse_merge = !(e[0] == '1');
     if (const char* e = getenv("E2EMV_B3_PLANES")) ctx->b3_planes = e[0] == '1';
+    if (const char* e = getenv("E2EMV_F16X2_KERNELS")) ctx->h2_legacy = strcmp(e, "r2") == 0;  // round-2 f16x2 kernels (A/B measurements)
     // default arithmetic of the dense GNN contractions: the split-operand fp16 x 2 path (22-bit operands, fp32 accumulate;
     // every parity test runs in all three modes at the same bar); E2EMV_PRECISION=bf16x3 selects the 24-bit bf16 x 3
     // split, =f32 the exact fp32-MFMA kernels
@@ -372,7 +374,7 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     // ---- GNN layers ----
     struct LOff {
         size_t wqkv, bqkv, wm, bm, w0, b0, w1, b1;
-        size_t w3qkv, w3m0, w3m1, whqkv, whm0, whm1;
+        size_t w3qkv, w3m0, w3m1, whqkv, whm0, whm1, wpqkv, wpm0, wpm1;
         float hsqkv, hsm0, hsm1;
     };
     std::vector<uint16_t> pk3;  // bf16x3 planes of the big GEMM weights
@@ -393,6 +395,7 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         loff[l].bqkv = pk.add(bqkv);
         loff[l].w3qkv = add_split3(pk3, wqkv, 3 * D, D);
         loff[l].whqkv = add_split_h2(pk3, wqkv, 3 * D, D, &loff[l].hsqkv);
+        loff[l].wpqkv = add_split_p2(pk3, wqkv, 3 * D, D, &loff[l].hsqkv);
         if ((rc = get_conv(ctx, base + ".attn.merge", D, D, w, b))) return rc;
         std::vector<float> wm((size_t)D * D);
         for (int o = 0; o < D; ++o)
@@ -427,11 +430,13 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         loff[l].b0 = pk.add(b);
         loff[l].w3m0 = add_split3(pk3, w, 2 * D, 2 * D);
         loff[l].whm0 = add_split_h2(pk3, w, 2 * D, 2 * D, &loff[l].hsm0);
+        loff[l].wpm0 = add_split_p2(pk3, w, 2 * D, 2 * D, &loff[l].hsm0);
         if ((rc = get_conv(ctx, base + ".mlp.3", D, 2 * D, w, b))) return rc;
         loff[l].w1 = pk.add(w);
         loff[l].b1 = pk.add(b);
         loff[l].w3m1 = add_split3(pk3, w, D, 2 * D);
         loff[l].whm1 = add_split_h2(pk3, w, D, 2 * D, &loff[l].hsm1);
+        loff[l].wpm1 = add_split_p2(pk3, w, D, 2 * D, &loff[l].hsm1);
     }
     if ((rc = get_conv(ctx, "final_proj", D, D, w, b))) return rc;
     size_t wf = pk.add(w), bf = pk.add(b);
@@ -507,6 +512,9 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         L.wh_qkv = ctx->d_w3arena + loff[l].whqkv; L.hs_qkv = loff[l].hsqkv;
         L.wh_mlp0 = ctx->d_w3arena + loff[l].whm0; L.hs_mlp0 = loff[l].hsm0;
         L.wh_mlp1 = ctx->d_w3arena + loff[l].whm1; L.hs_mlp1 = loff[l].hsm1;
+        L.wp_qkv = ctx->d_w3arena + loff[l].wpqkv;
+        L.wp_mlp0 = ctx->d_w3arena + loff[l].wpm0;
+        L.wp_mlp1 = ctx->d_w3arena + loff[l].wpm1;
     }
     ctx->w_final = base + wf;
     ctx->b_final = base + bf;
@@ -534,6 +542,14 @@ int e2emv_set_precision(e2emv_ctx* ctx, int precision) {
     if (precision != E2EMV_PRECISION_F32 && !ctx->fuse_merge)
         return set_err(ctx, E2EMV_ESTATE, "bf16x3 needs the merge conv folded into MLP0 (unset E2EMV_NO_FUSE_MERGE)");
     ctx->precision = precision;
+    return E2EMV_OK;
+}
+
+int e2emv_set_f16x2_kernels(e2emv_ctx* ctx, int generation) {
+    if (!ctx) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
+    if (generation != 2 && generation != 3) return set_err(ctx, E2EMV_EINVAL, "f16x2 kernel generation %d (2 or 3)", generation);
+    ctx->h2_legacy = generation == 2;
     return E2EMV_OK;
 }
 

@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "p2.h"
 
 namespace e2emv {
 
@@ -161,6 +162,9 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
     const int64_t split_min = ctx->split_min_rows >= 0 ? ctx->split_min_rows : (int64_t)128 * (ctx->num_cus / 2);
     const bool b3 = ctx->precision != E2EMV_PRECISION_F32 && ctx->fuse_merge && Mtot >= split_min;
     const bool h2 = b3 && ctx->precision == E2EMV_PRECISION_F16X2;  // fp16 x 2 planes instead of bf16 x 3 (gemm_x3.hip)
+    // f16x2 on PLANE activations (p2.h): every producer epilogue emits the two fp16 planes, consumers load them straight
+    // into LDS (gemm_p2.hip, attention_p2.hip); h2_legacy keeps the round-2 kernels (fp32 activations, split in the consumer)
+    const bool p2 = h2 && !ctx->h2_legacy && D == 256 && H == 4 && !ctx->layers.empty();
     // bf16x3 attention path: x as S3 planes (6D bytes/row) and V^T planes (6D bytes/row); the q|k planes
     // (S3, 2D wide = 12D bytes/row) live in the fp32 q|k|v buffer, which has exactly that size
     const size_t sz_x3 = b3 ? al((size_t)Mtot * 3 * D * 2) : 0;
@@ -235,9 +239,48 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
     }
 
     // ---- attentional GNN ----
+    uint16_t* xp = (uint16_t*)msg;            // x as scaled planes (msg is free until the conf head)
+    uint16_t* attp = (uint16_t*)att;          // attention output as scaled planes
+    uint16_t* qkp = (uint16_t*)qkv;           // q | k plain planes [Mtot][2D]
+    uint16_t* vtp = qkp + Mtot * 4 * D;       // V^T plain planes [n_img][H][64][n_rows]
+    uint16_t* hidp = (uint16_t*)hid;          // hidden as scaled planes [Mtot][2D]
+    if (p2) {
+        prof_begin(ctx, PS_INGEST, s);
+        rc = launch_to_planes(ctx, x, Mtot, D, D, xp, s);
+        prof_end(ctx, s);
+        if (rc) return rc;
+    }
     for (size_t l = 0; l < ctx->layers.size(); ++l) {
         const LayerWeights& L = ctx->layers[l];
         GemmArgs g;
+        if (p2) {
+            const bool last = l + 1 == ctx->layers.size();
+            GemmP2Args q;
+            q.M = (int)Mtot; q.N = 3 * D; q.K = D; q.K1 = D; q.A = xp; q.lda = D; q.W = L.wp_qkv; q.out_scale = L.hs_qkv; q.bias = L.b_qkv;
+            q.out = P2_OUT_QKV; q.Cp = qkp; q.Vt = vtp; q.n_rows = n_rows; q.heads = H;
+            prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_p2(ctx, q, s); prof_end(ctx, s);
+            if (rc) return rc;
+            prof_begin(ctx, PS_ATTN, s);
+            rc = launch_attention_p2(ctx, B, T, n_rows, Nt, D, H, qkp, vtp, L.type, attp, s);
+            prof_end(ctx, s);
+            if (rc) return rc;
+            // hidden = relu(W0 [x | attention] + b0)   (merge folded into W0, BN folded)
+            GemmP2Args m0;
+            m0.M = (int)Mtot; m0.N = 2 * D; m0.K = 2 * D; m0.K1 = D; m0.A = xp; m0.lda = D; m0.A2 = attp; m0.lda2 = D;
+            m0.W = L.wp_mlp0; m0.out_scale = L.hs_mlp0; m0.bias = L.b_mlp0; m0.relu = true;
+            m0.out = P2_OUT_PLANES; m0.Cp = hidp; m0.ldc = 2 * D;
+            prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_p2(ctx, m0, s); prof_end(ctx, s);
+            if (rc) return rc;
+            // x += W1 hidden + b1; the last layer hands x to final_proj as fp32
+            GemmP2Args m1;
+            m1.M = (int)Mtot; m1.N = D; m1.K = 2 * D; m1.K1 = 2 * D; m1.A = hidp; m1.lda = 2 * D;
+            m1.W = L.wp_mlp1; m1.out_scale = L.hs_mlp1; m1.bias = L.b_mlp1; m1.Rp = xp; m1.ldr = D;
+            if (last) { m1.out = P2_OUT_F32; m1.C32 = x; m1.ldc = D; }
+            else { m1.out = P2_OUT_PLANES; m1.Cp = xp; m1.ldc = D; }
+            prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_p2(ctx, m1, s); prof_end(ctx, s);
+            if (rc) return rc;
+            continue;
+        }
         if (b3) {
             // q|k|v on the split-operand GEMM with a plain fp32 output; the attention kernel splits Q / K / V^T into
             // bf16 planes on the way in (E2EMV_B3_PLANES=1 selects the first-generation hand-over: fp32-pipe GEMM whose

@@ -1,0 +1,344 @@
+// Plane-in / plane-out "NT" GEMM of the f16x2 arithmetic mode:  C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+ R[m][n])
+//
+// Same arithmetic as gemm_h2.hip (x = x_hi + 2^-11 x_lo', weights 2^s W = w_hi + w_lo, three fp16 MFMA products per
+// block into one fp32 accumulator), but the activation arrives ALREADY as the two planes (p2.h): whoever produced it
+// split it once, in its epilogue.  What that buys in the K loop, per 256 x 256 x 32 step and workgroup:
+//   * no fp32 -> plane split (40 VALU per thread) and no ds_write at all: the 64 KB of operand planes go from global
+//     memory straight into LDS, 64 buffer_load_dwordx4 ... lds per step (8 per wave), each a full 128-byte line per row;
+//   * LDS double-buffered (2 x 64 KB), ONE barrier per K step: the loads of step g + 1 are issued right after the barrier
+//     that opens step g and have that whole step (48 MFMAs per wave) to land;
+//   * bank-conflict-free fragment reads without padding (XOR swizzle applied on the source address, p2.h).
+// The epilogue goes through per-wave LDS slabs (32 rows x 36 floats) so that bias / ReLU / residual / the plane split
+// work on 8 consecutive columns of one row per lane and every store covers 64-byte row segments; the residual is read
+// back from its planes (22 bits) in the same layout.  Output kinds: fp32, scaled planes (the next GEMM's operand), or
+// the attention operands q | k (plain planes, q pre-scaled) + V^T (transposed plain planes, keys in the order of the
+// transposed-score registers) - attention_p2.hip then never touches an fp32 q|k|v matrix.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "p2.h"
+
+namespace e2emv {
+
+typedef __attribute__((ext_vector_type(16))) float p2_f32x16;
+
+constexpr int P2_BM = 256, P2_BN = 256, P2_BK = 32;
+constexpr int P2_ROWB = 128;                    // bytes of one tile row per K step: 32 hi halves | 32 lo halves
+constexpr int P2_TILEB = P2_BM * P2_ROWB;       // 32 KB per operand tile
+constexpr int P2_BUFB = 2 * P2_TILEB;           // A tile | W tile
+constexpr int P2_SLAB_LD = 36;                  // floats per slab row (32 + 4: conflict-free b128 writes)
+constexpr int P2_SLABB = 32 * P2_SLAB_LD * 4;   // 4608 B per wave
+
+struct GemmP2Params {
+    const uint16_t* A;
+    const uint16_t* A2;
+    const uint16_t* W;
+    unsigned a_bytes, a2_bytes, w_bytes;  // extents for the buffer descriptors
+    unsigned lda_b, lda2_b, ldw_b;        // row strides in bytes
+    const float* bias;
+    const uint16_t* Rp;
+    float* C32;
+    uint16_t* Cp;
+    uint16_t* Vt;
+    int64_t ldc, ldr;
+    int M, N, K, K1;
+    int tiles_n, total, relu;
+    float out_scale;
+    float col_scale[3];
+    int n_rows, heads;
+};
+
+template <int OUT>
+__global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_p2[];
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int per_xcd = (p.total + 7) / 8;
+    const int t_begin = xcd * per_xcd;
+    const int t_end = min(t_begin + per_xcd, p.total);
+    int tile = t_begin + slot;
+    if (tile >= t_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nk = p.K / P2_BK, nk1 = p.K1 / P2_BK;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.A2), 0, (int)p.a2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.W), 0, (int)p.w_bytes, 0x00020000);
+
+    // ---- loader: wave w moves rows 32 w .. 32 w + 31 of the activation tile and of the weight tile, 4 + 4 LDS-direct loads
+    // per K step; one load = 8 rows x 128 B, lane -> (row lane >> 3, LDS position lane & 7), source chunk = position ^ swizzle
+    const int ld_r = lane >> 3, ld_p = lane & 7;
+    unsigned a_vo[4], a2_vo[4], w_vo[4];
+    auto setup = [&](int t) {
+        const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 32 * wave + 8 * i + ld_r;
+            const unsigned c = (unsigned)(ld_p ^ ((row >> 1) & 7));
+            const unsigned gm = (unsigned)min(tm * P2_BM + row, p.M - 1);
+            a_vo[i] = gm * p.lda_b + c * 16u;
+            a2_vo[i] = gm * p.lda2_b + c * 16u;
+            const unsigned gn = (unsigned)min(tn * P2_BN + row, p.N - 1);
+            w_vo[i] = gn * p.ldw_b + c * 16u;
+        }
+    };
+    auto issue = [&](int buf, int kt) {
+        char* dst = smem_p2 + buf * P2_BUFB + 32 * wave * P2_ROWB;
+        if (kt < nk1) {
+            const unsigned so = (unsigned)kt * 128u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                p2_glds16(rsA, dst + i * 1024, a_vo[i], so);
+        } else {
+            const unsigned so = (unsigned)(kt - nk1) * 128u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                p2_glds16(rsA2, dst + i * 1024, a2_vo[i], so);
+        }
+        const unsigned sw = (unsigned)kt * 128u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            p2_glds16(rsW, dst + P2_TILEB + i * 1024, w_vo[i], sw);
+    };
+
+    // ---- fragments: lane (row l31, k half lh); chunk index c = 4 plane + 2 ks + lh, stored at position c ^ ((l31 >> 1) & 7)
+    const int swz = (l31 >> 1) & 7;
+    p2_f32x16 acc[4][2];
+    auto compute = [&](int buf, auto FIRST) {
+        constexpr bool first_step = decltype(FIRST)::value;
+        const char* xs = smem_p2 + buf * P2_BUFB + (wr * 64 + l31) * P2_ROWB;
+        const char* ws = smem_p2 + buf * P2_BUFB + P2_TILEB + (wc * 128 + l31) * P2_ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            p2_f16x8 x[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    x[t][pl] = *reinterpret_cast<const p2_f16x8*>(xs + t * 32 * P2_ROWB + (((4 * pl + 2 * ks + lh) ^ swz) << 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p2_f16x8 w[3];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    w[pl] = *reinterpret_cast<const p2_f16x8*>(ws + j * 32 * P2_ROWB + (((4 * pl + 2 * ks + lh) ^ swz) << 4));
+                w[2] = w[0] * (_Float16)(1.f / 2048.f);  // 2^-11 w_hi (exact wherever it matters: gemm_h2.hip)
+                constexpr int PW[3] = {1, 2, 0}, PX[3] = {0, 1, 0};  // x_hi w_lo, x_lo' (2^-11 w_hi), x_hi w_hi: smallest first
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (first_step && ks == 0 && q == 0) {
+                            const p2_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[PW[q]], x[i][PX[q]], zero, 0, 0, 0);
+                        } else {
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[PW[q]], x[i][PX[q]], acc[j][i], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+    };
+
+    // ---- epilogue (see the header); fb = the tile buffer nobody reads or fills during it
+    auto epilogue = [&](int t, int fb) {
+        float* slab = reinterpret_cast<float*>(smem_p2 + fb * P2_BUFB + wave * P2_SLABB);
+        const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+        const int o_r = lane >> 2, o_c = (lane & 3) * 8;  // row-contiguous view: 16 rows per pass, 8 columns per lane
+        const float cs = OUT == P2_OUT_QKV ? p.col_scale[min(tn, 2)] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    p2_f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+                    *reinterpret_cast<p2_f32x4*>(&slab[l31 * P2_SLAB_LD + 8 * g + 4 * lh]) = v;
+                }
+                const int m0 = tm * P2_BM + wr * 64 + i * 32;
+                const int n0 = tn * P2_BN + wc * 128 + j * 32;
+                if (OUT == P2_OUT_QKV && tn == 2) {
+                    // V^T: lane -> (dim d, 16-byte chunk q of the 32-key block) = 8 keys in accumulator order
+#pragma unroll
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const int dl = (lane >> 2) + 16 * pass, q = lane & 3;
+                        const int n = n0 + dl;
+                        const int rb = 16 * (q >> 1) + 4 * (q & 1);
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = slab[(rb + (e & 3) + 8 * (e >> 2)) * P2_SLAB_LD + dl];
+                        if (m0 >= p.M || n >= p.N) continue;
+                        const float b = p.bias ? p.bias[n] : 0.f;
+                        p2_u32x4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const P2Pair pr = p2_split_plain((v[2 * e] * p.out_scale + b) * cs, (v[2 * e + 1] * p.out_scale + b) * cs);
+                            hi[e] = pr.hi; lo[e] = pr.lo;
+                        }
+                        const int img = m0 / p.n_rows, key0 = m0 - img * p.n_rows;
+                        const int nv = n - 2 * P2_BN, head = nv >> 6, dd = nv & 63;
+                        uint16_t* dst = p.Vt + ((int64_t)(img * p.heads + head) * 64 + dd) * (2 * (int64_t)p.n_rows) + (key0 >> 5) * 64 + q * 8;
+                        *reinterpret_cast<p2_u32x4*>(dst) = hi;
+                        *reinterpret_cast<p2_u32x4*>(dst + 32) = lo;
+                    }
+                    continue;
+                }
+                const int n = n0 + o_c;
+                p2_f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias && n < p.N) b0 = *reinterpret_cast<const p2_f32x4*>(p.bias + n);
+                if (p.bias && n + 4 < p.N) b1 = *reinterpret_cast<const p2_f32x4*>(p.bias + n + 4);
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int r = o_r + 16 * pass;
+                    const int m = m0 + r;
+                    p2_f32x4 v0 = *reinterpret_cast<const p2_f32x4*>(&slab[r * P2_SLAB_LD + o_c]);
+                    p2_f32x4 v1 = *reinterpret_cast<const p2_f32x4*>(&slab[r * P2_SLAB_LD + o_c + 4]);
+                    if (m >= p.M || n >= p.N) continue;
+                    v0 = v0 * p.out_scale + b0;
+                    v1 = v1 * p.out_scale + b1;
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = relu_nan(v0[e]); v1[e] = relu_nan(v1[e]); }
+                    }
+                    if (p.Rp) {
+                        const uint16_t* rp = p.Rp + p2_index(m, n, p.ldr);
+                        const p2_u32x4 rh = *reinterpret_cast<const p2_u32x4*>(rp), rl = *reinterpret_cast<const p2_u32x4*>(rp + 32);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const p2_f32x2 a = p2_join_scaled(rh[e], rl[e]), c = p2_join_scaled(rh[2 + e], rl[2 + e]);
+                            v0[2 * e] += a[0]; v0[2 * e + 1] += a[1];
+                            v1[2 * e] += c[0]; v1[2 * e + 1] += c[1];
+                        }
+                    }
+                    if (OUT == P2_OUT_F32) {
+                        float* cp = p.C32 + (int64_t)m * p.ldc + n;
+                        *reinterpret_cast<p2_f32x4*>(cp) = v0;
+                        if (n + 4 < p.N) *reinterpret_cast<p2_f32x4*>(cp + 4) = v1;
+                    } else {
+                        p2_u32x4 hi, lo;
+                        if (OUT == P2_OUT_QKV) {
+                            v0 *= cs; v1 *= cs;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const P2Pair a = p2_split_plain(v0[2 * e], v0[2 * e + 1]), c = p2_split_plain(v1[2 * e], v1[2 * e + 1]);
+                                hi[e] = a.hi; lo[e] = a.lo; hi[2 + e] = c.hi; lo[2 + e] = c.lo;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const P2Pair a = p2_split_scaled(v0[2 * e], v0[2 * e + 1]), c = p2_split_scaled(v1[2 * e], v1[2 * e + 1]);
+                                hi[e] = a.hi; lo[e] = a.lo; hi[2 + e] = c.hi; lo[2 + e] = c.lo;
+                            }
+                        }
+                        uint16_t* cp = p.Cp + p2_index(m, n, p.ldc);
+                        *reinterpret_cast<p2_u32x4*>(cp) = hi;
+                        *reinterpret_cast<p2_u32x4*>(cp + 32) = lo;
+                    }
+                }
+            }
+    };
+
+    // ---- pipeline.  Step g = (tile, kt) in execution order lives in LDS buffer g & 1.  Every step opens with "my loads of
+    // this step have landed" (vmcnt(0): they were issued a whole step ago) + ONE barrier (everybody's have; everybody is
+    // done reading the other buffer), then issues the loads of step g + 1 into the other buffer and computes.  The load
+    // position runs one step ahead of the compute position across output tiles.
+    int ld_tile = tile, ld_kt = 0;
+    bool ld_valid = true;
+    auto advance = [&]() {
+        if (ld_kt + 1 < nk) { ++ld_kt; return; }
+        if (ld_tile + slots < t_end) {
+            ld_tile += slots;
+            ld_kt = 0;
+            setup(ld_tile);
+        } else {
+            ld_valid = false;
+        }
+    };
+    setup(tile);
+    issue(0, 0);
+    advance();
+    int buf = 0;
+    auto step = [&](auto FIRST) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ld_valid) {
+            issue(buf ^ 1, ld_kt);
+            advance();
+        }
+        compute(buf, FIRST);
+        buf ^= 1;
+    };
+    for (;;) {
+        step(std::true_type{});
+        for (int kt = 1; kt < nk; ++kt) step(std::false_type{});
+        __syncthreads();  // every wave is done with the buffer of the last step: it carries the slabs now
+        epilogue(tile, buf ^ 1);
+        tile += slots;
+        if (tile >= t_end) break;
+    }
+}
+
+int launch_gemm_p2(e2emv_ctx* ctx, const GemmP2Args& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: empty problem");
+    const int K1 = a.A2 ? a.K1 : a.K;
+    if (a.K % 32 || K1 % 32 || K1 <= 0 || K1 > a.K || (K1 < a.K && !a.A2))
+        return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: K=%d K1=%d must be multiples of 32", a.K, K1);
+    if (!a.A || !a.W || a.lda % 32 || a.lda < K1 || (a.A2 && (a.lda2 % 32 || a.lda2 < a.K - K1)))
+        return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: operand planes need whole 32-column blocks (lda=%lld lda2=%lld)", (long long)a.lda, (long long)a.lda2);
+    if ((uintptr_t)a.A % 16 || (a.A2 && (uintptr_t)a.A2 % 16) || (uintptr_t)a.W % 16 || (a.bias && (uintptr_t)a.bias % 16) || (a.Rp && (uintptr_t)a.Rp % 16))
+        return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: operands must be 16-byte aligned");
+    if (a.Rp && (a.ldr % 32 || a.ldr < a.N)) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: residual planes need ldr %% 32 == 0");
+    const int64_t a_bytes = (int64_t)a.M * a.lda * 4, a2_bytes = a.A2 ? (int64_t)a.M * a.lda2 * 4 : 16, w_bytes = (int64_t)a.N * a.K * 4;
+    if (a_bytes >= ((int64_t)1 << 31) || a2_bytes >= ((int64_t)1 << 31) || w_bytes >= ((int64_t)1 << 31))
+        return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: operand larger than 2 GB (M=%d lda=%lld): 32-bit byte offsets", a.M, (long long)a.lda);
+    GemmP2Params p{};
+    p.A = a.A; p.A2 = a.A2 ? a.A2 : a.A; p.W = a.W;
+    p.a_bytes = (unsigned)a_bytes; p.a2_bytes = (unsigned)(a.A2 ? a2_bytes : a_bytes); p.w_bytes = (unsigned)w_bytes;
+    p.lda_b = (unsigned)(a.lda * 4); p.lda2_b = (unsigned)((a.A2 ? a.lda2 : a.lda) * 4); p.ldw_b = (unsigned)(a.K * 4);
+    p.bias = a.bias; p.Rp = a.Rp; p.ldr = a.ldr;
+    p.C32 = a.C32; p.Cp = a.Cp; p.Vt = a.Vt; p.ldc = a.ldc;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.K1 = K1;
+    p.tiles_n = (a.N + P2_BN - 1) / P2_BN;
+    p.total = ((a.M + P2_BM - 1) / P2_BM) * p.tiles_n;
+    p.relu = a.relu ? 1 : 0;
+    p.out_scale = a.out_scale;
+    p.col_scale[0] = p.col_scale[1] = p.col_scale[2] = 1.f;
+    p.n_rows = a.n_rows; p.heads = a.heads;
+    const void* fn = nullptr;
+    switch (a.out) {
+        case P2_OUT_F32:
+            if (!a.C32 || a.N % 4 || a.ldc % 4 || (uintptr_t)a.C32 % 16) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: fp32 output needs N %% 4 == 0, ldc %% 4 == 0");
+            fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_F32>);
+            break;
+        case P2_OUT_PLANES:
+            if (!a.Cp || a.N % 8 || a.ldc % 32 || a.ldc < a.N || (uintptr_t)a.Cp % 16) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: plane output needs N %% 8 == 0, ldc %% 32 == 0");
+            fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES>);
+            break;
+        case P2_OUT_QKV:
+            if (!a.Cp || !a.Vt || a.N != 3 * P2_BN || a.heads != 4 || a.n_rows <= 0 || a.n_rows % 32 || a.M % a.n_rows || a.relu || a.Rp ||
+                (uintptr_t)a.Cp % 16 || (uintptr_t)a.Vt % 16)
+                return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: q|k|v output needs N = 768 (4 heads of 64), n_rows %% 32 == 0, M %% n_rows == 0");
+            p.ldc = 2 * P2_BN;
+            p.col_scale[0] = 0.125f * 1.4426950408889634f * P2_QS;  // log2(e) / sqrt(64), then the plane pre-scale
+            p.col_scale[2] = P2_VS;
+            fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_QKV>);
+            break;
+        default: return set_err(ctx, E2EMV_EINVAL, "gemm_p2: unknown output kind %d", a.out);
+    }
+    const int per_xcd = (p.total + 7) / 8;
+    const int sl = std::min(per_xcd, std::max(1, ctx->num_cus / 8));
+    const size_t lds = 2 * P2_BUFB;
+    if (int rc = ensure_dynamic_lds(ctx, fn, lds)) return rc;
+    void* args[] = {&p};
+    E2EMV_HIP(ctx, hipLaunchKernel(fn, dim3(8 * sl), dim3(512), args, lds, s));
+    E2EMV_CHECK_LAUNCH(ctx, "gemm_p2_kernel");
+    return E2EMV_OK;
+}
+
+}  // namespace e2emv

@@ -173,6 +173,9 @@ class MultiViewMatcher(nn.Module):
             want = _lib.PRECISION_NAMES[mode]
         if ctx.precision() != want:
             ctx.call("e2emv_set_precision", want)
+        gen = 2 if mode == "f16x2-r2" else ctx.default_f16x2_kernels
+        if ctx.f16x2_kernels != gen:
+            ctx.set_f16x2_kernels(gen)
         kpts, scores, descs = [], [], []
         fd = _lib.ForwardDesc()
         for m in range(T):

@@ -101,3 +101,47 @@ def attention_bf16x3(qkv, B, T, n_valid, H, cross, kernel="planes"):
         ctx.call("e2emv_attention_bf16x3", B, T, n_rows, n_valid, D, H, _lib.ptr(q),
                  (1 if cross else 0) | {"planes": 0, "fused": 2, "f16x2": 6}[kernel], _lib.ptr(out), _lib.stream_ptr(q.device))
     return out
+
+
+def gemm_p2(A, W, bias=None, relu=False, A2=None, residual=None, planes_out=False, reps=1):
+    """gemm_p2.hip on fp32 tensors: act([A | A2] W^T + bias) (+ residual).  The operands are converted to the plane format
+    (p2.h) by helper kernels, the kernel writes fp32 or (``planes_out``) planes that are converted back."""
+    ctx = _ctx(A)
+    A_, W_ = A.contiguous().float(), W.contiguous().float()
+    A2_ = A2.contiguous().float() if A2 is not None else None
+    M, K1 = A_.shape
+    N, K = W_.shape
+    C = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    b = bias.contiguous().float() if bias is not None else None
+    R = residual.contiguous().float() if residual is not None else None
+    flags = (1 if relu else 0) | (2 if planes_out else 0) | (int(reps) << 8 if reps > 1 else 0)
+    with torch.cuda.device(A.device):
+        ctx.call("e2emv_gemm_p2", M, N, K, K1, _lib.ptr(A_), _lib.ptr(A2_), _lib.ptr(W_), _lib.ptr(b), _lib.ptr(R), _lib.ptr(C), flags,
+                 _lib.stream_ptr(A.device))
+    return C
+
+
+def qkv_p2(X, W, bias, n_rows, H=4):
+    """q|k|v projection through gemm_p2's attention-operand epilogue, read back as fp32 [n_img*n_rows, 3D]."""
+    ctx = _ctx(X)
+    X_, W_ = X.contiguous().float(), W.contiguous().float()
+    M, D = X_.shape
+    out = torch.empty((M, 3 * D), dtype=torch.float32, device=X.device)
+    b = bias.contiguous().float() if bias is not None else None
+    with torch.cuda.device(X.device):
+        ctx.call("e2emv_qkv_p2", M // n_rows, n_rows, D, H, _lib.ptr(X_), _lib.ptr(W_), _lib.ptr(b), _lib.ptr(out), _lib.stream_ptr(X.device))
+    return out
+
+
+def attention_p2(qkv, B, T, n_valid, H, cross, waves=0, reps=1):
+    """attention_p2.hip on an fp32 q|k|v matrix (split into the plane operands by a helper kernel); same contract as
+    `attention`.  waves: 0 = by key count, 4 / 8 = workgroup size."""
+    ctx = _ctx(qkv)
+    q = qkv.contiguous().float()
+    n_img, n_rows, D3 = q.shape
+    D = D3 // 3
+    out = torch.empty((n_img, n_rows, D), dtype=torch.float32, device=q.device)
+    flags = (1 if cross else 0) | {0: 0, 4: 2, 8: 4}[waves] | (int(reps) << 8 if reps > 1 else 0)
+    with torch.cuda.device(q.device):
+        ctx.call("e2emv_attention_p2", B, T, n_rows, n_valid, D, H, _lib.ptr(q), flags, _lib.ptr(out), _lib.stream_ptr(q.device))
+    return out

@@ -328,6 +328,28 @@ int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const float* d_A, 
 int e2emv_attention_bf16x3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv,
                            int cross, float* d_out, void* stream);
 
+/* ---- f16x2 on plane activations (the default implementation of E2EMV_PRECISION_F16X2) ---------------------------
+ * Activations live in HBM as the two fp16 planes of the f16x2 arithmetic (4 bytes per element like fp32, 32-column
+ * blocks of {hi, lo}); every producer splits its output once in its epilogue, consumers move the planes from global
+ * memory straight into LDS.  generation 3 = these kernels (gemm_p2.hip, attention_p2.hip; needs descriptor_dim 256 /
+ * 4 heads, other widths use generation 2), 2 = the round-2 kernels that keep fp32 activations and split them inside
+ * the consuming GEMM / attention (kept as the A/B arm and for other widths).  Also E2EMV_F16X2_KERNELS=r2 at e2emv_create. */
+int e2emv_set_f16x2_kernels(e2emv_ctx* ctx, int generation);
+/* building blocks on fp32 buffers (conversion to / from planes done by helper kernels; for tests and micro-benchmarks):
+ * C = act([A | A2] W^T + bias) (+ R); A [M,K1], A2 [M,K-K1] or NULL, W [N,K], R [M,N] or NULL.  flags: bit0 relu, bit1 the
+ * kernel writes planes (converted back to fp32 afterwards) instead of fp32, bits 8.. = number of timed repetitions.  The
+ * weight planes are made on the host as e2emv_commit_weights makes them (host-synchronising). */
+int e2emv_gemm_p2(e2emv_ctx* ctx, int M, int Nout, int K, int K1, const float* d_A, const float* d_A2, const float* d_W,
+                  const float* d_bias, const float* d_R, float* d_C, int flags, void* stream);
+/* the q|k|v projection with its attention-operand epilogue (q | k planes + transposed V planes), read back as one fp32
+ * matrix: d_X [n_img*n_rows, D], d_W [3D, D] head-major, d_qkv [n_img*n_rows, 3D]. */
+int e2emv_qkv_p2(e2emv_ctx* ctx, int n_img, int n_rows, int D, int H, const float* d_X, const float* d_W, const float* d_bias,
+                 float* d_qkv, void* stream);
+/* same contract as e2emv_attention on the plane kernel; flags: bit0 cross, bit1 / bit2 force 4 / 8 waves per workgroup,
+ * bits 8.. = timed repetitions. */
+int e2emv_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv, int flags,
+                       float* d_out, void* stream);
+
 /* ---- timing hooks used by bench.py (HIP events on the caller's stream) -------------
  * After e2emv_profile(ctx, 1) every kernel family launched by the library is bracketed by
  * HIP events on its stream; e2emv_profile_read returns accumulated milliseconds and launch

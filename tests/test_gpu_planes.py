@@ -1,0 +1,143 @@
+"""Plane-format kernels of the f16x2 mode (-m gpu): gemm_p2.hip / attention_p2.hip through the C ABI vs torch fp64.
+
+The building-block entry points take fp32 tensors, convert them to the plane format (csrc/p2.h) with helper kernels, run
+the kernel under test and convert back; the bars are those of the round-2 f16x2 kernels (tests/test_gpu_kernels.py)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm_case(g, M, N, K, act_scale=1.0, K1=None):
+    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g) * 2) * act_scale
+    A = A.clamp(-6e4, 6e4)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * act_scale
+    return A, W, b
+
+
+def _err(out, ref, scale):
+    return float(((out.double() - ref).abs() / scale).max())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 64), (1024, 512, 512), (65, 36, 256), (777, 768, 256)])
+@pytest.mark.parametrize("act_scale", [1.0, 1e-3, 3e3])
+def test_gemm_p2_has_fp32_class_accuracy(gpu, M, N, K, act_scale):
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W, b = _gemm_case(g, M, N, K, act_scale)
+    ref = A.double() @ W.double().T + b.double()
+    scale = (A.double().abs() @ W.double().abs().T) + b.double().abs()
+    out = E.gemm_p2(A.to(gpu), W.to(gpu), bias=b.to(gpu)).cpu()
+    out32 = E.gemm_nt(A.to(gpu), W.to(gpu), bias=b.to(gpu)).cpu()
+    e, e32 = _err(out, ref, scale), _err(out32, ref, scale)
+    assert e < 5e-7, (e, e32)
+    assert e < 4 * e32 + 2e-7, (e, e32)
+    outr = E.gemm_p2(A.to(gpu), W.to(gpu), bias=b.to(gpu), relu=True).cpu()
+    assert torch.equal(outr, out.clamp_min(0))
+
+
+@pytest.mark.parametrize("M,N,K1,K2", [(257, 512, 256, 256), (1000, 256, 512, 0), (513, 96, 64, 32)])
+def test_gemm_p2_plane_epilogue_two_segments_residual(gpu, M, N, K1, K2):
+    """The forward pass's shapes of use: two K segments (x | attention), ReLU, residual read from its planes, plane output.
+    A plane output carries 22 significant bits: the bar adds 2^-22 of |value| to the contraction bar."""
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(M + N)
+    K = K1 + K2
+    A, W, b = _gemm_case(g, M, N, K)
+    R = torch.randn(M, N, generator=g) * 3
+    A1, A2 = A[:, :K1].contiguous(), (A[:, K1:].contiguous() if K2 else None)
+    for relu in (False, True):
+        core = A.double() @ W.double().T + b.double()
+        ref = (core.clamp_min(0) if relu else core) + R.double()
+        scale = (A.double().abs() @ W.double().abs().T) + b.double().abs() + R.double().abs()
+        for planes_out in (False, True):
+            out = E.gemm_p2(A1.to(gpu), W.to(gpu), bias=b.to(gpu), relu=relu, A2=A2.to(gpu) if K2 else None, residual=R.to(gpu),
+                            planes_out=planes_out).cpu()
+            e = _err(out, ref, scale)
+            assert e < 5e-7 + 2.5e-7 + (2.5e-7 if planes_out else 0.0), (relu, planes_out, e)
+
+
+def test_gemm_p2_random_shapes(gpu):
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(2025)
+    for case in range(24):
+        M = int(torch.randint(1, 1500, (1,), generator=g))
+        N = [4 * int(torch.randint(1, 200, (1,), generator=g)), 256 * int(torch.randint(1, 4, (1,), generator=g))][case % 2]
+        K = 32 * int(torch.randint(1, 25, (1,), generator=g))
+        relu = bool(case & 2)
+        A = torch.randn(M, K, generator=g) * float(torch.exp(torch.randn(1, generator=g) * 2))
+        W = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g) if case % 3 else None
+        ref = A.double() @ W.double().T + (b.double() if b is not None else 0.0)
+        if relu:
+            ref = ref.clamp_min(0)
+        out = E.gemm_p2(A.to(gpu), W.to(gpu), bias=b.to(gpu) if b is not None else None, relu=relu, planes_out=(N % 32 == 0 and case % 4 == 1)).cpu()
+        assert out.shape == (M, N)
+        scale = (A.double().abs() @ W.double().abs().T) + (b.double().abs() if b is not None else 0.0)
+        e = _err(out, ref, scale)
+        assert e < 7.5e-7, (case, M, N, K, relu, e)
+
+
+@pytest.mark.parametrize("n_img,n_rows", [(2, 128), (3, 256), (1, 1024)])
+def test_qkv_projection_attention_operand_epilogue(gpu, n_img, n_rows):
+    """q | k plain planes and the transposed, key-permuted V planes, read back through the helper that mirrors the attention
+    kernel's addressing: every element of x W^T + b must come back (to the 22 bits the planes carry)."""
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(n_rows)
+    D = 256
+    X = torch.randn(n_img * n_rows, D, generator=g) * torch.exp(torch.randn(n_img * n_rows, 1, generator=g))
+    W = torch.randn(3 * D, D, generator=g) / D ** 0.5
+    b = torch.randn(3 * D, generator=g)
+    ref = X.double() @ W.double().T + b.double()
+    scale = (X.double().abs() @ W.double().abs().T) + b.double().abs()
+    out = E.qkv_p2(X.to(gpu), W.to(gpu), b.to(gpu), n_rows).cpu()
+    e = _err(out, ref, scale)
+    assert e < 1e-6, e
+
+
+def _attention_ref(qkv, B, T, n_valid, H, cross):
+    from test_gpu_kernels import _attention_ref as r
+    return r(qkv, B, T, n_valid, H, cross)
+
+
+@pytest.mark.parametrize("B,T,n_rows,n_valid,cross", [(2, 2, 128, 128, 0), (2, 2, 256, 200, 1), (1, 3, 256, 131, 1),
+                                                       (1, 2, 128, 5, 0), (1, 2, 512, 300, 0)])
+@pytest.mark.parametrize("waves", [4, 8])
+def test_attention_p2(gpu, B, T, n_rows, n_valid, cross, waves):
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(n_valid)
+    qkv = torch.randn(B * T, n_rows, 3 * 256, generator=g) * 1.5
+    ref = _attention_ref(qkv, B, T, n_valid, 4, cross)
+    out = E.attention_p2(qkv.to(gpu), B, T, n_valid, 4, cross, waves=waves).cpu()
+    out32 = E.attention(qkv.to(gpu), B, T, n_valid, 4, cross).cpu()
+    err = float((out[:, :n_valid].double() - ref[:, :n_valid]).abs().max())
+    err32 = float((out32[:, :n_valid].double() - ref[:, :n_valid]).abs().max())
+    assert err < 2e-5 and err < 3 * err32 + 1e-6, (err, err32)
+
+
+def test_attention_p2_spiked_key_forces_rescale(gpu):
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(2, 256, 768, generator=g)
+    qkv[0, 200, 256:512] = qkv[0, 17, 0:256] * 6.0  # key 200 aligned with query 17, all heads
+    ref = _attention_ref(qkv, 1, 2, 256, 4, 0)
+    out = E.attention_p2(qkv.to(gpu), 1, 2, 256, 4, 0).cpu()
+    assert float((out.double() - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("qs,ks,vs", [(1.0, 1.0, 1.0), (0.05, 0.05, 0.01), (6.0, 6.0, 300.0), (30.0, 0.2, 1e-3)])
+def test_attention_p2_over_operand_magnitudes(gpu, qs, ks, vs):
+    import e2e_multi_view_matching_amd as E
+    B, T, n_rows, n_valid, cross = 1, 2, 256, 256, 1
+    g = torch.Generator().manual_seed(7)
+    qkv = torch.randn(B * T, n_rows, 3 * 256, generator=g)
+    qkv[..., :256] *= qs
+    qkv[..., 256:512] *= ks
+    qkv[..., 512:] *= vs
+    ref = _attention_ref(qkv, B, T, n_valid, 4, cross)
+    out = E.attention_p2(qkv.to(gpu), B, T, n_valid, 4, cross).cpu()
+    out32 = E.attention(qkv.to(gpu), B, T, n_valid, 4, cross).cpu()
+    err = float((out.double() - ref).abs().max()) / vs
+    err32 = float((out32.double() - ref).abs().max()) / vs
+    assert err < 3 * err32 + 2e-6, (err, err32)

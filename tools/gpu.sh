@@ -1,0 +1,62 @@
+#!/bin/bash
+# One parameterised GPU-box script (run through gpurun): tools/gpu.sh <stage> [...]; output under gpurun_out/r3/.
+#   planes   per-kernel parity of the plane kernels + matcher parity + micro-benchmarks + bench A/B (plane vs round-2 kernels)
+#   tests    the whole -m gpu suite
+#   bench    bench.py lines (c2 default, c4, c5)
+#   prof     rocprofv3 kernel trace + the three PMC passes of config c2
+cd "$GRAFT_REPO_ROOT" || exit 1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r3
+mkdir -p $OUT
+export TMPDIR=/tmp
+stage=${1:-tests}
+show() { python - "$@" <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split('/')[-1], d['value'], d['ms_per_step'], d['roofline']['kernel'], round(d['roofline']['frac'], 4), d.get('families'),
+              [(a['mode'], a['value']) for a in d.get('other_precisions', [])], d.get('batch1_latency'), d.get('fallbacks'))
+    except Exception as e:
+        print(f, 'FAILED', e)
+        try: print(open(f.replace('.json', '.err')).read()[-1500:])
+        except Exception: pass
+PY
+}
+case $stage in
+planes)
+  timeout 900 python -m pytest tests/test_gpu_planes.py -x -q 2>&1 | tail -15 | tee $OUT/planes_tests.log
+  timeout 900 python -m pytest tests/test_gpu_matcher.py tests/test_gpu_golden_direct.py -x -q 2>&1 | tail -15 | tee $OUT/planes_matcher.log
+  timeout 600 python tools/microbench.py --what p2 2>&1 | tee $OUT/microbench_p2.log
+  timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_p2.json 2> $OUT/bench_p2.err
+  E2EMV_F16X2_KERNELS=r2 timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_r2k.json 2> $OUT/bench_r2k.err
+  show $OUT/bench_p2.json $OUT/bench_r2k.json
+  ;;
+tests)
+  timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/tests.log
+  ;;
+bench)
+  timeout 400 python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+  timeout 300 python bench.py --config c4 --cpu-pairs 0 > $OUT/bench_c4.json 2> $OUT/bench_c4.err
+  timeout 300 python bench.py --config c5 --cpu-pairs 0 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+  show $OUT/bench_c2.json $OUT/bench_c4.json $OUT/bench_c5.json
+  ;;
+prof)
+  cfg=${2:-c2}; mode=${3:-f16x2}
+  args="--config $cfg --precision $mode --steps 2 --warmup 1 --cpu-pairs 0 --no-alt --no-latency --no-profile"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_${cfg}_${mode} -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_${cfg}_${mode}.log 2>&1)
+  db=$(find /tmp/kt_${cfg}_${mode} -name '*.db' | head -1)
+  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r3_kernel_stats_${cfg}_${mode}.md 2>&1
+  head -30 $OUT/r3_kernel_stats_${cfg}_${mode}.md
+  i=0
+  for ctr in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+    (cd /tmp && timeout 400 rocprofv3 --pmc $ctr -d /tmp/pmc_${cfg}_${mode}_$i -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/pmc_${cfg}_${mode}_$i.log 2>&1)
+    i=$((i+1))
+  done
+  d0=$(find /tmp/pmc_${cfg}_${mode}_0 -name '*.db' | head -1); d1=$(find /tmp/pmc_${cfg}_${mode}_1 -name '*.db' | head -1); d2=$(find /tmp/pmc_${cfg}_${mode}_2 -name '*.db' | head -1)
+  cp profiles/pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null
+  pairs=32; kpts=1024; [ "$cfg" = c4 ] && pairs=80; [ "$cfg" = c5 ] && { pairs=80; kpts=2048; }
+  python profiles/summarize_pmc.py "$d0" "$d1" "$d2" $OUT/r3_pmc_${cfg}_${mode}.md $OUT/pmc_traffic.json $cfg $mode $pairs $kpts > /dev/null 2> $OUT/pmc_${cfg}_${mode}_summ.err
+  head -12 $OUT/r3_pmc_${cfg}_${mode}.md
+  ;;
+*) echo "unknown stage $stage"; exit 2;;
+esac

@@ -81,6 +81,41 @@ def main():
                 ctx.call("e2emv_profile", 0)
                 ms = pr["ms"] / pr["launches"]
                 print(f"  B={B:3d} N={N:5d} cross={cross}  {ms * 1e3:9.1f} us  {B * 2 * 4.0 * N * N * 256 / ms / 1e9:7.1f} TF  ({kernel})")
+    if "p2" in args.what:
+        print("== f16x2 GEMM: gemm_h2 (fp32 activations, round 2) vs gemm_p2 (plane activations)  (M, N, K) -> us, TFLOP/s fp32-equivalent")
+        from e2e_multi_view_matching_amd import _lib
+        ctx = _lib.context(dev)
+
+        def family(fn, slot, n=10):
+            for _ in range(2):
+                fn(1)
+            ctx.call("e2emv_profile", 1)
+            _lib.profile_read(ctx, reset=True)
+            fn(n)
+            pr = _lib.profile_read(ctx, reset=True)[slot]
+            ctx.call("e2emv_profile", 0)
+            return pr["ms"] / max(pr["launches"], 1)
+        for (M, N, K, K1) in [(65536, 768, 256, 256), (65536, 512, 512, 256), (65536, 256, 512, 512), (65536, 256, 256, 256)]:
+            A = torch.randn(M, K1, device=dev)
+            A2 = torch.randn(M, K - K1, device=dev) if K1 < K else None
+            W = torch.randn(N, K, device=dev) / K ** 0.5
+            Afull = torch.cat([A, A2], 1) if A2 is not None else A
+            ms_h2 = family(lambda n: [E.gemm_bf16x3(Afull, W, f16x2=True) for _ in range(n)], "gemm")
+            for planes_out in (False, True):
+                ms = family(lambda n: E.gemm_p2(A, W, A2=A2, planes_out=planes_out, reps=n), "gemm")
+                print(f"  {M:7d} {N:5d} {K:5d}  gemm_h2 {ms_h2 * 1e3:7.1f} us {2.0 * M * N * K / ms_h2 / 1e9:6.1f} TF | gemm_p2 "
+                      f"{'planes' if planes_out else 'fp32  '} out {ms * 1e3:7.1f} us {2.0 * M * N * K / ms / 1e9:6.1f} TF")
+        print("== f16x2 attention: attention_h2f (fp32 q|k|v) vs attention_p2 (plane operands)  -> us, TFLOP/s fp32-equivalent")
+        for (B, N) in [(32, 1024), (8, 2048)]:
+            qkv = torch.randn(B * 2, N, 768, device=dev)
+            fl = B * 2 * 4.0 * N * N * 256
+            for cross in (0, 1):
+                ms_h = family(lambda n: [E.attention_bf16x3(qkv, B, 2, N, 4, cross, kernel="f16x2") for _ in range(n)], "attention", 5)
+                line = f"  B={B:3d} N={N:5d} cross={cross}  h2f {ms_h * 1e3:7.1f} us {fl / ms_h / 1e9:6.1f} TF |"
+                for waves in (4, 8):
+                    ms = family(lambda n: E.attention_p2(qkv, B, 2, N, 4, cross, waves=waves, reps=n), "attention", 5)
+                    line += f" p2/{waves}w {ms * 1e3:7.1f} us {fl / ms / 1e9:6.1f} TF |"
+                print(line)
     if "attn" in args.what:
         print("== attention (B pairs, N) -> us, TFLOP/s")
         for (B, N) in [(32, 1024), (8, 1024), (32, 512), (8, 2048)]:
