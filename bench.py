@@ -175,7 +175,7 @@ class HipWorkload:
         self.ctx.set_precision(name)  # explicit override for every model on this device that does not pin its own
 
     def precision(self):
-        return {v: k for k, v in self._lib.PRECISION_NAMES.items()}[self.ctx.precision()]
+        return {v: k for k, v in self._lib.PRECISION_NAMES.items() if "-" not in k}[self.ctx.precision()]
 
     def step(self, model=None, data=None):
         E, torch = self.E, self.torch

@@ -10,7 +10,8 @@ import threading
 import torch  # noqa: F401  (imported first so libamdhip64.so.7 resolves to the runtime torch loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libe2emv.so")
+# E2EMV_LIBRARY: a measurement build of the same sources (tools/p2_stamps.py); the product is always libe2emv.so next to this file
+LIB_PATH = os.environ.get("E2EMV_LIBRARY") or os.path.join(_HERE, "libe2emv.so")
 
 MAX_TUPLE, MAX_LAYERS, MAX_KENC, PROF_SLOTS = 8, 64, 8, 16
 FLAG_FULL_OUTPUT, FLAG_MULTI_FRAME = 1, 2

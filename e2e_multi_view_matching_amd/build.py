@@ -25,18 +25,28 @@ def _stamp():
     return h.hexdigest()
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, defines=(), out=None):
+    """`defines` / `out`: a measurement build beside the product library (tools/p2_stamps.py builds libe2emv_stamps.so with
+    -DE2EMV_STAMPS: in-kernel timestamps and ablation variants that the product library does not contain)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if defines or out:
+        return _build(hipcc, os.path.join(HERE, "build_" + os.path.basename(out).split(".")[0]), out, ["-D" + d for d in defines], verbose)
     stamp_file = os.path.join(HERE, "csrc", ".build_stamp")
     stamp = _stamp()
     if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
         return LIB
-    objdir = os.path.join(HERE, "build")
+    _build(hipcc, os.path.join(HERE, "build"), LIB, [], verbose)
+    with open(stamp_file, "w") as fh:
+        fh.write(stamp)
+    return LIB
+
+
+def _build(hipcc, objdir, lib, extra, verbose):
     os.makedirs(objdir, exist_ok=True)
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     objs = []
     for src, obj, p in procs:
@@ -46,13 +56,11 @@ def build_library(force=False, verbose=False):
         if verbose and out.strip():
             print(out)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
-    with open(stamp_file, "w") as fh:
-        fh.write(stamp)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

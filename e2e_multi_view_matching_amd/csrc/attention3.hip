@@ -478,7 +478,7 @@ __device__ __forceinline__ H2Pair split2h_pair(float x0, float x1, float c) {
     asm("" : "+v"(v0), "+v"(v1));
     const f32x2 vv = {v0, v1};
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector(vv, f16x2));
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1"
         : "=&v"(lo) : "v"(hi), "v"(v0), "v"(v1));
     return {hi, lo};
 }

@@ -27,8 +27,7 @@ constexpr int P2_BM = 256, P2_BN = 256, P2_BK = 32;
 constexpr int P2_ROWB = 128;                    // bytes of one tile row per K step: 32 hi halves | 32 lo halves
 constexpr int P2_TILEB = P2_BM * P2_ROWB;       // 32 KB per operand tile
 constexpr int P2_BUFB = 2 * P2_TILEB;           // A tile | W tile
-constexpr int P2_SLAB_LD = 36;                  // floats per slab row (32 + 4: conflict-free b128 writes)
-constexpr int P2_SLABB = 32 * P2_SLAB_LD * 4;   // 4608 B per wave
+constexpr int P2_SLABB = 32 * 32 * 4;            // one epilogue slab: 32 rows x 32 floats; two per wave = the whole free buffer
 
 struct GemmP2Params {
     const uint16_t* A;
@@ -47,9 +46,13 @@ struct GemmP2Params {
     float out_scale;
     float col_scale[3];
     int n_rows, heads;
+    long long* dbg;  // E2EMV_STAMPS builds only: phase timestamps of two workgroups
 };
 
-template <int OUT>
+// DBG (instantiated only in -DE2EMV_STAMPS builds, tools/p2_stamps.py): 1 no MFMA, 2 no operand loads after the first two K
+// steps, 4 no epilogue, 8 s_memtime stamps per K step, 16 loads of step g + 1 issued one per MFMA group, 32 every wave issues
+// its loads before it computes (no opposite orders on a SIMD)
+template <int OUT, int DBG = 0>
 __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem_p2[];
 
@@ -87,29 +90,38 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
             w_vo[i] = gn * p.ldw_b + c * 16u;
         }
     };
-    auto issue = [&](int buf, int kt) {
+    // piece i of a K step: 0..3 activation rows, 4..7 weight rows
+    auto issue_piece = [&](int buf, int kt, int i, unsigned dep) {
+        char* dst = smem_p2 + buf * P2_BUFB + 32 * wave * P2_ROWB;
+        if (i < 4) {
+            if (kt < nk1) p2_glds16(rsA, dst + i * 1024, a_vo[i] + dep, (unsigned)kt * 128u);
+            else p2_glds16(rsA2, dst + i * 1024, a2_vo[i] + dep, (unsigned)(kt - nk1) * 128u);
+        } else {
+            p2_glds16(rsW, dst + P2_TILEB + (i - 4) * 1024, w_vo[i - 4] + dep, (unsigned)kt * 128u);
+        }
+    };
+    auto issue = [&](int buf, int kt, unsigned dep) {
         char* dst = smem_p2 + buf * P2_BUFB + 32 * wave * P2_ROWB;
         if (kt < nk1) {
             const unsigned so = (unsigned)kt * 128u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                p2_glds16(rsA, dst + i * 1024, a_vo[i], so);
+            for (int i = 0; i < 4; ++i) p2_glds16(rsA, dst + i * 1024, a_vo[i] + dep, so);
         } else {
             const unsigned so = (unsigned)(kt - nk1) * 128u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                p2_glds16(rsA2, dst + i * 1024, a2_vo[i], so);
+            for (int i = 0; i < 4; ++i) p2_glds16(rsA2, dst + i * 1024, a2_vo[i] + dep, so);
         }
         const unsigned sw = (unsigned)kt * 128u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            p2_glds16(rsW, dst + P2_TILEB + i * 1024, w_vo[i], sw);
+        for (int i = 0; i < 4; ++i) p2_glds16(rsW, dst + P2_TILEB + i * 1024, w_vo[i] + dep, sw);
     };
 
     // ---- fragments: lane (row l31, k half lh); chunk index c = 4 plane + 2 ks + lh, stored at position c ^ ((l31 >> 1) & 7)
     const int swz = (l31 >> 1) & 7;
     p2_f32x16 acc[4][2];
-    auto compute = [&](int buf, auto FIRST) {
+    // (`late`, DBG & 16 in measurement builds only: the loads of the next step go out one per MFMA group, each behind a
+    // scheduling-only dependency on that group's accumulator - an empty asm, no instruction)
+    auto compute = [&](int buf, auto FIRST, bool late, int ld_buf, int ld_k) {
         constexpr bool first_step = decltype(FIRST)::value;
         const char* xs = smem_p2 + buf * P2_BUFB + (wr * 64 + l31) * P2_ROWB;
         const char* ws = smem_p2 + buf * P2_BUFB + P2_TILEB + (wc * 128 + l31) * P2_ROWB;
@@ -129,6 +141,11 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                     w[pl] = *reinterpret_cast<const p2_f16x8*>(ws + j * 32 * P2_ROWB + (((4 * pl + 2 * ks + lh) ^ swz) << 4));
                 w[2] = w[0] * (_Float16)(1.f / 2048.f);  // 2^-11 w_hi (exact wherever it matters: gemm_h2.hip)
                 constexpr int PW[3] = {1, 2, 0}, PX[3] = {0, 1, 0};  // x_hi w_lo, x_lo' (2^-11 w_hi), x_hi w_hi: smallest first
+                if (DBG & 1) {  // operand pipeline only
+                    asm volatile("" :: "v"(x[0][0]), "v"(x[0][1]), "v"(x[1][0]), "v"(x[1][1]), "v"(w[0]), "v"(w[1]), "v"(w[2]));
+                    if ((DBG & 16) && late) issue_piece(ld_buf, ld_k, 4 * ks + j, 0u);
+                    continue;
+                }
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -140,31 +157,44 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[PW[q]], x[i][PX[q]], acc[j][i], 0, 0, 0);
                         }
                     }
+                if ((DBG & 16) && late) {
+                    unsigned dep = 0;
+                    asm("" : "+v"(dep) : "v"(acc[j][0]));
+                    issue_piece(ld_buf, ld_k, 4 * ks + j, dep);
+                }
             }
         }
     };
 
-    // ---- epilogue (see the header); fb = the tile buffer nobody reads or fills during it
+    // ---- epilogue (see the header); fb = the tile buffer nobody reads or fills during it.  Each wave owns two slabs of
+    // 32 rows x 32 floats in it (16-byte chunk c of row r at position c ^ (r & 7): conflict-free b128 writes, 2-way reads).
+    // The 8 blocks (32 rows x 32 columns) of a wave are software-pipelined: block b + 1 goes through its slab and its
+    // residual loads are issued while block b is finished (bias / ReLU / residual / split) and stored.
     auto epilogue = [&](int t, int fb) {
-        float* slab = reinterpret_cast<float*>(smem_p2 + fb * P2_BUFB + wave * P2_SLABB);
+        char* slab0 = smem_p2 + fb * P2_BUFB + wave * (2 * P2_SLABB);
         const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
         const int o_r = lane >> 2, o_c = (lane & 3) * 8;  // row-contiguous view: 16 rows per pass, 8 columns per lane
+        const int o_z = o_r & 7;
         const float cs = OUT == P2_OUT_QKV ? p.col_scale[min(tn, 2)] : 1.f;
+        auto slab_write = [&](char* sl, int i, int j) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int g = 0; g < 4; ++g) {
+                p2_f32x4 v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+                *reinterpret_cast<p2_f32x4*>(sl + l31 * 128 + (((2 * g + lh) ^ (l31 & 7)) << 4)) = v;
+            }
+        };
+        if (OUT == P2_OUT_QKV && tn == 2) {
+            // V^T: lane -> (dim d, 16-byte chunk q of the 32-key block) = 8 keys in accumulator order; not pipelined (a third of
+            // the q|k|v projection's tiles)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    p2_f32x4 v;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
-                    *reinterpret_cast<p2_f32x4*>(&slab[l31 * P2_SLAB_LD + 8 * g + 4 * lh]) = v;
-                }
-                const int m0 = tm * P2_BM + wr * 64 + i * 32;
-                const int n0 = tn * P2_BN + wc * 128 + j * 32;
-                if (OUT == P2_OUT_QKV && tn == 2) {
-                    // V^T: lane -> (dim d, 16-byte chunk q of the 32-key block) = 8 keys in accumulator order
+                for (int j = 0; j < 4; ++j) {
+                    slab_write(slab0, i, j);
+                    const int m0 = tm * P2_BM + wr * 64 + i * 32;
+                    const int n0 = tn * P2_BN + wc * 128 + j * 32;
 #pragma unroll
                     for (int pass = 0; pass < 2; ++pass) {
                         const int dl = (lane >> 2) + 16 * pass, q = lane & 3;
@@ -172,7 +202,10 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                         const int rb = 16 * (q >> 1) + 4 * (q & 1);
                         float v[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = slab[(rb + (e & 3) + 8 * (e >> 2)) * P2_SLAB_LD + dl];
+                        for (int e = 0; e < 8; ++e) {
+                            const int row = rb + (e & 3) + 8 * (e >> 2);
+                            v[e] = *reinterpret_cast<const float*>(slab0 + row * 128 + ((((dl >> 2) ^ (row & 7)) << 4) | ((dl & 3) << 2)));
+                        }
                         if (m0 >= p.M || n >= p.N) continue;
                         const float b = p.bias ? p.bias[n] : 0.f;
                         p2_u32x4 hi, lo;
@@ -187,67 +220,106 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                         *reinterpret_cast<p2_u32x4*>(dst) = hi;
                         *reinterpret_cast<p2_u32x4*>(dst + 32) = lo;
                     }
-                    continue;
                 }
-                const int n = n0 + o_c;
-                p2_f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias && n < p.N) b0 = *reinterpret_cast<const p2_f32x4*>(p.bias + n);
-                if (p.bias && n + 4 < p.N) b1 = *reinterpret_cast<const p2_f32x4*>(p.bias + n + 4);
+            return;
+        }
+        p2_f32x4 rv[2][2][2];   // [slab][pass][half]: the block in the row-contiguous view
+        p2_u32x4 rr[2][2][2];   // [slab][pass][plane]: its residual
+        auto stage = [&](auto BB) {  // block b -> slab b & 1 -> registers; residual loads issued
+            constexpr int b = decltype(BB)::value;
+            constexpr int i = b >> 2, j = b & 3;
+            char* sl = slab0 + (b & 1) * P2_SLABB;
+            slab_write(sl, i, j);
+            const int n = tn * P2_BN + wc * 128 + j * 32 + o_c;
 #pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-                    const int r = o_r + 16 * pass;
-                    const int m = m0 + r;
-                    p2_f32x4 v0 = *reinterpret_cast<const p2_f32x4*>(&slab[r * P2_SLAB_LD + o_c]);
-                    p2_f32x4 v1 = *reinterpret_cast<const p2_f32x4*>(&slab[r * P2_SLAB_LD + o_c + 4]);
-                    if (m >= p.M || n >= p.N) continue;
-                    v0 = v0 * p.out_scale + b0;
-                    v1 = v1 * p.out_scale + b1;
-                    if (p.relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v0[e] = relu_nan(v0[e]); v1[e] = relu_nan(v1[e]); }
-                    }
-                    if (p.Rp) {
-                        const uint16_t* rp = p.Rp + p2_index(m, n, p.ldr);
-                        const p2_u32x4 rh = *reinterpret_cast<const p2_u32x4*>(rp), rl = *reinterpret_cast<const p2_u32x4*>(rp + 32);
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const p2_f32x2 a = p2_join_scaled(rh[e], rl[e]), c = p2_join_scaled(rh[2 + e], rl[2 + e]);
-                            v0[2 * e] += a[0]; v0[2 * e + 1] += a[1];
-                            v1[2 * e] += c[0]; v1[2 * e + 1] += c[1];
-                        }
-                    }
-                    if (OUT == P2_OUT_F32) {
-                        float* cp = p.C32 + (int64_t)m * p.ldc + n;
-                        *reinterpret_cast<p2_f32x4*>(cp) = v0;
-                        if (n + 4 < p.N) *reinterpret_cast<p2_f32x4*>(cp + 4) = v1;
-                    } else {
-                        p2_u32x4 hi, lo;
-                        if (OUT == P2_OUT_QKV) {
-                            v0 *= cs; v1 *= cs;
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const P2Pair a = p2_split_plain(v0[2 * e], v0[2 * e + 1]), c = p2_split_plain(v1[2 * e], v1[2 * e + 1]);
-                                hi[e] = a.hi; lo[e] = a.lo; hi[2 + e] = c.hi; lo[2 + e] = c.lo;
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const P2Pair a = p2_split_scaled(v0[2 * e], v0[2 * e + 1]), c = p2_split_scaled(v1[2 * e], v1[2 * e + 1]);
-                                hi[e] = a.hi; lo[e] = a.lo; hi[2 + e] = c.hi; lo[2 + e] = c.lo;
-                            }
-                        }
-                        uint16_t* cp = p.Cp + p2_index(m, n, p.ldc);
-                        *reinterpret_cast<p2_u32x4*>(cp) = hi;
-                        *reinterpret_cast<p2_u32x4*>(cp + 32) = lo;
-                    }
+            for (int pass = 0; pass < 2; ++pass) {
+                const int r = o_r + 16 * pass;
+                const int c0 = 2 * (lane & 3);
+                rv[b & 1][pass][0] = *reinterpret_cast<const p2_f32x4*>(sl + r * 128 + ((c0 ^ o_z) << 4));
+                rv[b & 1][pass][1] = *reinterpret_cast<const p2_f32x4*>(sl + r * 128 + (((c0 + 1) ^ o_z) << 4));
+                if (OUT != P2_OUT_QKV && p.Rp) {
+                    const int m = min(tm * P2_BM + wr * 64 + i * 32 + r, p.M - 1);
+                    const uint16_t* rp = p.Rp + p2_index(m, min(n, p.N - 8), p.ldr);
+                    rr[b & 1][pass][0] = *reinterpret_cast<const p2_u32x4*>(rp);
+                    rr[b & 1][pass][1] = *reinterpret_cast<const p2_u32x4*>(rp + 32);
                 }
             }
+        };
+        auto finish = [&](auto BB) {
+            constexpr int b = decltype(BB)::value;
+            constexpr int i = b >> 2, j = b & 3;
+            const int m0 = tm * P2_BM + wr * 64 + i * 32;
+            const int n = tn * P2_BN + wc * 128 + j * 32 + o_c;
+            p2_f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) b0 = *reinterpret_cast<const p2_f32x4*>(p.bias + n);
+            if (p.bias && n + 4 < p.N) b1 = *reinterpret_cast<const p2_f32x4*>(p.bias + n + 4);
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int m = m0 + o_r + 16 * pass;
+                if (m >= p.M || n >= p.N) continue;
+                p2_f32x4 v0 = rv[b & 1][pass][0] * p.out_scale + b0;
+                p2_f32x4 v1 = rv[b & 1][pass][1] * p.out_scale + b1;
+                if (OUT != P2_OUT_QKV && p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = relu_nan(v0[e]); v1[e] = relu_nan(v1[e]); }
+                }
+                if (OUT != P2_OUT_QKV && p.Rp) {
+                    const p2_u32x4 rh = rr[b & 1][pass][0], rl = rr[b & 1][pass][1];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const p2_f32x2 a = p2_join_scaled(rh[e], rl[e]), c = p2_join_scaled(rh[2 + e], rl[2 + e]);
+                        v0[2 * e] += a[0]; v0[2 * e + 1] += a[1];
+                        v1[2 * e] += c[0]; v1[2 * e + 1] += c[1];
+                    }
+                }
+                if (OUT == P2_OUT_F32) {
+                    float* cp = p.C32 + (int64_t)m * p.ldc + n;
+                    *reinterpret_cast<p2_f32x4*>(cp) = v0;
+                    if (n + 4 < p.N) *reinterpret_cast<p2_f32x4*>(cp + 4) = v1;
+                } else {
+                    p2_u32x4 hi, lo;
+                    if (OUT == P2_OUT_QKV) {
+                        v0 *= cs; v1 *= cs;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const P2Pair a = p2_split_plain(v0[2 * e], v0[2 * e + 1]), c = p2_split_plain(v1[2 * e], v1[2 * e + 1]);
+                            hi[e] = a.hi; lo[e] = a.lo; hi[2 + e] = c.hi; lo[2 + e] = c.lo;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const P2Pair a = p2_split_scaled(v0[2 * e], v0[2 * e + 1]), c = p2_split_scaled(v1[2 * e], v1[2 * e + 1]);
+                            hi[e] = a.hi; lo[e] = a.lo; hi[2 + e] = c.hi; lo[2 + e] = c.lo;
+                        }
+                    }
+                    uint16_t* cp = p.Cp + p2_index(m, n, p.ldc);
+                    if (DBG & 64) { asm volatile("" :: "v"(hi), "v"(lo), "v"(cp)); continue; }          // measurement: no stores
+                    if (DBG & 128) cp = p.Cp + (p2_index(m, n, p.ldc) & ((1 << 19) - 1) & ~63ll);         // measurement: 1 MB target
+                    *reinterpret_cast<p2_u32x4*>(cp) = hi;
+                    *reinterpret_cast<p2_u32x4*>(cp + 32) = lo;
+                }
+            }
+        };
+#define P2_BLK(b) std::integral_constant<int, b>{}
+        stage(P2_BLK(0));
+        stage(P2_BLK(1)); finish(P2_BLK(0));
+        stage(P2_BLK(2)); finish(P2_BLK(1));
+        stage(P2_BLK(3)); finish(P2_BLK(2));
+        stage(P2_BLK(4)); finish(P2_BLK(3));
+        stage(P2_BLK(5)); finish(P2_BLK(4));
+        stage(P2_BLK(6)); finish(P2_BLK(5));
+        stage(P2_BLK(7)); finish(P2_BLK(6));
+        finish(P2_BLK(7));
+#undef P2_BLK
     };
 
     // ---- pipeline.  Step g = (tile, kt) in execution order lives in LDS buffer g & 1.  Every step opens with "my loads of
-    // this step have landed" (vmcnt(0): they were issued a whole step ago) + ONE barrier (everybody's have; everybody is
-    // done reading the other buffer), then issues the loads of step g + 1 into the other buffer and computes.  The load
-    // position runs one step ahead of the compute position across output tiles.
+    // this step have landed" (vmcnt(0): they were issued most of a step ago) + ONE barrier (everybody's have; everybody is
+    // done reading the other buffer); the loads of step g + 1 then go into the other buffer.  The two waves that share a
+    // SIMD (w and w + 4) take OPPOSITE orders: waves 4-7 issue their 8 loads first and compute after, waves 0-3 compute
+    // first and issue after - one keeps the matrix pipe busy while the other sits in the ~700-1000 cycles it takes to get
+    // 8 LDS-direct loads out (measured, s_memtime stamps: with both waves issuing first the pipe idled for that long in
+    // every step).  The load position runs one step ahead of the compute position across output tiles.
     int ld_tile = tile, ld_kt = 0;
     bool ld_valid = true;
     auto advance = [&]() {
@@ -261,24 +333,58 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         }
     };
     setup(tile);
-    issue(0, 0);
+    issue(0, 0, 0u);
     advance();
-    int buf = 0;
+    const bool issue_first = (DBG & 32) ? true : wave >= 4;
+    int buf = 0, dbg_n = 0, dbg_steps = 0;
+    if (DBG & 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    }
     auto step = [&](auto FIRST) {
+        long long t0 = 0, t1 = 0, t2 = 0;
+        if (DBG & 8) t0 = clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (ld_valid) {
-            issue(buf ^ 1, ld_kt);
-            advance();
+        if (DBG & 8) t1 = clock64();
+        const bool ldv = ld_valid && !((DBG & 2) && dbg_steps >= 1);
+        ++dbg_steps;
+        if (!(DBG & 16) && issue_first && ldv) issue(buf ^ 1, ld_kt, 0u);
+        if (DBG & 8) t2 = clock64();
+        compute(buf, FIRST, (DBG & 16) && ldv, buf ^ 1, ld_kt);  // ONE call site: two would double the accumulator live ranges
+        if (!(DBG & 16) && !issue_first && ldv) {
+            unsigned dep = 0;
+            if (!(DBG & 1)) asm("" : "+v"(dep) : "v"(acc[3][1]));  // scheduling-only: keeps the loads behind the MFMAs
+            issue(buf ^ 1, ld_kt, dep);
         }
-        compute(buf, FIRST);
+        if (ldv) advance();
+        if (DBG & 8) {
+            const long long t3 = clock64();
+            if (p.dbg && lane == 0 && dbg_n < 48 && (blockIdx.x == 0 || blockIdx.x == 101)) {
+                long long* o = p.dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 50 * 4 + dbg_n * 4;
+                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+                ++dbg_n;
+            }
+        }
         buf ^= 1;
     };
     for (;;) {
         step(std::true_type{});
         for (int kt = 1; kt < nk; ++kt) step(std::false_type{});
+        long long e0 = 0;
+        if (DBG & 8) e0 = clock64();
         __syncthreads();  // every wave is done with the buffer of the last step: it carries the slabs now
-        epilogue(tile, buf ^ 1);
+        if (!(DBG & 4)) epilogue(tile, buf ^ 1);
+        else asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));
+        if ((DBG & 8) && p.dbg && lane == 0 && dbg_n < 48 && (blockIdx.x == 0 || blockIdx.x == 101)) {
+            long long* o = p.dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 50 * 4 + dbg_n * 4;
+            o[0] = -1; o[1] = e0; o[2] = clock64(); o[3] = 0;
+            ++dbg_n;
+        }
         tile += slots;
         if (tile >= t_end) break;
     }
@@ -334,10 +440,62 @@ int launch_gemm_p2(e2emv_ctx* ctx, const GemmP2Args& a, hipStream_t s) {
     const int per_xcd = (p.total + 7) / 8;
     const int sl = std::min(per_xcd, std::max(1, ctx->num_cus / 8));
     const size_t lds = 2 * P2_BUFB;
+    p.dbg = nullptr;
+#ifdef E2EMV_STAMPS
+    // measurement build only (tools/p2_stamps.py): E2EMV_P2_DBG selects an ablation / the stamped variant of the planes kernel
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("E2EMV_P2_DBG"); dbg = e ? atoi(e) : 0; }
+    static long long* d_buf = nullptr;
+    const size_t nb = sizeof(long long) * 2 * 8 * 50 * 4;
+    if (dbg && a.out == P2_OUT_PLANES) {
+        switch (dbg) {
+            case 1: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 1>); break;
+            case 2: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 2>); break;
+            case 3: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 3>); break;
+            case 4: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 4>); break;
+            case 6: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 6>); break;
+            case 8: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 8>); break;
+            case 16: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 16>); break;
+            case 17: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 17>); break;
+            case 24: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 24>); break;
+            case 32: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 32>); break;
+            case 64: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 64>); break;
+            case 128: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 128>); break;
+            case 36: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 36>); break;
+            case 40: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 40>); break;
+            default: break;
+        }
+        if (dbg & 8) {
+            if (!d_buf) E2EMV_HIP(ctx, hipMalloc((void**)&d_buf, nb));
+            E2EMV_HIP(ctx, hipMemsetAsync(d_buf, 0, nb, s));
+            p.dbg = d_buf;
+        }
+    }
+#endif
     if (int rc = ensure_dynamic_lds(ctx, fn, lds)) return rc;
     void* args[] = {&p};
     E2EMV_HIP(ctx, hipLaunchKernel(fn, dim3(8 * sl), dim3(512), args, lds, s));
     E2EMV_CHECK_LAUNCH(ctx, "gemm_p2_kernel");
+#ifdef E2EMV_STAMPS
+    if (p.dbg) {
+        E2EMV_HIP(ctx, hipStreamSynchronize(s));
+        std::vector<long long> h(2 * 8 * 50 * 4);
+        E2EMV_HIP(ctx, hipMemcpy(h.data(), d_buf, nb, hipMemcpyDeviceToHost));
+        static int printed = 0;
+        if (printed++ < 1)
+            for (int wg = 0; wg < 2; ++wg)
+                for (int w = 0; w < 8; w += 5) {
+                    const long long* o = &h[((size_t)wg * 8 + w) * 50 * 4];
+                    fprintf(stderr, "gemm_p2 M=%d N=%d K=%d wg %d wave %d: per K step wait+barrier | issue | compute | total   (epilogue rows: -1)\n", p.M, p.N, p.K, wg ? 101 : 0, w);
+                    for (int i = 0; i < 44; ++i) {
+                        const long long* t = o + i * 4;
+                        if (!t[0]) break;
+                        if (t[0] == -1) { fprintf(stderr, "  %2d: epilogue %lld\n", i, t[2] - t[1]); continue; }
+                        fprintf(stderr, "  %2d: %5lld %5lld %5lld | %5lld\n", i, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[3] - t[0]);
+                    }
+                }
+    }
+#endif
     return E2EMV_OK;
 }
 

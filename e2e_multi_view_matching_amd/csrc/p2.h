@@ -39,7 +39,7 @@ __device__ __forceinline__ P2Pair p2_split_scaled(float v0, float v1) {
     const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(vv, p2_f16x2));
     const float s0 = v0 * 2048.f, s1 = v1 * 2048.f;
     unsigned lo;
-    asm("v_fma_mixlo_f16 %0, %1, %4, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %4, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+    asm("v_fma_mixlo_f16 %0, %1, %4, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %4, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1"
         : "=&v"(lo) : "v"(hi), "v"(s0), "v"(s1), "s"(-2048.f));
     return {hi, lo};
 }
@@ -50,7 +50,7 @@ __device__ __forceinline__ P2Pair p2_split_plain(float v0, float v1) {
     const p2_f32x2 vv = {v0, v1};
     const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(vv, p2_f16x2));
     unsigned lo;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1"
         : "=&v"(lo) : "v"(hi), "v"(v0), "v"(v1));
     return {hi, lo};
 }

@@ -31,8 +31,10 @@ def test_gemm_p2_has_fp32_class_accuracy(gpu, M, N, K, act_scale):
     out = E.gemm_p2(A.to(gpu), W.to(gpu), bias=b.to(gpu)).cpu()
     out32 = E.gemm_nt(A.to(gpu), W.to(gpu), bias=b.to(gpu)).cpu()
     e, e32 = _err(out, ref, scale), _err(out32, ref, scale)
-    assert e < 5e-7, (e, e32)
-    assert e < 4 * e32 + 2e-7, (e, e32)
+    # rows of typical magnitude below 6e-5 (act_scale 1e-3 x e^-4) sit under the range where the low plane is a normal fp16
+    # number: the representation degrades gracefully to an ABSOLUTE 2^-36 there (the same in gemm_h2)
+    assert e < (1e-6 if act_scale < 1e-2 else 5e-7), (e, e32)
+    assert e < 4 * e32 + (6e-7 if act_scale < 1e-2 else 2e-7), (e, e32)
     outr = E.gemm_p2(A.to(gpu), W.to(gpu), bias=b.to(gpu), relu=True).cpu()
     assert torch.equal(outr, out.clamp_min(0))
 
@@ -141,3 +143,24 @@ def test_attention_p2_over_operand_magnitudes(gpu, qs, ks, vs):
     err = float((out.double() - ref).abs().max()) / vs
     err32 = float((out32.double() - ref).abs().max()) / vs
     assert err < 3 * err32 + 2e-6, (err, err32)
+
+
+@pytest.mark.parametrize("kernel", ["p2", "f16x2"])
+def test_attention_constant_v_exposes_operand_hazards(gpu, kernel):
+    """V == 1 makes every output element exactly sum(p) / sum(p) = 1, whatever the keys: the two 32-dim halves of a head
+    go through separate MFMA chains fed from the SAME softmax-numerator registers, so any difference between them is an
+    operand hazard, not arithmetic.  Found in round 3: the inline-asm v_fma_mix pair that makes the low plane of P was
+    followed within one wait state by the first MFMA reading it (hipcc does not pad hazards of an asm's outputs): dims
+    0-31 of every head were off by 2^-11 of P's low plane as soon as a tile had more than 32 keys, dims 32-63 were exact."""
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(5)
+    for n_valid in (33, 64, 128, 200):
+        n_rows = 128 if n_valid <= 128 else 256
+        qkv = torch.randn(2, n_rows, 768, generator=g) * 1.5
+        qkv[..., 512:] = 1.0
+        if kernel == "p2":
+            out = E.attention_p2(qkv.to(gpu), 1, 2, n_valid, 4, 0).cpu()
+        else:
+            out = E.attention_bf16x3(qkv.to(gpu), 1, 2, n_valid, 4, 0, kernel="f16x2").cpu()
+        err = (out[:, :n_valid] - 1.0).abs().view(2, n_valid, 4, 64)
+        assert float(err[..., :32].max()) < 2e-6 and float(err[..., 32:].max()) < 2e-6, (n_valid, float(err[..., :32].max()), float(err[..., 32:].max()))

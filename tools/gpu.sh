@@ -31,6 +31,14 @@ planes)
   E2EMV_F16X2_KERNELS=r2 timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_r2k.json 2> $OUT/bench_r2k.err
   show $OUT/bench_p2.json $OUT/bench_r2k.json
   ;;
+stamps)
+  timeout 900 python tools/p2_stamps.py 2>&1 | tee $OUT/p2_stamps.log
+  ;;
+ab)
+  timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_p2.json 2> $OUT/bench_p2.err
+  E2EMV_F16X2_KERNELS=r2 timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_r2k.json 2> $OUT/bench_r2k.err
+  show $OUT/bench_p2.json $OUT/bench_r2k.json
+  ;;
 tests)
   timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/tests.log
   ;;
