@@ -120,6 +120,7 @@ struct e2emv_ctx {
     size_t attn_part_bytes = 0;
     // device flags: [0] give-up flag of the running resident Sinkhorn launch, [1] sticky count of give-ups
     unsigned* d_flags = nullptr;
+    char* d_dummy = nullptr;  // 4 KB scratch line: target of masked-out stores of kernels that must issue a fixed number of stores (gemm_p2.hip)
     // workspace arena
     char* d_ws = nullptr;
     size_t ws_bytes = 0;

@@ -181,6 +181,7 @@ void e2emv_destroy(e2emv_ctx* ctx) {
     if (ctx->d_sparena) (void)hipFree(ctx->d_sparena);
     if (ctx->d_attn_part) (void)hipFree(ctx->d_attn_part);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->d_dummy) (void)hipFree(ctx->d_dummy);
     for (auto& pe : ctx->prof_events) (void)hipEventDestroy(pe.ev);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     delete ctx;

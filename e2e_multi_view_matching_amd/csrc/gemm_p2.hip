@@ -27,7 +27,8 @@ constexpr int P2_BM = 256, P2_BN = 256, P2_BK = 32;
 constexpr int P2_ROWB = 128;                    // bytes of one tile row per K step: 32 hi halves | 32 lo halves
 constexpr int P2_TILEB = P2_BM * P2_ROWB;       // 32 KB per operand tile
 constexpr int P2_BUFB = 2 * P2_TILEB;           // A tile | W tile
-constexpr int P2_SLABB = 32 * 32 * 4;            // one epilogue slab: 32 rows x 32 floats; two per wave = the whole free buffer
+constexpr int P2_SLABB = 32 * 32 * 4;            // one epilogue slab per wave (32 rows x 32 floats), behind the tile buffers
+constexpr int P2_LDSB = 2 * P2_BUFB + 8 * P2_SLABB;  // 160 KB: the whole LDS of a CU
 
 struct GemmP2Params {
     const uint16_t* A;
@@ -46,13 +47,14 @@ struct GemmP2Params {
     float out_scale;
     float col_scale[3];
     int n_rows, heads;
+    char* dummy;     // 4 KB: target of the stores of rows / columns beyond the matrix (a wave always issues all its stores)
     long long* dbg;  // E2EMV_STAMPS builds only: phase timestamps of two workgroups
 };
 
 // DBG (instantiated only in -DE2EMV_STAMPS builds, tools/p2_stamps.py): 1 no MFMA, 2 no operand loads after the first two K
 // steps, 4 no epilogue, 8 s_memtime stamps per K step, 16 loads of step g + 1 issued one per MFMA group, 32 every wave issues
-// its loads before it computes (no opposite orders on a SIMD)
-template <int OUT, int DBG = 0>
+// its loads before it computes (no opposite orders on a SIMD), 256 vmcnt(0) at every step (no store overlap)
+template <int OUT, bool HAS_R = false, int DBG = 0>
 __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem_p2[];
 
@@ -166,17 +168,24 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         }
     };
 
-    // ---- epilogue (see the header); fb = the tile buffer nobody reads or fills during it.  Each wave owns two slabs of
-    // 32 rows x 32 floats in it (16-byte chunk c of row r at position c ^ (r & 7): conflict-free b128 writes, 2-way reads).
-    // The 8 blocks (32 rows x 32 columns) of a wave are software-pipelined: block b + 1 goes through its slab and its
-    // residual loads are issued while block b is finished (bias / ReLU / residual / split) and stored.
-    auto epilogue = [&](int t, int fb) {
-        char* slab0 = smem_p2 + fb * P2_BUFB + wave * (2 * P2_SLABB);
+    // ---- epilogue (see the header).  Each wave owns ONE slab of 32 rows x 32 floats behind the two tile buffers (16-byte
+    // chunk c of row r at position c ^ (r & 7): conflict-free b128 writes, 2-way reads).  The 8 blocks (32 rows x 32
+    // columns) of a wave are software-pipelined through registers: block b + 1 goes through the slab and its residual
+    // loads are issued while block b is finished (bias / ReLU / residual / split) and stored.  Two rules keep the store
+    // stream asynchronous (gfx950 retires loads AND stores in issue order on one counter, vmcnt):
+    //   * no load is issued behind a store whose completion we do not want to wait for: the bias is fetched once, up
+    //     front, and the residual of block b + 1 before the stores of block b;
+    //   * every wave issues EXACTLY 32 store instructions per tile (rows / columns beyond the matrix go to a dummy line
+    //     instead of being skipped), so the K loop of the next tile can wait with a COUNTED vmcnt for its operand loads,
+    //     which were issued before these stores, and leave the stores in flight (see the pipeline below).
+    auto epilogue = [&](int t) {
+        char* sl = smem_p2 + 2 * P2_BUFB + wave * P2_SLABB;
         const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
         const int o_r = lane >> 2, o_c = (lane & 3) * 8;  // row-contiguous view: 16 rows per pass, 8 columns per lane
         const int o_z = o_r & 7;
         const float cs = OUT == P2_OUT_QKV ? p.col_scale[min(tn, 2)] : 1.f;
-        auto slab_write = [&](char* sl, int i, int j) {
+        char* dummy = p.dummy + lane * 64;
+        auto slab_write = [&](int i, int j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 p2_f32x4 v;
@@ -186,13 +195,12 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
             }
         };
         if (OUT == P2_OUT_QKV && tn == 2) {
-            // V^T: lane -> (dim d, 16-byte chunk q of the 32-key block) = 8 keys in accumulator order; not pipelined (a third of
-            // the q|k|v projection's tiles)
+            // V^T: lane -> (dim d, 16-byte chunk q of the 32-key block) = 8 keys in accumulator order
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    slab_write(slab0, i, j);
+                    slab_write(i, j);
                     const int m0 = tm * P2_BM + wr * 64 + i * 32;
                     const int n0 = tn * P2_BN + wc * 128 + j * 32;
 #pragma unroll
@@ -204,10 +212,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const int row = rb + (e & 3) + 8 * (e >> 2);
-                            v[e] = *reinterpret_cast<const float*>(slab0 + row * 128 + ((((dl >> 2) ^ (row & 7)) << 4) | ((dl & 3) << 2)));
+                            v[e] = *reinterpret_cast<const float*>(sl + row * 128 + ((((dl >> 2) ^ (row & 7)) << 4) | ((dl & 3) << 2)));
                         }
-                        if (m0 >= p.M || n >= p.N) continue;
-                        const float b = p.bias ? p.bias[n] : 0.f;
+                        const float b = (p.bias && n < p.N) ? p.bias[n] : 0.f;
                         p2_u32x4 hi, lo;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -217,27 +224,42 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                         const int img = m0 / p.n_rows, key0 = m0 - img * p.n_rows;
                         const int nv = n - 2 * P2_BN, head = nv >> 6, dd = nv & 63;
                         uint16_t* dst = p.Vt + ((int64_t)(img * p.heads + head) * 64 + dd) * (2 * (int64_t)p.n_rows) + (key0 >> 5) * 64 + q * 8;
+                        if (m0 >= p.M || n >= p.N) dst = reinterpret_cast<uint16_t*>(dummy);
                         *reinterpret_cast<p2_u32x4*>(dst) = hi;
                         *reinterpret_cast<p2_u32x4*>(dst + 32) = lo;
                     }
                 }
             return;
         }
-        p2_f32x4 rv[2][2][2];   // [slab][pass][half]: the block in the row-contiguous view
-        p2_u32x4 rr[2][2][2];   // [slab][pass][plane]: its residual
-        auto stage = [&](auto BB) {  // block b -> slab b & 1 -> registers; residual loads issued
+        // bias: without a residual the epilogue issues NO load behind its first store (all four column blocks up front, 32
+        // registers); with one, the bias of block b + 1 travels with its residual loads (the registers go to the residual)
+        constexpr int NB = HAS_R ? 2 : 4;
+        p2_f32x4 bias8[NB][2];
+        auto load_bias = [&](int slot, int j) {
+            const int n = tn * P2_BN + wc * 128 + j * 32 + o_c;
+            bias8[slot][0] = bias8[slot][1] = p2_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) bias8[slot][0] = *reinterpret_cast<const p2_f32x4*>(p.bias + n);
+            if (p.bias && n + 4 < p.N) bias8[slot][1] = *reinterpret_cast<const p2_f32x4*>(p.bias + n + 4);
+        };
+        if (!HAS_R) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_bias(j, j);
+        }
+        p2_f32x4 rv[2][2][2];              // [parity][pass][half]: the block in the row-contiguous view
+        p2_u32x4 rr[HAS_R ? 2 : 1][2][2];  // [parity][pass][plane]: its residual
+        auto stage = [&](auto BB) {  // block b -> slab -> registers; residual loads issued
             constexpr int b = decltype(BB)::value;
             constexpr int i = b >> 2, j = b & 3;
-            char* sl = slab0 + (b & 1) * P2_SLABB;
-            slab_write(sl, i, j);
+            slab_write(i, j);
             const int n = tn * P2_BN + wc * 128 + j * 32 + o_c;
+            if (HAS_R) load_bias(b & 1, j);
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 const int r = o_r + 16 * pass;
                 const int c0 = 2 * (lane & 3);
                 rv[b & 1][pass][0] = *reinterpret_cast<const p2_f32x4*>(sl + r * 128 + ((c0 ^ o_z) << 4));
                 rv[b & 1][pass][1] = *reinterpret_cast<const p2_f32x4*>(sl + r * 128 + (((c0 + 1) ^ o_z) << 4));
-                if (OUT != P2_OUT_QKV && p.Rp) {
+                if (HAS_R) {
                     const int m = min(tm * P2_BM + wr * 64 + i * 32 + r, p.M - 1);
                     const uint16_t* rp = p.Rp + p2_index(m, min(n, p.N - 8), p.ldr);
                     rr[b & 1][pass][0] = *reinterpret_cast<const p2_u32x4*>(rp);
@@ -250,20 +272,17 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
             constexpr int i = b >> 2, j = b & 3;
             const int m0 = tm * P2_BM + wr * 64 + i * 32;
             const int n = tn * P2_BN + wc * 128 + j * 32 + o_c;
-            p2_f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && n < p.N) b0 = *reinterpret_cast<const p2_f32x4*>(p.bias + n);
-            if (p.bias && n + 4 < p.N) b1 = *reinterpret_cast<const p2_f32x4*>(p.bias + n + 4);
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 const int m = m0 + o_r + 16 * pass;
-                if (m >= p.M || n >= p.N) continue;
-                p2_f32x4 v0 = rv[b & 1][pass][0] * p.out_scale + b0;
-                p2_f32x4 v1 = rv[b & 1][pass][1] * p.out_scale + b1;
+                const bool ok = m < p.M && n < p.N;
+                p2_f32x4 v0 = rv[b & 1][pass][0] * p.out_scale + bias8[HAS_R ? (b & 1) : j][0];
+                p2_f32x4 v1 = rv[b & 1][pass][1] * p.out_scale + bias8[HAS_R ? (b & 1) : j][1];
                 if (OUT != P2_OUT_QKV && p.relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v0[e] = relu_nan(v0[e]); v1[e] = relu_nan(v1[e]); }
                 }
-                if (OUT != P2_OUT_QKV && p.Rp) {
+                if (HAS_R) {
                     const p2_u32x4 rh = rr[b & 1][pass][0], rl = rr[b & 1][pass][1];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
@@ -273,9 +292,10 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                     }
                 }
                 if (OUT == P2_OUT_F32) {
-                    float* cp = p.C32 + (int64_t)m * p.ldc + n;
+                    float* cp = ok ? p.C32 + (int64_t)m * p.ldc + n : reinterpret_cast<float*>(dummy);
+                    float* cq = (ok && n + 4 < p.N) ? cp + 4 : reinterpret_cast<float*>(dummy + 16);
                     *reinterpret_cast<p2_f32x4*>(cp) = v0;
-                    if (n + 4 < p.N) *reinterpret_cast<p2_f32x4*>(cp + 4) = v1;
+                    *reinterpret_cast<p2_f32x4*>(cq) = v1;
                 } else {
                     p2_u32x4 hi, lo;
                     if (OUT == P2_OUT_QKV) {
@@ -292,7 +312,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                             hi[e] = a.hi; lo[e] = a.lo; hi[2 + e] = c.hi; lo[2 + e] = c.lo;
                         }
                     }
-                    uint16_t* cp = p.Cp + p2_index(m, n, p.ldc);
+                    uint16_t* cp = ok ? p.Cp + p2_index(m, n, p.ldc) : reinterpret_cast<uint16_t*>(dummy);
                     if (DBG & 64) { asm volatile("" :: "v"(hi), "v"(lo), "v"(cp)); continue; }          // measurement: no stores
                     if (DBG & 128) cp = p.Cp + (p2_index(m, n, p.ldc) & ((1 << 19) - 1) & ~63ll);         // measurement: 1 MB target
                     *reinterpret_cast<p2_u32x4*>(cp) = hi;
@@ -313,13 +333,17 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
 #undef P2_BLK
     };
 
-    // ---- pipeline.  Step g = (tile, kt) in execution order lives in LDS buffer g & 1.  Every step opens with "my loads of
-    // this step have landed" (vmcnt(0): they were issued most of a step ago) + ONE barrier (everybody's have; everybody is
-    // done reading the other buffer); the loads of step g + 1 then go into the other buffer.  The two waves that share a
-    // SIMD (w and w + 4) take OPPOSITE orders: waves 4-7 issue their 8 loads first and compute after, waves 0-3 compute
-    // first and issue after - one keeps the matrix pipe busy while the other sits in the ~700-1000 cycles it takes to get
-    // 8 LDS-direct loads out (measured, s_memtime stamps: with both waves issuing first the pipe idled for that long in
-    // every step).  The load position runs one step ahead of the compute position across output tiles.
+    // ---- pipeline.  Step g = (tile, kt) in execution order lives in LDS buffer g & 1.  A step opens with "my loads of this
+    // step have landed" + ONE barrier (everybody's have; everybody is done reading the other buffer); the loads of step
+    // g + 1 then go into the other buffer.  The two waves that share a SIMD (w and w + 4) take OPPOSITE orders: waves 4-7
+    // issue their 8 loads first and compute after, waves 0-3 compute first and issue after (s_memtime stamps: with both
+    // issuing first the matrix pipe idled ~700-1000 cycles per step).
+    // Across an epilogue the load position runs TWO steps ahead: the loads of step L + 1 went out during the tile's last
+    // step L as always, those of step L + 2 go out right after it (its buffer is free: the slabs live behind the tile
+    // buffers) - both BEFORE the 32 stores of the epilogue.  vmcnt retires in issue order, so step L + 1 waits with
+    // vmcnt(40) (8 loads of L + 2 and 32 stores may stay in flight) and step L + 2 with vmcnt(32): the store burst of the
+    // epilogue - every CU of the chip reaches it at the same time - drains under two K steps of the next tile instead of
+    // in front of them.  Barriers are raw s_barrier: __syncthreads() would add vmcnt(0) while LDS-direct loads are in flight.
     int ld_tile = tile, ld_kt = 0;
     bool ld_valid = true;
     auto advance = [&]() {
@@ -336,6 +360,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
     issue(0, 0, 0u);
     advance();
     const bool issue_first = (DBG & 32) ? true : wave >= 4;
+    const bool overlap = nk >= 3 && !(DBG & (256 | 64 | 4 | 2));
+    int since = 8;       // K steps since the last epilogue
+    bool ahead = false;  // the loads of the step after next were issued before that epilogue
     int buf = 0, dbg_n = 0, dbg_steps = 0;
     if (DBG & 1) {
 #pragma unroll
@@ -348,10 +375,12 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
     auto step = [&](auto FIRST) {
         long long t0 = 0, t1 = 0, t2 = 0;
         if (DBG & 8) t0 = clock64();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (since == 0 && ahead) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+        else if (since <= 1 && overlap) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");  // (since == 0 without `ahead`: 8 loads, then the stores)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (DBG & 8) t1 = clock64();
-        const bool ldv = ld_valid && !((DBG & 2) && dbg_steps >= 1);
+        const bool ldv = ld_valid && !(since == 0 && ahead) && !((DBG & 2) && dbg_steps >= 1);
         ++dbg_steps;
         if (!(DBG & 16) && issue_first && ldv) issue(buf ^ 1, ld_kt, 0u);
         if (DBG & 8) t2 = clock64();
@@ -362,6 +391,8 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
             issue(buf ^ 1, ld_kt, dep);
         }
         if (ldv) advance();
+        if (since == 0) ahead = false;
+        ++since;
         if (DBG & 8) {
             const long long t3 = clock64();
             if (p.dbg && lane == 0 && dbg_n < 48 && (blockIdx.x == 0 || blockIdx.x == 101)) {
@@ -377,9 +408,18 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         for (int kt = 1; kt < nk; ++kt) step(std::false_type{});
         long long e0 = 0;
         if (DBG & 8) e0 = clock64();
-        __syncthreads();  // every wave is done with the buffer of the last step: it carries the slabs now
-        if (!(DBG & 4)) epilogue(tile, buf ^ 1);
+        if (overlap && ld_valid && !(DBG & 2)) {
+            // the buffer of the step just computed is free once every wave is through it: the loads of the step after next
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            unsigned dep = 0;
+            if (!(DBG & 1)) asm("" : "+v"(dep) : "v"(acc[3][1]));
+            issue(buf ^ 1, ld_kt, dep);
+            advance();
+            ahead = true;
+        }
+        if (!(DBG & 4)) epilogue(tile);
         else asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));
+        since = overlap ? 0 : 8;
         if ((DBG & 8) && p.dbg && lane == 0 && dbg_n < 48 && (blockIdx.x == 0 || blockIdx.x == 101)) {
             long long* o = p.dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 50 * 4 + dbg_n * 4;
             o[0] = -1; o[1] = e0; o[2] = clock64(); o[3] = 0;
@@ -420,11 +460,11 @@ int launch_gemm_p2(e2emv_ctx* ctx, const GemmP2Args& a, hipStream_t s) {
     switch (a.out) {
         case P2_OUT_F32:
             if (!a.C32 || a.N % 4 || a.ldc % 4 || (uintptr_t)a.C32 % 16) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: fp32 output needs N %% 4 == 0, ldc %% 4 == 0");
-            fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_F32>);
+            fn = a.Rp ? reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_F32, true>) : reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_F32, false>);
             break;
         case P2_OUT_PLANES:
             if (!a.Cp || a.N % 8 || a.ldc % 32 || a.ldc < a.N || (uintptr_t)a.Cp % 16) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: plane output needs N %% 8 == 0, ldc %% 32 == 0");
-            fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES>);
+            fn = a.Rp ? reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, true>) : reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false>);
             break;
         case P2_OUT_QKV:
             if (!a.Cp || !a.Vt || a.N != 3 * P2_BN || a.heads != 4 || a.n_rows <= 0 || a.n_rows % 32 || a.M % a.n_rows || a.relu || a.Rp ||
@@ -433,36 +473,39 @@ int launch_gemm_p2(e2emv_ctx* ctx, const GemmP2Args& a, hipStream_t s) {
             p.ldc = 2 * P2_BN;
             p.col_scale[0] = 0.125f * 1.4426950408889634f * P2_QS;  // log2(e) / sqrt(64), then the plane pre-scale
             p.col_scale[2] = P2_VS;
-            fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_QKV>);
+            fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_QKV, false>);
             break;
         default: return set_err(ctx, E2EMV_EINVAL, "gemm_p2: unknown output kind %d", a.out);
     }
     const int per_xcd = (p.total + 7) / 8;
     const int sl = std::min(per_xcd, std::max(1, ctx->num_cus / 8));
-    const size_t lds = 2 * P2_BUFB;
+    const size_t lds = P2_LDSB;
     p.dbg = nullptr;
+    if (!ctx->d_dummy) E2EMV_HIP(ctx, hipMalloc((void**)&ctx->d_dummy, 4096));
+    p.dummy = ctx->d_dummy;
 #ifdef E2EMV_STAMPS
     // measurement build only (tools/p2_stamps.py): E2EMV_P2_DBG selects an ablation / the stamped variant of the planes kernel
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("E2EMV_P2_DBG"); dbg = e ? atoi(e) : 0; }
     static long long* d_buf = nullptr;
     const size_t nb = sizeof(long long) * 2 * 8 * 50 * 4;
-    if (dbg && a.out == P2_OUT_PLANES) {
+    if (dbg && a.out == P2_OUT_PLANES && !a.Rp) {
         switch (dbg) {
-            case 1: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 1>); break;
-            case 2: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 2>); break;
-            case 3: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 3>); break;
-            case 4: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 4>); break;
-            case 6: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 6>); break;
-            case 8: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 8>); break;
-            case 16: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 16>); break;
-            case 17: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 17>); break;
-            case 24: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 24>); break;
-            case 32: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 32>); break;
-            case 64: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 64>); break;
-            case 128: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 128>); break;
-            case 36: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 36>); break;
-            case 40: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, 40>); break;
+            case 1: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 1>); break;
+            case 2: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 2>); break;
+            case 3: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 3>); break;
+            case 4: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 4>); break;
+            case 6: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 6>); break;
+            case 8: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 8>); break;
+            case 16: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 16>); break;
+            case 17: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 17>); break;
+            case 24: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 24>); break;
+            case 32: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 32>); break;
+            case 64: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 64>); break;
+            case 128: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 128>); break;
+            case 256: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 256>); break;
+            case 36: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 36>); break;
+            case 40: fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_PLANES, false, 40>); break;
             default: break;
         }
         if (dbg & 8) {
