@@ -346,7 +346,7 @@ int e2emv_gemm_p2(e2emv_ctx* ctx, int M, int Nout, int K, int K1, const float* d
 int e2emv_qkv_p2(e2emv_ctx* ctx, int n_img, int n_rows, int D, int H, const float* d_X, const float* d_W, const float* d_bias,
                  float* d_qkv, void* stream);
 /* same contract as e2emv_attention on the plane kernel; flags: bit0 cross, bit1 / bit2 force 4 / 8 waves per workgroup,
- * bit3 = without the two-block score pipeline (the A/B arm), bits 8.. = timed repetitions. */
+ * bits 8.. = timed repetitions. */
 int e2emv_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv, int flags,
                        float* d_out, void* stream);
 

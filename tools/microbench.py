@@ -113,9 +113,8 @@ def main():
                 ms_h = family(lambda n: [E.attention_bf16x3(qkv, B, 2, N, 4, cross, kernel="f16x2") for _ in range(n)], "attention", 5)
                 line = f"  B={B:3d} N={N:5d} cross={cross}  h2f {ms_h * 1e3:7.1f} us {fl / ms_h / 1e9:6.1f} TF |"
                 for waves in (4, 8):
-                    for pipe in (True, False):
-                        ms = family(lambda n: E.attention_p2(qkv, B, 2, N, 4, cross, waves=waves, reps=n, pipe=pipe), "attention", 5)
-                        line += f" p2/{waves}w{'' if pipe else '-nopipe'} {ms * 1e3:6.1f} us {fl / ms / 1e9:5.1f} TF |"
+                    ms = family(lambda n: E.attention_p2(qkv, B, 2, N, 4, cross, waves=waves, reps=n), "attention", 5)
+                    line += f" p2/{waves}w {ms * 1e3:7.1f} us {fl / ms / 1e9:6.1f} TF |"
                 print(line)
     if "attn" in args.what:
         print("== attention (B pairs, N) -> us, TFLOP/s")
