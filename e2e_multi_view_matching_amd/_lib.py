@@ -109,6 +109,7 @@ SIGNATURES = {
                               c_void_p]),
     "e2emv_qkv_p2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_attention_p2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "e2emv_get_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_uint64), c_int, c_int]),
     "e2emv_profile": (c_int, [c_void_p, c_int]),
     "e2emv_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int64), c_int, c_int]),
     "e2emv_profile_name": (c_char_p, [c_int]),
@@ -193,6 +194,13 @@ class Context:
         (fp32 activations split inside the consuming kernel)."""
         self.call("e2emv_set_f16x2_kernels", int(generation))
         self.f16x2_kernels = int(generation)
+
+    def stats(self, reset=False):
+        """{'rescaled_blocks': plane blocks that needed a non-zero tile exponent, 'sinkhorn_bad': Sinkhorn problems reported
+        non-finite} since the last reset (host-synchronising)."""
+        v = (ctypes.c_uint64 * 2)()
+        self.call("e2emv_get_stats", v, 2, 1 if reset else 0)
+        return {"rescaled_blocks": int(v[0]), "sinkhorn_bad": int(v[1])}
 
     def set_split_min_rows(self, min_rows=-1):
         """Calls with fewer keypoint rows than this run the fp32-MFMA kernels even in a split-operand mode

@@ -29,6 +29,9 @@ struct AttnP2Params {
     const uint16_t* vt;   // [n_img][H][64][n_rows] plain planes
     uint16_t* out;        // [n_img*n_rows][D] scaled planes
     unsigned qk_bytes, vt_bytes;
+    const int* EQK;       // tile exponents (p2.h) of q | k [rows/64][8] and of V^T [rows/64][4] (by key rows); null = all zero
+    const int* EVt;
+    int* EO;              // exponents of the output [rows/64][4]; null = not wanted
     int B, T, n_rows, D, H, cross;
     int nv[E2EMV_MAX_TUPLE];
     int nq, groups, gper;
@@ -70,7 +73,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_p2_kernel(
     ap_f32x16 O0, O1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = -1e30f, l_run = 0.f;   // m_run: running maximum in TRUE base-2 logits (the score units change with k's exponent)
+    // tile exponents: q's (this wave's 32 queries lie in one 64-row block) goes into the logit scale together with the key
+    // tile's; the O accumulator lives at the exponent of the CURRENT V tile and is rescaled (exactly) when that changes
+    const int q_blk = __builtin_amdgcn_readfirstlane(((int64_t)img * p.n_rows + min(qt * QT + wave * 32, p.n_rows - 1)) >> 6);
+    const int e_q = p.EQK ? p.EQK[q_blk * 8 + head] : 0;
+    int e_o = 0;
+    bool o_started = false;
 
     const int n_src = p.cross ? p.T - 1 : 1;
     auto src_t = [&](int si) { return !p.cross ? t : (si < t ? si : si + 1); };
@@ -109,20 +118,44 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_p2_kernel(
     constexpr int PB[3] = {0, 1, 0};  // plane of the B operand (Q or P)
     const int kz = l31 & 15;          // swizzle of this lane's fragment rows (keys l31 / l31 + 32, dims l31 / l31 + 32)
 
+    // tile exponents of a key tile (k's, v's): fetched by lane 0 right behind the tile's loads, i.e. a whole tile before
+    // they are needed, and broadcast with readfirstlane - no scalar-memory latency at the head of a tile
+    auto fetch_e = [&](int si, int kt, int& ek, int& evv) {
+        ek = 0; evv = 0;
+        if (p.EQK && lane == 0) {
+            const int blk = ((b * p.T + src_t(si)) * p.n_rows + kt * AP_KV) >> 6;
+            ek = p.EQK[blk * 8 + 4 + head];
+            evv = p.EVt ? p.EVt[blk * 4 + head] : 0;
+        }
+    };
     TilePos cur{0, 0}, nxt{0, 0};
     issue(0, nxt.si, nxt.kt);
+    int ek_n = 0, ev_n = 0;
+    fetch_e(nxt.si, nxt.kt, ek_n, ev_n);
     int buf = 0;
     for (int tile = 0; tile < n_tiles; ++tile) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's pieces have landed (issued a whole tile ago)
         __syncthreads();                                   // ... everybody's; and everybody is done with the other buffer
         cur = nxt;
+        const int e_k = __builtin_amdgcn_readfirstlane(ek_n), e_v = __builtin_amdgcn_readfirstlane(ev_n);
         if (tile + 1 < n_tiles) {
             advance_pos(nxt);
             issue(buf ^ 1, nxt.si, nxt.kt);
+            fetch_e(nxt.si, nxt.kt, ek_n, ev_n);
         }
         const char* Kt = smem_ap + buf * AP_BUFB;
         const char* Vt = Kt + AP_TILEB;
         const int valid_in_tile = p.nv[src_t(cur.si)] - cur.kt * AP_KV;
+        const float sinv = AP_SINV * p2_exp2i(e_q + e_k);
+        if (p.EVt) {
+            if (o_started && e_v != e_o) {
+                const float f = e_o - e_v < -126 ? 0.f : p2_exp2i(e_o - e_v);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { O0[r] *= f; O1[r] *= f; }
+            }
+            e_o = e_v;
+            o_started = true;
+        }
         // S^T of a 32-key block: 12 MFMAs on one accumulator (the first takes the zero C operand)
         auto qk = [&](int sub) {
             ap_f32x16 S;
@@ -161,21 +194,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_p2_kernel(
             // S (and m) are in units of 1 / P2_QS of a base-2 logit; P carries the factor 2^AP_PLOG (cancels in O / l).  Lazy
             // running maximum as in attention_h2f_kernel: m_run moves (and O, l are rescaled) only when a row's new maximum
             // exceeds it by more than 2^AP_LAZY; P then stays below 2^(AP_PLOG + AP_LAZY) = 32768, inside fp16's range
+            mx *= sinv;
             float m_new = m_run, alpha = 1.f;
-            const bool grow = (mx - m_run) * AP_SINV > AP_LAZY;
+            const bool grow = mx - m_run > AP_LAZY;
             if (__builtin_amdgcn_ballot_w64(grow) != 0) {  // wave-uniform
                 m_new = fmaxf(m_run, mx);
-                alpha = __builtin_amdgcn_exp2f((m_run - m_new) * AP_SINV);
+                alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { O0[r] *= alpha; O1[r] *= alpha; }
             }
-            const float e0 = AP_PLOG - m_new * AP_SINV;
+            const float e0 = AP_PLOG - m_new;
             float ps = 0.f;
             p2_u32x4 Pf[2][2];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], AP_SINV, e0));
-                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r + 1], AP_SINV, e0));
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], sinv, e0));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r + 1], sinv, e0));
                 ps += p0 + p1;
                 const P2Pair pr = p2_split_plain(p0, p1);
                 Pf[0][r >> 3][(r & 7) >> 1] = pr.hi; Pf[1][r >> 3][(r & 7) >> 1] = pr.lo;
@@ -211,6 +245,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_p2_kernel(
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / (l_tot * P2_VS);
     if (!q_ok) return;
+    // |O / l| <= max |v'| < 2^15 / P2_VS: the output planes inherit the exponent of the last V tile (every wave of the
+    // workgroup - and of the other query tiles of this image and head - walks the same tiles: the same value)
+    if (p.EO && lane == 0) p.EO[(((int64_t)img * p.n_rows + q_row) >> 6) * 4 + head] = e_o;
     // scaled planes of the output row: lane (query, lh) owns dims (r & 3) + 8 (r >> 2) + 4 lh of each 32-dim block
     uint16_t* op = p.out + p2_index((int64_t)img * p.n_rows + q_row, head * AP_HD + 4 * lh, p.D);
 #pragma unroll
@@ -225,7 +262,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_p2_kernel(
 }
 
 int launch_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, int D, int H, const uint16_t* qk,
-                        const uint16_t* vt, int cross, uint16_t* outp, hipStream_t s) {
+                        const uint16_t* vt, int cross, uint16_t* outp, hipStream_t s, const int* EQK, const int* EVt, int* EO) {
     int n_valid = 0;
     for (int t = 0; t < T; ++t) {
         if (nv[t] <= 0 || nv[t] > n_rows) return set_err(ctx, E2EMV_ESHAPE, "attention_p2: image %d has %d keypoints (n_rows %d)", t, nv[t], n_rows);
@@ -239,6 +276,7 @@ int launch_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv,
     if (rows * 8 * D >= ((int64_t)1 << 31)) return set_err(ctx, E2EMV_ESHAPE, "attention_p2: q|k planes larger than 2 GB (32-bit byte offsets)");
     AttnP2Params p{};
     p.qk = qk; p.vt = vt; p.out = outp;
+    p.EQK = EQK; p.EVt = EVt; p.EO = EO;
     p.qk_bytes = (unsigned)(rows * 8 * D); p.vt_bytes = (unsigned)(rows * 4 * D);
     p.B = B; p.T = T; p.n_rows = n_rows; p.D = D; p.H = H;
     for (int t = 0; t < E2EMV_MAX_TUPLE; ++t) p.nv[t] = t < T ? nv[t] : 0;

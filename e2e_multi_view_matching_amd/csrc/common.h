@@ -64,6 +64,7 @@ struct LayerWeights {
     uint16_t* wp_qkv = nullptr;
     uint16_t* wp_mlp0 = nullptr;
     uint16_t* wp_mlp1 = nullptr;
+    float ba_qkv = 0.f, ba_mlp0 = 0.f, ba_mlp1 = 0.f;  // max |bias| of the three GEMMs (bounds for the tile exponents, p2.h)
 };
 
 // Family timing as a CHAIN of events on the launch stream: one event where the family changes (it ends the previous
@@ -120,6 +121,8 @@ struct e2emv_ctx {
     size_t attn_part_bytes = 0;
     // device flags: [0] give-up flag of the running resident Sinkhorn launch, [1] sticky count of give-ups
     unsigned* d_flags = nullptr;
+    uint64_t stat_sinkhorn_bad = 0;  // Sinkhorn problems reported non-finite / timed out so far (e2emv_get_stats)
+    bool sinkhorn_stream = false;    // set by the first such report: later calls run the log-domain launch chain
     char* d_dummy = nullptr;  // 4 KB scratch line: target of masked-out stores of kernels that must issue a fixed number of stores (gemm_p2.hip)
     // workspace arena
     char* d_ws = nullptr;
@@ -178,6 +181,8 @@ struct CallGuard {
 // workspace: makes ctx->d_ws at least `bytes` large, growing the arena (synchronising) when needed; each
 // top-level entry point carves it with 256-byte aligned offsets.
 int ws_reserve(e2emv_ctx* ctx, size_t bytes);
+// ctx->d_flags (device words: [0] Sinkhorn give-up flag, [1] its sticky count, [2] plane blocks that needed a tile exponent)
+int ensure_flags(e2emv_ctx* ctx);
 // hipFuncAttributeMaxDynamicSharedMemorySize for kernels that use more than the default dynamic LDS: once per
 // (device, kernel), thread-safe (ctx.hip)
 int ensure_dynamic_lds(e2emv_ctx* ctx, const void* kernel, size_t bytes);

@@ -33,6 +33,13 @@ int ensure_dynamic_lds(e2emv_ctx* ctx, const void* kernel, size_t bytes) {
     return E2EMV_OK;
 }
 
+int ensure_flags(e2emv_ctx* ctx) {
+    if (ctx->d_flags) return E2EMV_OK;
+    E2EMV_HIP(ctx, hipMalloc((void**)&ctx->d_flags, 256));
+    E2EMV_HIP(ctx, hipMemset(ctx->d_flags, 0, 256));
+    return E2EMV_OK;
+}
+
 int ws_reserve(e2emv_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return E2EMV_OK;
     E2EMV_HIP(ctx, hipDeviceSynchronize());
@@ -231,8 +238,11 @@ int e2emv_sync(e2emv_ctx* ctx, void* stream) {
         if (f[1]) {
             unsigned zero = 0;
             (void)hipMemcpy(ctx->d_flags + 1, &zero, sizeof(zero), hipMemcpyHostToDevice);
-            return set_err(ctx, E2EMV_EHIP, "sinkhorn (resident kernel): %u problems left fp32's range or gave up an inter-workgroup "
-                           "wait - their outputs are NaN/inf; E2EMV_SINKHORN=stream runs the log-domain launch chain", f[1]);
+            ctx->stat_sinkhorn_bad += f[1];
+            ctx->sinkhorn_stream = true;  // this model's scores leave the exponential-domain kernel's range: from now on the log-domain launch chain
+            return set_err(ctx, E2EMV_EHIP, "sinkhorn (resident kernel): scores left the exponential-domain kernel's range or an inter-workgroup "
+                           "wait gave up (%u workgroup reports) - the outputs of those problems are NaN/inf; this context runs the "
+                           "log-domain launch chain from now on", f[1]);
         }
     }
     return E2EMV_OK;
@@ -376,7 +386,7 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     struct LOff {
         size_t wqkv, bqkv, wm, bm, w0, b0, w1, b1;
         size_t w3qkv, w3m0, w3m1, whqkv, whm0, whm1, wpqkv, wpm0, wpm1;
-        float hsqkv, hsm0, hsm1;
+        float hsqkv, hsm0, hsm1, baqkv, bam0, bam1;
     };
     std::vector<uint16_t> pk3;  // bf16x3 planes of the big GEMM weights
     std::vector<LOff> loff(m->n_layers);
@@ -397,6 +407,8 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         loff[l].w3qkv = add_split3(pk3, wqkv, 3 * D, D);
         loff[l].whqkv = add_split_h2(pk3, wqkv, 3 * D, D, &loff[l].hsqkv);
         loff[l].wpqkv = add_split_p2(pk3, wqkv, 3 * D, D, &loff[l].hsqkv);
+        loff[l].baqkv = 0.f;
+        for (float v : bqkv) loff[l].baqkv = std::max(loff[l].baqkv, std::fabs(v));
         if ((rc = get_conv(ctx, base + ".attn.merge", D, D, w, b))) return rc;
         std::vector<float> wm((size_t)D * D);
         for (int o = 0; o < D; ++o)
@@ -432,12 +444,16 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         loff[l].w3m0 = add_split3(pk3, w, 2 * D, 2 * D);
         loff[l].whm0 = add_split_h2(pk3, w, 2 * D, 2 * D, &loff[l].hsm0);
         loff[l].wpm0 = add_split_p2(pk3, w, 2 * D, 2 * D, &loff[l].hsm0);
+        loff[l].bam0 = 0.f;
+        for (float v : b) loff[l].bam0 = std::max(loff[l].bam0, std::fabs(v));
         if ((rc = get_conv(ctx, base + ".mlp.3", D, 2 * D, w, b))) return rc;
         loff[l].w1 = pk.add(w);
         loff[l].b1 = pk.add(b);
         loff[l].w3m1 = add_split3(pk3, w, D, 2 * D);
         loff[l].whm1 = add_split_h2(pk3, w, D, 2 * D, &loff[l].hsm1);
         loff[l].wpm1 = add_split_p2(pk3, w, D, 2 * D, &loff[l].hsm1);
+        loff[l].bam1 = 0.f;
+        for (float v : b) loff[l].bam1 = std::max(loff[l].bam1, std::fabs(v));
     }
     if ((rc = get_conv(ctx, "final_proj", D, D, w, b))) return rc;
     size_t wf = pk.add(w), bf = pk.add(b);
@@ -516,6 +532,7 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         L.wp_qkv = ctx->d_w3arena + loff[l].wpqkv;
         L.wp_mlp0 = ctx->d_w3arena + loff[l].wpm0;
         L.wp_mlp1 = ctx->d_w3arena + loff[l].wpm1;
+        L.ba_qkv = loff[l].baqkv; L.ba_mlp0 = loff[l].bam0; L.ba_mlp1 = loff[l].bam1;
     }
     ctx->w_final = base + wf;
     ctx->b_final = base + bf;
@@ -543,6 +560,29 @@ int e2emv_set_precision(e2emv_ctx* ctx, int precision) {
     if (precision != E2EMV_PRECISION_F32 && !ctx->fuse_merge)
         return set_err(ctx, E2EMV_ESTATE, "bf16x3 needs the merge conv folded into MLP0 (unset E2EMV_NO_FUSE_MERGE)");
     ctx->precision = precision;
+    return E2EMV_OK;
+}
+
+int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset) {
+    if (!ctx || !stats || n < 0) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
+    (void)hipSetDevice(ctx->device);
+    E2EMV_HIP(ctx, hipDeviceSynchronize());
+    unsigned f[4] = {0, 0, 0, 0};
+    if (ctx->d_flags) E2EMV_HIP(ctx, hipMemcpy(f, ctx->d_flags, sizeof(f), hipMemcpyDeviceToHost));
+    ctx->stat_sinkhorn_bad += f[1];
+    const uint64_t v[2] = {(uint64_t)f[2], ctx->stat_sinkhorn_bad};
+    for (int i = 0; i < n; ++i) stats[i] = i < 2 ? v[i] : 0;
+    if (reset) {
+        ctx->stat_sinkhorn_bad = 0;
+        ctx->sinkhorn_stream = false;  // (a reset also returns the Sinkhorn to the resident kernel)
+        if (ctx->d_flags) E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 2, 0, sizeof(unsigned)));
+    }
+    if (ctx->d_flags && f[1]) {  // the Sinkhorn count moves into the host-side total (e2emv_sync reports and clears it the same way)
+        unsigned zero = 0;
+        E2EMV_HIP(ctx, hipMemcpy(ctx->d_flags + 1, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        if (!reset) ctx->sinkhorn_stream = true;
+    }
     return E2EMV_OK;
 }
 

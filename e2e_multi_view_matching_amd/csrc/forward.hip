@@ -168,7 +168,10 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
     // bf16x3 attention path: x as S3 planes (6D bytes/row) and V^T planes (6D bytes/row); the q|k planes
     // (S3, 2D wide = 12D bytes/row) live in the fp32 q|k|v buffer, which has exactly that size
     const size_t sz_x3 = b3 ? al((size_t)Mtot * 3 * D * 2) : 0;
-    const size_t need = sz_x * 3 + sz_qkv + sz_hid + sz_S + sz_sk + sz_match + sz_x3 + 4096;
+    // tile exponents of the plane tensors (p2.h): one int per 64 rows x 64 columns of x (4), attention output (4), q|k (8),
+    // V^T (4), hidden (8)
+    const size_t sz_e = p2 ? al((size_t)(Mtot / 64) * 32 * sizeof(int)) : 0;  // + max |x| per block (4 floats)
+    const size_t need = sz_x * 3 + sz_qkv + sz_hid + sz_S + sz_sk + sz_match + sz_x3 + sz_e + 4096;
     int rc = ws_reserve(ctx, need);
     if (rc) return rc;
     char* w = ctx->d_ws;
@@ -184,6 +187,12 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         vt3 = (uint16_t*)w; w += sz_x3;
         qk3 = (uint16_t*)qkv;
     }
+    int* e_x = (int*)w; w += sz_e;
+    int* e_att = e_x + (Mtot / 64) * 4;
+    int* e_qk = e_att + (Mtot / 64) * 4;
+    int* e_vt = e_qk + (Mtot / 64) * 8;
+    int* e_hid = e_vt + (Mtot / 64) * 4;
+    float* a_x = (float*)(e_hid + (Mtot / 64) * 8);  // max |x| of the blocks: the residual's share of the bound that picks x's next exponent
     std::vector<int64_t*> tmp_m0(P, nullptr);
     std::vector<float*> tmp_ms0(P, nullptr);
     if (full)
@@ -246,7 +255,9 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
     uint16_t* hidp = (uint16_t*)hid;          // hidden as scaled planes [Mtot][2D]
     if (p2) {
         prof_begin(ctx, PS_INGEST, s);
-        rc = launch_to_planes(ctx, x, Mtot, D, D, xp, s);
+        // (the attention skips query tiles beyond the keypoints of an image: their exponent entries must not be stale)
+        E2EMV_HIP(ctx, hipMemsetAsync(e_x, 0, (size_t)(Mtot / 64) * 28 * sizeof(int), s));
+        rc = launch_to_planes(ctx, x, Mtot, D, D, xp, s, e_x, a_x);
         prof_end(ctx, s);
         if (rc) return rc;
     }
@@ -258,10 +269,11 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
             GemmP2Args q;
             q.M = (int)Mtot; q.N = 3 * D; q.K = D; q.K1 = D; q.A = xp; q.lda = D; q.W = L.wp_qkv; q.out_scale = L.hs_qkv; q.bias = L.b_qkv;
             q.out = P2_OUT_QKV; q.Cp = qkp; q.Vt = vtp; q.n_rows = n_rows; q.heads = H;
+            q.EA = e_x; q.EC = e_qk; q.EVt = e_vt; q.bias_amax = L.ba_qkv;
             prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_p2(ctx, q, s); prof_end(ctx, s);
             if (rc) return rc;
             prof_begin(ctx, PS_ATTN, s);
-            rc = launch_attention_p2(ctx, B, T, n_rows, Nt, D, H, qkp, vtp, L.type, attp, s);
+            rc = launch_attention_p2(ctx, B, T, n_rows, Nt, D, H, qkp, vtp, L.type, attp, s, e_qk, e_vt, e_att);
             prof_end(ctx, s);
             if (rc) return rc;
             // hidden = relu(W0 [x | attention] + b0)   (merge folded into W0, BN folded)
@@ -269,14 +281,16 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
             m0.M = (int)Mtot; m0.N = 2 * D; m0.K = 2 * D; m0.K1 = D; m0.A = xp; m0.lda = D; m0.A2 = attp; m0.lda2 = D;
             m0.W = L.wp_mlp0; m0.out_scale = L.hs_mlp0; m0.bias = L.b_mlp0; m0.relu = true;
             m0.out = P2_OUT_PLANES; m0.Cp = hidp; m0.ldc = 2 * D;
+            m0.EA = e_x; m0.EA2 = e_att; m0.EC = e_hid; m0.bias_amax = L.ba_mlp0;
             prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_p2(ctx, m0, s); prof_end(ctx, s);
             if (rc) return rc;
             // x += W1 hidden + b1; the last layer hands x to final_proj as fp32
             GemmP2Args m1;
             m1.M = (int)Mtot; m1.N = D; m1.K = 2 * D; m1.K1 = 2 * D; m1.A = hidp; m1.lda = 2 * D;
             m1.W = L.wp_mlp1; m1.out_scale = L.hs_mlp1; m1.bias = L.b_mlp1; m1.Rp = xp; m1.ldr = D;
+            m1.EA = e_hid; m1.ER = e_x; m1.AR = a_x; m1.bias_amax = L.ba_mlp1;
             if (last) { m1.out = P2_OUT_F32; m1.C32 = x; m1.ldc = D; }
-            else { m1.out = P2_OUT_PLANES; m1.Cp = xp; m1.ldc = D; }
+            else { m1.out = P2_OUT_PLANES; m1.Cp = xp; m1.ldc = D; m1.EC = e_x; m1.AC = a_x; }
             prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_p2(ctx, m1, s); prof_end(ctx, s);
             if (rc) return rc;
             continue;

@@ -47,6 +47,16 @@ struct GemmP2Params {
     float out_scale;
     float col_scale[3];
     int n_rows, heads;
+    const int* EA;   // tile exponents (p2.h); null = all zero
+    const int* EA2;
+    const int* ER;
+    int* EC;
+    int* EVt;
+    const float* AR;  // max |value| of the residual's 64 x 64 blocks (true units) - the bound that picks the output exponent
+    float* AC;        // the same of the output (written when the output is a later residual: x)
+    int eld_a, eld_a2, eld_r, eld_c;  // entries per 64-row block
+    float bias_amax;
+    unsigned* stats;  // [0]: number of output blocks that needed a non-zero exponent
     char* dummy;     // 4 KB: target of the stores of rows / columns beyond the matrix (a wave always issues all its stores)
     long long* dbg;  // E2EMV_STAMPS builds only: phase timestamps of two workgroups
 };
@@ -178,13 +188,52 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
     //   * every wave issues EXACTLY 32 store instructions per tile (rows / columns beyond the matrix go to a dummy line
     //     instead of being skipped), so the K loop of the next tile can wait with a COUNTED vmcnt for its operand loads,
     //     which were issued before these stores, and leave the stores in flight (see the pipeline below).
-    auto epilogue = [&](int t) {
+    auto epilogue = [&](int t, int e_run) {
         char* sl = smem_p2 + 2 * P2_BUFB + wave * P2_SLABB;
         const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
         const int o_r = lane >> 2, o_c = (lane & 3) * 8;  // row-contiguous view: 16 rows per pass, 8 columns per lane
         const int o_z = o_r & 7;
         const float cs = OUT == P2_OUT_QKV ? p.col_scale[min(tn, 2)] : 1.f;
         char* dummy = p.dummy + lane * 64;
+        const float os = p.out_scale * p2_exp2i(e_run);  // the accumulators carry the exponent of the last K block
+        // ---- tile exponents of the output: one per 64 columns of this wave's 64 rows, from an upper bound of the values
+        const int erow = tm * 4 + wr;
+        float rsc[2] = {1.f, 1.f};   // 2^e of the residual blocks
+        float osc[2] = {1.f, 1.f};   // 2^-e of the output blocks
+        float amx[2] = {0.f, 0.f};   // max |final value| of the output blocks (this lane's share)
+        if ((OUT != P2_OUT_F32 && (p.EC || p.EVt)) || (HAS_R && p.ER)) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int cb = tn * 4 + wc * 2 + ch;  // 64-column block of the output
+                int er = 0;
+                float ar = 0.f;
+                if (HAS_R && erow * 64 < p.M && cb < p.eld_r) {
+                    if (p.ER) er = p.ER[erow * p.eld_r + cb];
+                    ar = p.AR ? p.AR[erow * p.eld_r + cb] : 65536.f * p2_exp2i(er);
+                }
+                rsc[ch] = p2_exp2i(er);
+                int* E = (OUT == P2_OUT_QKV && tn == 2) ? p.EVt : p.EC;
+                if (OUT == P2_OUT_F32 || !E) continue;
+                float am = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(acc[2 * ch + jj][i][r]));
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+                const float bound = am * os + p.bias_amax + ar;
+                const int e = p2_pick_exponent(bound * cs);
+                osc[ch] = p2_exp2i(-e);
+                const int ecb = (OUT == P2_OUT_QKV && tn == 2) ? wc * 2 + ch : cb;
+                const int eld = (OUT == P2_OUT_QKV && tn == 2) ? 4 : p.eld_c;
+                if (lane == 0 && erow * 64 < p.M && ecb < eld) {
+                    E[erow * eld + ecb] = e;
+                    if (e != 0 && p.stats) atomicAdd(p.stats, 1u);
+                }
+            }
+        }
         auto slab_write = [&](int i, int j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -218,7 +267,8 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                         p2_u32x4 hi, lo;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const P2Pair pr = p2_split_plain((v[2 * e] * p.out_scale + b) * cs, (v[2 * e + 1] * p.out_scale + b) * cs);
+                            const float f = cs * osc[j >> 1];
+                            const P2Pair pr = p2_split_plain((v[2 * e] * os + b) * f, (v[2 * e + 1] * os + b) * f);
                             hi[e] = pr.hi; lo[e] = pr.lo;
                         }
                         const int img = m0 / p.n_rows, key0 = m0 - img * p.n_rows;
@@ -259,7 +309,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                 const int c0 = 2 * (lane & 3);
                 rv[b & 1][pass][0] = *reinterpret_cast<const p2_f32x4*>(sl + r * 128 + ((c0 ^ o_z) << 4));
                 rv[b & 1][pass][1] = *reinterpret_cast<const p2_f32x4*>(sl + r * 128 + (((c0 + 1) ^ o_z) << 4));
-                if (HAS_R) {
+                if constexpr (HAS_R) {
                     const int m = min(tm * P2_BM + wr * 64 + i * 32 + r, p.M - 1);
                     const uint16_t* rp = p.Rp + p2_index(m, min(n, p.N - 8), p.ldr);
                     rr[b & 1][pass][0] = *reinterpret_cast<const p2_u32x4*>(rp);
@@ -276,20 +326,27 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
             for (int pass = 0; pass < 2; ++pass) {
                 const int m = m0 + o_r + 16 * pass;
                 const bool ok = m < p.M && n < p.N;
-                p2_f32x4 v0 = rv[b & 1][pass][0] * p.out_scale + bias8[HAS_R ? (b & 1) : j][0];
-                p2_f32x4 v1 = rv[b & 1][pass][1] * p.out_scale + bias8[HAS_R ? (b & 1) : j][1];
+                p2_f32x4 v0 = rv[b & 1][pass][0] * os + bias8[HAS_R ? (b & 1) : j][0];
+                p2_f32x4 v1 = rv[b & 1][pass][1] * os + bias8[HAS_R ? (b & 1) : j][1];
                 if (OUT != P2_OUT_QKV && p.relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v0[e] = relu_nan(v0[e]); v1[e] = relu_nan(v1[e]); }
                 }
-                if (HAS_R) {
+                if constexpr (HAS_R) {
                     const p2_u32x4 rh = rr[b & 1][pass][0], rl = rr[b & 1][pass][1];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const p2_f32x2 a = p2_join_scaled(rh[e], rl[e]), c = p2_join_scaled(rh[2 + e], rl[2 + e]);
-                        v0[2 * e] += a[0]; v0[2 * e + 1] += a[1];
-                        v1[2 * e] += c[0]; v1[2 * e + 1] += c[1];
+                        const float rs = rsc[j >> 1];
+                        v0[2 * e] += a[0] * rs; v0[2 * e + 1] += a[1] * rs;
+                        v1[2 * e] += c[0] * rs; v1[2 * e + 1] += c[1] * rs;
                     }
+                }
+                if (OUT == P2_OUT_PLANES && p.AC && ok) {
+                    float a = amx[j >> 1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = fmaxf(a, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
+                    amx[j >> 1] = a;
                 }
                 if (OUT == P2_OUT_F32) {
                     float* cp = ok ? p.C32 + (int64_t)m * p.ldc + n : reinterpret_cast<float*>(dummy);
@@ -298,14 +355,16 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                     *reinterpret_cast<p2_f32x4*>(cq) = v1;
                 } else {
                     p2_u32x4 hi, lo;
+                    const float f = cs * osc[j >> 1];
                     if (OUT == P2_OUT_QKV) {
-                        v0 *= cs; v1 *= cs;
+                        v0 *= f; v1 *= f;
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             const P2Pair a = p2_split_plain(v0[2 * e], v0[2 * e + 1]), c = p2_split_plain(v1[2 * e], v1[2 * e + 1]);
                             hi[e] = a.hi; lo[e] = a.lo; hi[2 + e] = c.hi; lo[2 + e] = c.lo;
                         }
                     } else {
+                        if (f != 1.f) { v0 *= f; v1 *= f; }  // (wave-uniform; never taken inside the dead zone)
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             const P2Pair a = p2_split_scaled(v0[2 * e], v0[2 * e + 1]), c = p2_split_scaled(v1[2 * e], v1[2 * e + 1]);
@@ -331,6 +390,16 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         stage(P2_BLK(7)); finish(P2_BLK(6));
         finish(P2_BLK(7));
 #undef P2_BLK
+        if (OUT == P2_OUT_PLANES && p.AC) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                float a = amx[ch];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o));
+                const int cb = tn * 4 + wc * 2 + ch;
+                if (lane == 0 && erow * 64 < p.M && cb < p.eld_c) p.AC[erow * p.eld_c + cb] = a;
+            }
+        }
     };
 
     // ---- pipeline.  Step g = (tile, kt) in execution order lives in LDS buffer g & 1.  A step opens with "my loads of this
@@ -361,6 +430,23 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
     advance();
     const bool issue_first = (DBG & 32) ? true : wave >= 4;
     const bool overlap = nk >= 3 && !(DBG & (256 | 64 | 4 | 2));
+    // tile exponents of the A operand (p2.h): the accumulators live at the exponent of the CURRENT K block; when it changes
+    // they are rescaled (exact: a power of two) - a wave-uniform branch that an ordinary network never takes
+    // The exponents of a tile's K blocks are fetched ONCE, by one vector load (lane i: block i of this wave's 64 rows; the
+    // next tile's before the epilogue of this one), and read with v_readlane in the loop: no memory operation there.
+    const bool has_e = p.EA != nullptr;
+    int e_run = 0, cur_kt = 0;
+    int ev = 0, ev_next = 0;
+    auto fetch_e = [&](int t) {
+        int v = 0;
+        if (has_e) {
+            const int erow = (t / p.tiles_n) * 4 + wr;
+            const int nb1 = nk1 >> 1, nb = (nk + 1) >> 1;
+            if (erow * 64 < p.M && lane < nb) v = lane < nb1 ? p.EA[erow * p.eld_a + lane] : (p.EA2 ? p.EA2[erow * p.eld_a2 + lane - nb1] : 0);
+        }
+        return v;
+    };
+    ev = fetch_e(tile);
     int since = 8;       // K steps since the last epilogue
     bool ahead = false;  // the loads of the step after next were issued before that epilogue
     int buf = 0, dbg_n = 0, dbg_steps = 0;
@@ -380,6 +466,21 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (DBG & 8) t1 = clock64();
+        if (has_e) {
+            const int e_step = __builtin_amdgcn_readlane(ev, cur_kt >> 1);
+            if (!decltype(FIRST)::value && e_step != e_run) {
+                const int d = e_run - e_step;
+                const float f = d < -126 ? 0.f : p2_exp2i(d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[j][i][r] *= f;
+            }
+            e_run = e_step;
+        }
+        ++cur_kt;
         const bool ldv = ld_valid && !(since == 0 && ahead) && !((DBG & 2) && dbg_steps >= 1);
         ++dbg_steps;
         if (!(DBG & 16) && issue_first && ldv) issue(buf ^ 1, ld_kt, 0u);
@@ -417,8 +518,11 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
             advance();
             ahead = true;
         }
-        if (!(DBG & 4)) epilogue(tile);
+        cur_kt = 0;
+        if (has_e && tile + slots < t_end) ev_next = fetch_e(tile + slots);  // (issued BEFORE the epilogue's stores)
+        if (!(DBG & 4)) epilogue(tile, e_run);
         else asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));
+        ev = ev_next;
         since = overlap ? 0 : 8;
         if ((DBG & 8) && p.dbg && lane == 0 && dbg_n < 48 && (blockIdx.x == 0 || blockIdx.x == 101)) {
             long long* o = p.dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 50 * 4 + dbg_n * 4;
@@ -456,6 +560,15 @@ int launch_gemm_p2(e2emv_ctx* ctx, const GemmP2Args& a, hipStream_t s) {
     p.out_scale = a.out_scale;
     p.col_scale[0] = p.col_scale[1] = p.col_scale[2] = 1.f;
     p.n_rows = a.n_rows; p.heads = a.heads;
+    p.EA = a.EA; p.EA2 = a.EA2; p.ER = a.ER; p.EC = a.EC; p.EVt = a.EVt; p.AR = a.AR; p.AC = a.AC;
+    p.eld_a = (int)(a.lda / 64); p.eld_a2 = (int)(a.lda2 / 64); p.eld_r = (int)(a.ldr / 64); p.eld_c = (int)(a.ldc / 64);
+    p.bias_amax = a.bias ? a.bias_amax : 0.f;
+    if (a.EA && (a.lda % 64 || K1 % 64 || (a.A2 && (a.lda2 % 64 || (a.K - K1) % 64)) || a.M % 64))
+        return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: tile exponents need 64-column / 64-row blocks (lda=%lld K1=%d M=%d)", (long long)a.lda, K1, a.M);
+    if ((a.EC || a.EVt) && (a.M % 64 || (a.out == P2_OUT_PLANES && a.ldc % 64))) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: output exponents need 64 x 64 blocks");
+    if (a.ER && (a.ldr % 64 || a.M % 64)) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: residual exponents need 64 x 64 blocks");
+    if (int rc = ensure_flags(ctx)) return rc;
+    p.stats = ctx->d_flags + 2;
     const void* fn = nullptr;
     switch (a.out) {
         case P2_OUT_F32:
@@ -471,6 +584,7 @@ int launch_gemm_p2(e2emv_ctx* ctx, const GemmP2Args& a, hipStream_t s) {
                 (uintptr_t)a.Cp % 16 || (uintptr_t)a.Vt % 16)
                 return set_err(ctx, E2EMV_ESHAPE, "gemm_p2: q|k|v output needs N = 768 (4 heads of 64), n_rows %% 32 == 0, M %% n_rows == 0");
             p.ldc = 2 * P2_BN;
+            p.eld_c = 8;
             p.col_scale[0] = 0.125f * 1.4426950408889634f * P2_QS;  // log2(e) / sqrt(64), then the plane pre-scale
             p.col_scale[2] = P2_VS;
             fn = reinterpret_cast<const void*>(gemm_p2_kernel<P2_OUT_QKV, false>);

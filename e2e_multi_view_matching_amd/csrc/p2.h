@@ -72,6 +72,28 @@ __device__ __forceinline__ void p2_glds16(__amdgpu_buffer_rsrc_t rsrc, char* dst
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 0);
 }
 
+// ---- range side-band: tile exponents -------------------------------------------------------------------------------------
+// fp16 planes have fp16's exponent range.  Every plane tensor therefore carries one int32 exponent e per block of 64 rows x
+// 64 columns (E [rows / 64][C / 64]): the planes hold X 2^-e.  A producer picks e from an upper bound of the block's
+// magnitudes; inside the dead zone 2^-6 ... 2^15 it is 0 (every block of an ordinary network: the consumers then take
+// their plain paths, which cost nothing), above it the block's maximum is brought to [2^14, 2^15), below it to ~2^10.
+// Consumers undo it exactly (powers of two): a GEMM rescales its accumulators when the exponent changes between K
+// blocks and folds the last one into its output scale, the attention folds q's and k's into the logit scale and v's into
+// the O accumulator.  Range of the mode: 2^-16 ... 2^60 on top of fp16's own, i.e. |x| < 2^75; precision is relative to
+// the largest element of a 64 x 64 block (22 bits down to 2^-14 of it, absolute 2^-36 of it below).
+constexpr int P2_EMIN = -16, P2_EMAX = 60;
+__host__ __device__ __forceinline__ float p2_exp2i(int e) {  // 2^e, |e| <= 126
+    return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+__device__ __forceinline__ int p2_pick_exponent(float bound) {
+    if (!(bound < 3.0e38f)) return 0;  // inf / NaN: the values go through as they are
+    const int lg = (int)((__builtin_bit_cast(unsigned, bound) >> 23) & 255u) - 127;  // floor(log2 bound) for normal numbers
+    int e = 0;
+    if (lg >= 15) e = lg - 14;
+    else if (lg < -6 && bound > 0.f) e = lg - 10;
+    return e < P2_EMIN ? P2_EMIN : (e > P2_EMAX ? P2_EMAX : e);
+}
+
 // offset (in halves) of the hi half of element (m, k) in a P2 matrix of C columns; the lo half sits 32 halves further
 __host__ __device__ __forceinline__ int64_t p2_index(int64_t m, int k, int64_t C) { return m * 2 * C + (k >> 5) * 64 + (k & 31); }
 
@@ -102,16 +124,30 @@ struct GemmP2Args {
     int64_t ldc = 0;
     uint16_t* Vt = nullptr;        // P2_OUT_QKV: V^T plain planes [M / n_rows][heads][64][n_rows]
     int n_rows = 0, heads = 0;
+    // tile exponents (see above; any pointer may be null = all zero / not wanted).  EA [M/64][lda/64], EA2 [M/64][lda2/64],
+    // ER [M/64][ldr/64]; outputs EC [M/64][ldc/64] (P2_OUT_QKV: q | k -> [M/64][8]) and EVt [M/64][4] (V^T, indexed by key rows)
+    const int* EA = nullptr;
+    const int* EA2 = nullptr;
+    const int* ER = nullptr;
+    int* EC = nullptr;
+    int* EVt = nullptr;
+    const float* AR = nullptr;     // [M/64][ldr/64] max |value| of the residual's blocks (picks the output exponent; null: 2^(16 + e))
+    float* AC = nullptr;           // [M/64][ldc/64] the same of a plane output that is a later residual
+    float bias_amax = 0.f;         // upper bound of |bias| (0 when there is none)
 };
 int launch_gemm_p2(e2emv_ctx* ctx, const GemmP2Args& a, hipStream_t s);
 // fp32 [rows][C] (row stride ld_src floats) -> P2 scaled planes [rows][C]
-int launch_to_planes(e2emv_ctx* ctx, const float* src, int64_t rows, int C, int64_t ld_src, uint16_t* dst, hipStream_t s);
-int launch_from_planes(e2emv_ctx* ctx, const uint16_t* src, int64_t rows, int C, float* dst, int64_t ld_dst, hipStream_t s);
+// E (optional) [rows/64][C/64]: the tile exponents are computed from the data (rows % 64 == 0, C % 64 == 0 then)
+int launch_to_planes(e2emv_ctx* ctx, const float* src, int64_t rows, int C, int64_t ld_src, uint16_t* dst, hipStream_t s, int* E = nullptr,
+                     float* AM = nullptr);  // AM (optional, with E): the blocks' max |value|
+int launch_from_planes(e2emv_ctx* ctx, const uint16_t* src, int64_t rows, int C, float* dst, int64_t ld_dst, hipStream_t s, const int* E = nullptr);
 // host: fp32 weights [rows][cols] -> P2 planes of 2^s W appended to `out` (offset returned), *out_scale = 2^-s
 size_t add_split_p2(std::vector<uint16_t>& out, const std::vector<float>& w, int rows, int cols, float* out_scale);
 // softmax(q k^T / sqrt(64)) v on plane operands: qk = q | k plain planes [n_img * n_rows][2D], vt = V^T plain planes;
 // out = P2 scaled planes [n_img * n_rows][D]
+// EQK [rows/64][8], EVt [rows/64][4]: tile exponents of the operands, EO [rows/64][4] of the output (null = zero / not wanted)
 int launch_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, const int* n_valid_img, int D, int H, const uint16_t* qk,
-                        const uint16_t* vt, int cross, uint16_t* outp, hipStream_t s);
+                        const uint16_t* vt, int cross, uint16_t* outp, hipStream_t s, const int* EQK = nullptr, const int* EVt = nullptr,
+                        int* EO = nullptr);
 
 }  // namespace e2emv

@@ -995,6 +995,9 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
     if (const char* e = getenv("E2EMV_SINKHORN")) {
         if (strcmp(e, "stream") == 0) resident = false;
     }
+    // once a call of this context reported scores outside the exponential-domain kernel's range (e2emv_sync / e2emv_get_stats),
+    // the model at hand is served by the log-domain chain: slower, no range limit
+    if (ctx->sinkhorn_stream) resident = false;
     int wg_per_cu = 0;
     const void* kfn = nullptr;
     const size_t res_lds = sizeof(float) * (size_t)(9 * KT_of(ldS) * 256 + 4 + 32);
@@ -1012,10 +1015,11 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
             std::lock_guard<std::mutex> lk(occupancy_mu);
             auto it = occupancy.find({ctx->device, kfn});
             if (it == occupancy.end()) {
-                if (res_lds > 48 * 1024)
-                    if (int rc = ensure_dynamic_lds(ctx, kfn, res_lds)) return rc;
                 int nb = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 512, res_lds) != hipSuccess) {
+                if (res_lds > 48 * 1024 && ensure_dynamic_lds(ctx, kfn, res_lds) != E2EMV_OK) {
+                    (void)hipGetLastError();  // a device with less LDS: the streaming chain below serves the call
+                    nb = 0;
+                } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 512, res_lds) != hipSuccess) {
                     (void)hipGetLastError();
                     nb = 0;
                 }
@@ -1027,10 +1031,7 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
         if (wg_per_cu < 1 || G > wg_per_cu * ctx->num_cus) resident = false;
     }
     if (resident) {
-        if (!ctx->d_flags) {
-            E2EMV_HIP(ctx, hipMalloc((void**)&ctx->d_flags, 256));
-            E2EMV_HIP(ctx, hipMemset(ctx->d_flags, 0, 256));
-        }
+        if (int rc_f = ensure_flags(ctx)) return rc_f;
         const ResidentPlan rp = resident_plan(B, M, N, wg_per_cu * ctx->num_cus);
         SkResParams rpar{};
         rpar.S = S; rpar.ldS = ldS; rpar.M = M; rpar.N = N; rpar.B = B; rpar.iters = iters;

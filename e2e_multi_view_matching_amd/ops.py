@@ -103,9 +103,10 @@ def attention_bf16x3(qkv, B, T, n_valid, H, cross, kernel="planes"):
     return out
 
 
-def gemm_p2(A, W, bias=None, relu=False, A2=None, residual=None, planes_out=False, reps=1):
+def gemm_p2(A, W, bias=None, relu=False, A2=None, residual=None, planes_out=False, reps=1, exponents=False):
     """gemm_p2.hip on fp32 tensors: act([A | A2] W^T + bias) (+ residual).  The operands are converted to the plane format
-    (p2.h) by helper kernels, the kernel writes fp32 or (``planes_out``) planes that are converted back."""
+    (p2.h) by helper kernels, the kernel writes fp32 or (``planes_out``) planes that are converted back; ``exponents``: with
+    the tile exponents of the range side-band (shapes in multiples of 64)."""
     ctx = _ctx(A)
     A_, W_ = A.contiguous().float(), W.contiguous().float()
     A2_ = A2.contiguous().float() if A2 is not None else None
@@ -114,7 +115,7 @@ def gemm_p2(A, W, bias=None, relu=False, A2=None, residual=None, planes_out=Fals
     C = torch.empty((M, N), dtype=torch.float32, device=A.device)
     b = bias.contiguous().float() if bias is not None else None
     R = residual.contiguous().float() if residual is not None else None
-    flags = (1 if relu else 0) | (2 if planes_out else 0) | (int(reps) << 8 if reps > 1 else 0)
+    flags = (1 if relu else 0) | (2 if planes_out else 0) | (4 if exponents else 0) | (int(reps) << 8 if reps > 1 else 0)
     with torch.cuda.device(A.device):
         ctx.call("e2emv_gemm_p2", M, N, K, K1, _lib.ptr(A_), _lib.ptr(A2_), _lib.ptr(W_), _lib.ptr(b), _lib.ptr(R), _lib.ptr(C), flags,
                  _lib.stream_ptr(A.device))

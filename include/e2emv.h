@@ -337,7 +337,8 @@ int e2emv_attention_bf16x3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid
 int e2emv_set_f16x2_kernels(e2emv_ctx* ctx, int generation);
 /* building blocks on fp32 buffers (conversion to / from planes done by helper kernels; for tests and micro-benchmarks):
  * C = act([A | A2] W^T + bias) (+ R); A [M,K1], A2 [M,K-K1] or NULL, W [N,K], R [M,N] or NULL.  flags: bit0 relu, bit1 the
- * kernel writes planes (converted back to fp32 afterwards) instead of fp32, bits 8.. = number of timed repetitions.  The
+ * kernel writes planes (converted back to fp32 afterwards) instead of fp32, bit2 = with the tile exponents of the range
+ * side-band (M, K1, K - K1, N multiples of 64), bits 8.. = number of timed repetitions.  The
  * weight planes are made on the host as e2emv_commit_weights makes them (host-synchronising). */
 int e2emv_gemm_p2(e2emv_ctx* ctx, int M, int Nout, int K, int K1, const float* d_A, const float* d_A2, const float* d_W,
                   const float* d_bias, const float* d_R, float* d_C, int flags, void* stream);
@@ -349,6 +350,14 @@ int e2emv_qkv_p2(e2emv_ctx* ctx, int n_img, int n_rows, int D, int H, const floa
  * bits 8.. = timed repetitions. */
 int e2emv_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv, int flags,
                        float* d_out, void* stream);
+
+/* ---- range statistics ------------------------------------------------------------------------------------------------
+ * The f16x2 mode keeps its fp16 planes inside fp16's range with one exponent per block of 64 x 64 activations (see
+ * DESIGN.md 4d): there is no out-of-range fallback to take.  stats[0] = plane blocks that needed a non-zero exponent since
+ * the last reset (0 for an ordinary network: every block sat inside the dead zone and took the plain paths), stats[1] =
+ * Sinkhorn problems that left fp32's range or gave up an inter-workgroup wait (their outputs are NaN and e2emv_sync
+ * reports them; after the first such event the context runs the log-domain launch chain).  Host-synchronising. */
+int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset);
 
 /* ---- timing hooks used by bench.py (HIP events on the caller's stream) -------------
  * After e2emv_profile(ctx, 1) every kernel family launched by the library is bracketed by

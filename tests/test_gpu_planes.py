@@ -164,3 +164,61 @@ def test_attention_constant_v_exposes_operand_hazards(gpu, kernel):
             out = E.attention_bf16x3(qkv.to(gpu), 1, 2, n_valid, 4, 0, kernel="f16x2").cpu()
         err = (out[:, :n_valid] - 1.0).abs().view(2, n_valid, 4, 64)
         assert float(err[..., :32].max()) < 2e-6 and float(err[..., 32:].max()) < 2e-6, (n_valid, float(err[..., :32].max()), float(err[..., 32:].max()))
+
+
+# ---------------------------------------------------------------- range side-band: tile exponents
+def _block_scales(g, rows, cols, choices):
+    """one magnitude per 64 x 64 block"""
+    idx = torch.randint(len(choices), (rows // 64, cols // 64), generator=g)
+    sc = torch.tensor(choices, dtype=torch.float32)[idx]
+    return sc.repeat_interleave(64, 0).repeat_interleave(64, 1)
+
+
+@pytest.mark.parametrize("choices", [(1.0,), (1e-8, 1.0), (1.0, 3e6), (1e-9, 1e-3, 1.0, 1e5, 2e9), (7e4, 3e12)])
+def test_gemm_p2_tile_exponents_carry_fp32_range(gpu, choices):
+    """Activations far outside fp16's range (and mixed by 64 x 64 blocks inside one contraction): the plane GEMM with tile
+    exponents keeps the fp32-class error bound relative to sum |a||w|; residual and plane output included."""
+    import e2e_multi_view_matching_amd as E
+    g = torch.Generator().manual_seed(len(choices))
+    M, N, K1, K2 = 320, 256, 256, 256
+    K = K1 + K2
+    A = torch.randn(M, K, generator=g) * _block_scales(g, M, K, choices)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * max(choices)
+    R = torch.randn(M, N, generator=g) * _block_scales(g, M, N, choices)
+    A1, A2 = A[:, :K1].contiguous(), A[:, K1:].contiguous()
+    for relu, planes_out in ((False, False), (True, True)):
+        core = A.double() @ W.double().T + b.double()
+        ref = (core.clamp_min(0) if relu else core) + R.double()
+        scale = (A.double().abs() @ W.double().abs().T) + b.double().abs() + R.double().abs()
+        out = E.gemm_p2(A1.to(gpu), W.to(gpu), bias=b.to(gpu), relu=relu, A2=A2.to(gpu), residual=R.to(gpu), planes_out=planes_out,
+                        exponents=True).cpu()
+        assert torch.isfinite(out).all()
+        e = _err(out, ref, scale)
+        # a plane output is 22 bits relative to the largest element of its 64 x 64 block: the bar is taken against the block maximum
+        bar = 1.5e-6
+        if planes_out:
+            blk = ref.abs().view(M // 64, 64, N // 64, 64).amax((1, 3), keepdim=True).expand(M // 64, 64, N // 64, 64).reshape(M, N)
+            e = float(((out.double() - ref).abs() / (scale + blk)).max())
+        assert e < bar, (choices, relu, planes_out, e)
+
+
+@pytest.mark.parametrize("qs,ks,vs", [(1.0, 1.0, 1.0), (300.0, 1.0, 1e6), (1e-3, 2e3, 1e-7), (1e4, 1e-4, 3e9), (50.0, 50.0, 7e4)])
+def test_attention_p2_tile_exponents_carry_fp32_range(gpu, qs, ks, vs):
+    """q, k, v magnitudes beyond the old limits of the mode (|q| < 5.6e3, |v| < 4e3): exponents in the logit scale and in
+    the O accumulator; peaked and flat softmaxes."""
+    import e2e_multi_view_matching_amd as E
+    B, T, n_rows, n_valid, cross = 1, 2, 256, 200, 1
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(B * T, n_rows, 3 * 256, generator=g)
+    qkv[..., :256] *= qs
+    qkv[..., 256:512] *= ks
+    qkv[..., 512:] *= vs
+    qkv[0, 64:128, 512:] *= 1e-3  # one key block of one image three decades below the others: the O accumulator is rescaled
+    ref = _attention_ref(qkv, B, T, n_valid, 4, cross)
+    out = E.attention_p2(qkv.to(gpu), B, T, n_valid, 4, cross).cpu()
+    out32 = E.attention(qkv.to(gpu), B, T, n_valid, 4, cross).cpu()
+    assert torch.isfinite(out[:, :n_valid]).all()
+    err = float((out[:, :n_valid].double() - ref[:, :n_valid]).abs().max()) / vs
+    err32 = float((out32[:, :n_valid].double() - ref[:, :n_valid]).abs().max()) / vs
+    assert err < 3 * err32 + 3e-6, (err, err32)

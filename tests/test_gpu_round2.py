@@ -240,10 +240,10 @@ def test_config5_per_gpu_shape_t5_2048_fp16_batch8(gpu):
     _full_size(gpu, 2048, torch.float16, ["f32", "bf16x3", "f16x2"])
 
 
-def test_f16x2_out_of_range_activations_are_reported_not_silent(gpu, split_always):
-    """The f16x2 mode carries operands as fp16 planes: an activation beyond fp16's range (|x| > 65504 in a GEMM input)
-    becomes +-inf.  That must be loud: the scores turn non-finite and e2emv_sync reports it (like a Sinkhorn overflow);
-    bf16x3 - fp32's exponent range - solves the same input."""
+def test_f16x2_out_of_range_activations(gpu, split_always):
+    """Activations beyond fp16's range (|x| > 65504 in a GEMM input).  Round 2's f16x2 kernels turn them into +-inf and
+    e2emv_sync reports it; the plane kernels (round 3, the default) carry a tile exponent per 64 x 64 block and solve the same
+    input like bf16x3 does - there is nothing to fall back to."""
     from e2e_multi_view_matching_amd import MultiViewMatcher, _lib
     from e2e_multi_view_matching_amd.synthetic import make_tuples
     ctx = _lib.context(gpu)
@@ -255,7 +255,21 @@ def test_f16x2_out_of_range_activations_are_reported_not_silent(gpu, split_alway
         data[f"descriptors{m}"] = data[f"descriptors{m}"] * 3e6     # far outside anything a descriptor network produces
     dg = _dev(data, gpu)
     assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK
+    model.config["mfma_precision"] = "bf16x3"
+    with torch.no_grad():
+        ref = model(dg)
+    assert bool(torch.isfinite(ref["scores_0_1"]).all())
+    ctx.stats(reset=True)
     model.config["mfma_precision"] = "f16x2"
+    with torch.no_grad():
+        out = model(dg)
+    assert bool(torch.isfinite(out["scores_0_1"]).all())
+    assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK
+    z, zr = out["scores_0_1"], ref["scores_0_1"]
+    assert float((z - zr).abs().max() / zr.abs().max()) < 1e-6
+    assert torch.equal(out["matches0_0_1"], ref["matches0_0_1"])
+    assert ctx.stats()["rescaled_blocks"] > 0                        # the exponents were at work
+    model.config["mfma_precision"] = "f16x2-r2"                      # round-2 kernels: loud, not silent
     with torch.no_grad():
         out = model(dg)
     assert not bool(torch.isfinite(out["scores_0_1"]).all())
@@ -264,8 +278,4 @@ def test_f16x2_out_of_range_activations_are_reported_not_silent(gpu, split_alway
     model.config["check_finite"] = True                              # the same report as an exception from forward()
     with pytest.raises(_lib.E2EMVError), torch.no_grad():
         model(dg)
-    model.config["mfma_precision"] = "bf16x3"
-    with torch.no_grad():
-        out = model(dg)
-    assert bool(torch.isfinite(out["scores_0_1"]).all())
-    assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK
+    ctx.stats(reset=True)                                            # (the report also moved the context's Sinkhorn to the log-domain chain)

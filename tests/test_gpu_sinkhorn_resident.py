@@ -124,6 +124,12 @@ def test_dynamic_range_of_the_exponential_domain(gpu):
     else:
         assert rc == _lib.EHIP and b"range" in ctx.lib.e2emv_last_error(ctx.h)   # loud, not silent
         assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK                         # the report is consumed once
+        # ... and from that report on the context serves this model with the log-domain chain by itself
+        assert ctx.stats()["sinkhorn_bad"] >= 1
+        again = E.log_optimal_transport(s.to(gpu), 1.0, 100).cpu()
+        assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK and bool(torch.isfinite(again).all())
+        assert float((again - log_optimal_transport(s.double(), 1.0, 100).float()).abs().max()) < 5e-3
+        ctx.stats(reset=True)                                                     # back to the resident kernel for the other tests
     try:
         _stream_mode(True)
         out = E.log_optimal_transport(s.to(gpu), 1.0, 100).cpu()

@@ -15,7 +15,7 @@ for f in sys.argv[1:]:
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
         print(f.split('/')[-1], d['value'], d['ms_per_step'], d['roofline']['kernel'], round(d['roofline']['frac'], 4), d.get('families'),
-              [(a['mode'], a['value']) for a in d.get('other_precisions', [])], d.get('batch1_latency'), d.get('fallbacks'))
+              [(a['mode'], a['value']) for a in d.get('other_precisions', [])], d.get('batch1_latency'), d.get('range'))
     except Exception as e:
         print(f, 'FAILED', e)
         try: print(open(f.replace('.json', '.err')).read()[-1500:])
