@@ -479,6 +479,13 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                         for (int r = 0; r < 16; ++r) acc[j][i][r] *= f;
             }
             e_run = e_step;
+            // the NEXT tile's exponents: loaded beside the operand loads of K step 2, picked up at the head of step 3, right
+            // behind that step's vmcnt(0) - the wait hipcc attaches to the use is then free.  (Fetched at the tile boundary the
+            // wait would sit behind the epilogue's 32 stores and drain them.)
+            if (nk >= 4 && tile + slots < t_end) {
+                if (cur_kt == 2) ev_next = fetch_e(tile + slots);
+                if (cur_kt == 3) asm volatile("" : "+v"(ev_next));
+            }
         }
         ++cur_kt;
         const bool ldv = ld_valid && !(since == 0 && ahead) && !((DBG & 2) && dbg_steps >= 1);
@@ -519,7 +526,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
             ahead = true;
         }
         cur_kt = 0;
-        if (has_e && tile + slots < t_end) ev_next = fetch_e(tile + slots);  // (issued BEFORE the epilogue's stores)
+        if (has_e && nk < 4 && tile + slots < t_end) ev_next = fetch_e(tile + slots);
         if (!(DBG & 4)) epilogue(tile, e_run);
         else asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));
         ev = ev_next;

@@ -275,6 +275,7 @@ def test_f16x2_out_of_range_activations(gpu, split_always):
     assert not bool(torch.isfinite(out["scores_0_1"]).all())
     assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.EHIP and b"range" in ctx.lib.e2emv_last_error(ctx.h)
     assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK                # the report is consumed once
+    ctx.stats(reset=True)                                            # (the report moved the context's Sinkhorn to the log-domain chain: undo)
     model.config["check_finite"] = True                              # the same report as an exception from forward()
     with pytest.raises(_lib.E2EMVError), torch.no_grad():
         model(dg)

@@ -101,10 +101,10 @@ def main():
             W = torch.randn(N, K, device=dev) / K ** 0.5
             Afull = torch.cat([A, A2], 1) if A2 is not None else A
             ms_h2 = family(lambda n: [E.gemm_bf16x3(Afull, W, f16x2=True) for _ in range(n)], "gemm")
-            for planes_out in (False, True):
-                ms = family(lambda n: E.gemm_p2(A, W, A2=A2, planes_out=planes_out, reps=n), "gemm")
+            for planes_out, ex in ((False, False), (True, False), (True, True)):
+                ms = family(lambda n: E.gemm_p2(A, W, A2=A2, planes_out=planes_out, reps=n, exponents=ex), "gemm")
                 print(f"  {M:7d} {N:5d} {K:5d}  gemm_h2 {ms_h2 * 1e3:7.1f} us {2.0 * M * N * K / ms_h2 / 1e9:6.1f} TF | gemm_p2 "
-                      f"{'planes' if planes_out else 'fp32  '} out {ms * 1e3:7.1f} us {2.0 * M * N * K / ms / 1e9:6.1f} TF")
+                      f"{'planes' if planes_out else 'fp32  '} out{' + tile exponents' if ex else ''} {ms * 1e3:7.1f} us {2.0 * M * N * K / ms / 1e9:6.1f} TF")
         print("== f16x2 attention: attention_h2f (fp32 q|k|v) vs attention_p2 (plane operands)  -> us, TFLOP/s fp32-equivalent")
         for (B, N) in [(32, 1024), (8, 2048)]:
             qkv = torch.randn(B * 2, N, 768, device=dev)
