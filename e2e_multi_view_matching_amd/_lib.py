@@ -109,6 +109,10 @@ SIGNATURES = {
                               c_void_p]),
     "e2emv_qkv_p2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_attention_p2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "e2emv_train_commit": (c_int, [c_void_p, ctypes.POINTER(ModelDesc)]),
+    "e2emv_matcher_forward_train": (c_int, [c_void_p, ctypes.POINTER(ForwardDesc), _PP, _PP, _PP, _PP, c_void_p]),
+    "e2emv_matcher_backward": (c_int, [c_void_p, _PP, c_void_p]),
+    "e2emv_get_grad": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, c_void_p]),
     "e2emv_get_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_uint64), c_int, c_int]),
     "e2emv_profile": (c_int, [c_void_p, c_int]),
     "e2emv_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int64), c_int, c_int]),
@@ -170,6 +174,8 @@ class Context:
         # alternating on one device (checkpoint comparison, EMA copy) re-push instead of running on each other's weights.
         self.weights_owner = None
         self.sp_weights_owner = None
+        self.train_owner = None       # (module, fingerprint) whose weights e2emv_train_commit folded last
+        self.train_generation = 0     # bumped by every forward_train: the context keeps the tape of the LAST one only
         self.default_precision = self.precision()  # E2EMV_PRECISION at creation time (else f32)
         self.f16x2_kernels = 2 if os.environ.get("E2EMV_F16X2_KERNELS") == "r2" else 3
         self.default_f16x2_kernels = self.f16x2_kernels

@@ -132,6 +132,7 @@ struct e2emv_ctx {
     // arena).  Work of consecutive calls is ordered by the stream; when the caller switches streams the previous one is
     // drained first, because the arena contents of the earlier call may still be in use there.
     std::recursive_mutex mu;
+    void* train = nullptr;  // e2emv::TrainState (train.hip)
     hipStream_t last_stream = nullptr;
     bool have_last_stream = false;
     // profiling
@@ -181,6 +182,7 @@ struct CallGuard {
 // workspace: makes ctx->d_ws at least `bytes` large, growing the arena (synchronising) when needed; each
 // top-level entry point carves it with 256-byte aligned offsets.
 int ws_reserve(e2emv_ctx* ctx, size_t bytes);
+void train_free(e2emv_ctx* ctx);  // train.hip
 // ctx->d_flags (device words: [0] Sinkhorn give-up flag, [1] its sticky count, [2] plane blocks that needed a tile exponent)
 int ensure_flags(e2emv_ctx* ctx);
 // hipFuncAttributeMaxDynamicSharedMemorySize for kernels that use more than the default dynamic LDS: once per

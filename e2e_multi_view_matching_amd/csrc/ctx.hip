@@ -182,6 +182,7 @@ void e2emv_destroy(e2emv_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    e2emv::train_free(ctx);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_warena) (void)hipFree(ctx->d_warena);
     if (ctx->d_w3arena) (void)hipFree(ctx->d_w3arena);

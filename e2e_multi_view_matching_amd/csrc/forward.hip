@@ -17,24 +17,12 @@
 #include <algorithm>
 
 #include "common.h"
+#include "ingest.h"
 #include "p2.h"
 
 namespace e2emv {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-struct IngestParams {
-    const float* kpts[E2EMV_MAX_TUPLE];
-    const float* ksc[E2EMV_MAX_TUPLE];
-    const void* desc[E2EMV_MAX_TUPLE];
-    float img_w[E2EMV_MAX_TUPLE], img_h[E2EMV_MAX_TUPLE];
-    int B, T, n_rows, D, c0, f16;
-    int Nimg[E2EMV_MAX_TUPLE];  // keypoints of image t
-    const float* w0;
-    const float* b0;
-    float* x0;
-    float* h0;
-};
 
 // [B][D][N] (N contiguous) -> [img][n_rows][D] (D contiguous); rows >= N := 0
 __global__ __launch_bounds__(256) void ingest_transpose(IngestParams p) {
@@ -73,6 +61,7 @@ __global__ __launch_bounds__(256) void ingest_kenc0(IngestParams p) {
     const float kx = (p.kpts[t][((int64_t)b * Nn + row) * 2] - W / 2) / sc;
     const float ky = (p.kpts[t][((int64_t)b * Nn + row) * 2 + 1] - H / 2) / sc;
     const float ks = p.ksc[t][(int64_t)b * Nn + row];
+    if (p.inp) *reinterpret_cast<f32x4*>(p.inp + ((int64_t)img * p.n_rows + row) * 4) = f32x4{kx, ky, ks, 0.f};
     for (int c = 0; c < p.c0; c += 4) {
         f32x4 o;
 #pragma unroll

@@ -1,0 +1,628 @@
+// Training path, first slice (VERDICT r2 row g): the matcher forward with a tape and the backward of the match
+// loss, so that the reference's `run_matcher` -> `train_loss.backward()` (helpers.py:243-260, train.py:406-425, stage 1:
+// pose_loss = False) runs through this library.  Reference arithmetic: fp32 everywhere (the f32 kernels of the inference
+// path for the forward, train_kernels.h for the rest).
+//
+// What is differentiated: keypoint encoder, the L x {q|k|v projection, attention, merge, MLP}, final_proj, the score
+// matrix, the dustbin score and the unrolled log-domain Sinkhorn (the reverse sweep walks the stored u_t, v_t of every
+// iteration - the same gradient torch.autograd computes through upstream's log_optimal_transport, not an implicit
+// differentiation).  BatchNorm layers normalise with their RUNNING statistics (frozen-statistics fine-tuning; the
+// reference builds its DDP wrapper with broadcast_buffers=False "until BatchNorm stats are updated", train.py:351-356);
+// their affine parameters get gradients through the folded convolution.  Still forward-only: conf_mlp and the pose-loss
+// path (weighted 8-point), batch-statistics BatchNorm, ragged keypoint counts.
+//
+// The backward is a sequence of general fp32 MFMA GEMMs (dgrad: dY W, wgrad: dY^T X with the row contraction split over
+// workgroups) and row-wise kernels; the attention backward re-computes the probabilities from the saved q|k|v.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ingest.h"
+#include "train_kernels.h"
+
+namespace e2emv {
+
+struct TrainLayer {
+    size_t wqkv, bqkv, wm, bm, w0, b0, w1, b1;  // offsets (floats) into the folded arena: q|k|v [3D][D] head-major rows,
+    int type;                                    // merge [D][D] head-major columns, MLP0 [2D][2D] BN folded, MLP1 [D][2D]
+};
+
+struct RawRef {
+    size_t off, numel;
+};
+
+struct TrainState {
+    e2emv_model_desc model{};
+    // folded weights and their gradients (same offsets)
+    float* d_w = nullptr;
+    float* d_gw = nullptr;
+    size_t w_floats = 0;
+    std::vector<size_t> kw, kb;  // keypoint encoder layers 0..n (BN folded)
+    std::vector<int> kdims;      // [3, c0, ..., D]
+    std::vector<TrainLayer> layers;
+    size_t wf = 0, bf = 0, alpha = 0;
+    float bin_score = 1.f;
+    // upstream parameters (for the unfolding) and their gradients (same offsets)
+    float* d_raw = nullptr;
+    float* d_graw = nullptr;
+    size_t raw_floats = 0;
+    std::map<std::string, RawRef> raw;
+    int* d_maps = nullptr;  // [0, D): upstream channel -> head-major channel
+    // tape of the last forward
+    char* d_tape = nullptr;
+    size_t tape_bytes = 0;
+    bool have_tape = false;
+    int B = 0, T = 0, N = 0, n_rows = 0, iters = 0, P = 0, ldS = 0;
+    int64_t Mtot = 0;
+    float* t_inp = nullptr;               // [Mtot][4] normalised keypoints + score
+    std::vector<float*> t_kh;             // hidden activations of the keypoint encoder (post ReLU)
+    std::vector<float*> t_x;              // x_0 ... x_L
+    std::vector<float*> t_qkv, t_att, t_msg, t_h;
+    float* t_mdesc = nullptr;
+    float* t_S = nullptr;                 // [P*B][N][ldS]
+    float* t_uv = nullptr;                // [P*B][iters + 1][2][N + 1]: u_t, v_t (t = 0: zeros)
+};
+
+static TrainState* ts_of(e2emv_ctx* ctx) { return static_cast<TrainState*>(ctx->train); }
+
+void train_free(e2emv_ctx* ctx) {
+    TrainState* t = ts_of(ctx);
+    if (!t) return;
+    for (void* p : {(void*)t->d_w, (void*)t->d_gw, (void*)t->d_raw, (void*)t->d_graw, (void*)t->d_maps, (void*)t->d_tape})
+        if (p) (void)hipFree(p);
+    delete t;
+    ctx->train = nullptr;
+}
+
+static int launch_gg(e2emv_ctx* ctx, const GG& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) return E2EMV_OK;
+    dim3 grid((g.N + GG_T - 1) / GG_T, (g.M + GG_T - 1) / GG_T, g.batch * g.splits);
+    hipLaunchKernelGGL(gg_kernel, grid, dim3(256), 0, s, g);
+    E2EMV_CHECK_LAUNCH(ctx, "gg_kernel");
+    return E2EMV_OK;
+}
+
+// wgrad: dW [n_out][n_in] (row stride ldw) += dY^T X over `rows` rows (dY [rows][ldy], X [rows][ldx])
+static int wgrad(e2emv_ctx* ctx, const float* dY, int64_t ldy, int n_out, const float* X, int64_t ldx, int n_in, int64_t rows, float* dW, int64_t ldw,
+                 hipStream_t s) {
+    GG g;
+    g.M = n_out; g.N = n_in; g.K = (int)rows;
+    g.A = dY; g.am = 1; g.ak = ldy;
+    g.B = X; g.bk = ldx; g.bn = 1;
+    g.C = dW; g.ldc = ldw;
+    g.mode = 2;
+    g.splits = (int)std::max<int64_t>(1, std::min<int64_t>(256, rows / 512));
+    return launch_gg(ctx, g, s);
+}
+// dgrad: dX [rows][n_in] (row stride ldx) (+)= dY [rows][n_out] W [n_out][n_in]
+static int dgrad(e2emv_ctx* ctx, const float* dY, int64_t ldy, int n_out, const float* W, int64_t ldw, int n_in, int64_t rows, float* dX, int64_t ldx,
+                 bool accumulate, hipStream_t s) {
+    GG g;
+    g.M = (int)rows; g.N = n_in; g.K = n_out;
+    g.A = dY; g.am = ldy; g.ak = 1;
+    g.B = W; g.bk = ldw; g.bn = 1;
+    g.C = dX; g.ldc = ldx;
+    g.mode = accumulate ? 1 : 0;
+    return launch_gg(ctx, g, s);
+}
+static int colsum(e2emv_ctx* ctx, const float* X, int64_t rows, int N, int64_t ld, float* out, hipStream_t s) {
+    const int64_t per = 2048;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (unsigned)((rows + per - 1) / per)), dim3(256), 0, s, X, rows, N, ld, out, per);
+    E2EMV_CHECK_LAUNCH(ctx, "colsum_kernel");
+    return E2EMV_OK;
+}
+static unsigned ew_grid(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 4096); }
+
+}  // namespace e2emv
+
+using namespace e2emv;
+
+namespace {
+
+const HostTensor* findt(e2emv_ctx* ctx, const std::string& k) {
+    auto it = ctx->raw.find(k);
+    return it == ctx->raw.end() ? nullptr : &it->second;
+}
+
+struct Pack {
+    std::vector<float> host;
+    size_t add(const std::vector<float>& v) {
+        size_t off = (host.size() + 63) & ~size_t(63);
+        host.resize(off);
+        host.insert(host.end(), v.begin(), v.end());
+        return off;
+    }
+};
+
+// conv `prefix` [out][in] (+ the BatchNorm `bn` behind it when present) -> folded copies; the raw tensors go to `raw`
+int conv_bn(e2emv_ctx* ctx, TrainState* t, Pack& raw, const std::string& prefix, const std::string& bn, int out, int in, std::vector<float>& w,
+            std::vector<float>& b) {
+    const HostTensor* tw = findt(ctx, prefix + ".weight");
+    const HostTensor* tb = findt(ctx, prefix + ".bias");
+    if (!tw || !tb || (int64_t)tw->data.size() != (int64_t)out * in || (int)tb->data.size() != out)
+        return set_err(ctx, E2EMV_ESTATE, "train_commit: '%s.{weight,bias}' missing or not [%d,%d]", prefix.c_str(), out, in);
+    w = tw->data;
+    b = tb->data;
+    t->raw[prefix + ".weight"] = {raw.add(w), w.size()};
+    t->raw[prefix + ".bias"] = {raw.add(b), b.size()};
+    if (bn.empty()) return E2EMV_OK;
+    const HostTensor* mean = findt(ctx, bn + ".running_mean");
+    if (!mean) return E2EMV_OK;
+    const HostTensor* var = findt(ctx, bn + ".running_var");
+    const HostTensor* g = findt(ctx, bn + ".weight");
+    const HostTensor* be = findt(ctx, bn + ".bias");
+    if (!var || !g || !be || (int)mean->data.size() != out || (int)var->data.size() != out || (int)g->data.size() != out || (int)be->data.size() != out)
+        return set_err(ctx, E2EMV_ESHAPE, "train_commit: BatchNorm '%s' incomplete", bn.c_str());
+    t->raw[bn + ".weight"] = {raw.add(g->data), (size_t)out};
+    t->raw[bn + ".bias"] = {raw.add(be->data), (size_t)out};
+    t->raw[bn + ".running_mean"] = {raw.add(mean->data), (size_t)out};
+    t->raw[bn + ".running_var"] = {raw.add(var->data), (size_t)out};
+    for (int o = 0; o < out; ++o) {
+        const double sc = (double)g->data[o] / std::sqrt((double)var->data[o] + 1e-5);
+        for (int i = 0; i < in; ++i) w[(size_t)o * in + i] = (float)((double)w[(size_t)o * in + i] * sc);
+        b[o] = (float)(((double)b[o] - (double)mean->data[o]) * sc + (double)be->data[o]);
+    }
+    return E2EMV_OK;
+}
+
+}  // namespace
+
+extern "C" int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* m) {
+    if (!ctx || !m) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
+    const int D = m->desc_dim, H = m->num_heads;
+    if (D <= 0 || H <= 0 || D % H || D / H != 64) return set_err(ctx, E2EMV_ESHAPE, "train_commit: head dim must be 64 (D=%d H=%d)", D, H);
+    if (m->n_kenc < 1 || m->n_kenc > E2EMV_MAX_KENC || m->n_layers < 0 || m->n_layers > E2EMV_MAX_LAYERS) return set_err(ctx, E2EMV_ESHAPE, "train_commit: bad layer counts");
+    (void)hipSetDevice(ctx->device);
+    E2EMV_HIP(ctx, hipDeviceSynchronize());
+    train_free(ctx);
+    TrainState* t = new TrainState();
+    ctx->train = t;
+    t->model = *m;
+    const int d = D / H;
+    Pack pk, raw;
+    std::vector<float> w, b;
+    int rc;
+    t->kdims = {3};
+    for (int i = 0; i < m->n_kenc; ++i) t->kdims.push_back(m->kenc[i]);
+    t->kdims.push_back(D);
+    for (int c : t->kdims)
+        if (c > 2 * D || (c != 3 && c % 4)) return set_err(ctx, E2EMV_ESHAPE, "train_commit: encoder width %d", c);
+    const int nk = (int)t->kdims.size() - 1;
+    for (int i = 0; i < nk; ++i) {
+        const std::string pfx = "kenc.encoder." + std::to_string(3 * i);
+        if ((rc = conv_bn(ctx, t, raw, pfx, i < nk - 1 ? "kenc.encoder." + std::to_string(3 * i + 1) : std::string(), t->kdims[i + 1], t->kdims[i], w, b))) return rc;
+        t->kw.push_back(pk.add(w));
+        t->kb.push_back(pk.add(b));
+    }
+    t->layers.resize(m->n_layers);
+    for (int l = 0; l < m->n_layers; ++l) {
+        TrainLayer& L = t->layers[l];
+        L.type = m->layer_types[l] ? 1 : 0;
+        const std::string base = "gnn.layers." + std::to_string(l);
+        std::vector<float> wqkv((size_t)3 * D * D), bqkv((size_t)3 * D);
+        for (int p = 0; p < 3; ++p) {
+            if ((rc = conv_bn(ctx, t, raw, base + ".attn.proj." + std::to_string(p), "", D, D, w, b))) return rc;
+            for (int h = 0; h < H; ++h)
+                for (int dd = 0; dd < d; ++dd) {
+                    const int src = dd * H + h, dst = p * D + h * d + dd;
+                    memcpy(&wqkv[(size_t)dst * D], &w[(size_t)src * D], sizeof(float) * D);
+                    bqkv[dst] = b[src];
+                }
+        }
+        L.wqkv = pk.add(wqkv);
+        L.bqkv = pk.add(bqkv);
+        if ((rc = conv_bn(ctx, t, raw, base + ".attn.merge", "", D, D, w, b))) return rc;
+        std::vector<float> wm((size_t)D * D);
+        for (int o = 0; o < D; ++o)
+            for (int h = 0; h < H; ++h)
+                for (int dd = 0; dd < d; ++dd) wm[(size_t)o * D + h * d + dd] = w[(size_t)o * D + dd * H + h];
+        L.wm = pk.add(wm);
+        L.bm = pk.add(b);
+        if ((rc = conv_bn(ctx, t, raw, base + ".mlp.0", base + ".mlp.1", 2 * D, 2 * D, w, b))) return rc;
+        L.w0 = pk.add(w);
+        L.b0 = pk.add(b);
+        if ((rc = conv_bn(ctx, t, raw, base + ".mlp.3", "", D, 2 * D, w, b))) return rc;
+        L.w1 = pk.add(w);
+        L.b1 = pk.add(b);
+    }
+    if ((rc = conv_bn(ctx, t, raw, "final_proj", "", D, D, w, b))) return rc;
+    t->wf = pk.add(w);
+    t->bf = pk.add(b);
+    const HostTensor* bs = findt(ctx, "bin_score");
+    if (!bs || bs->data.size() != 1) return set_err(ctx, E2EMV_ESTATE, "train_commit: missing scalar 'bin_score'");
+    t->bin_score = bs->data[0];
+    t->alpha = pk.add(std::vector<float>{bs->data[0]});
+    t->raw["bin_score"] = {raw.add(bs->data), 1};
+    t->w_floats = pk.host.size();
+    t->raw_floats = raw.host.size();
+    E2EMV_HIP(ctx, hipMalloc((void**)&t->d_w, t->w_floats * sizeof(float)));
+    E2EMV_HIP(ctx, hipMalloc((void**)&t->d_gw, t->w_floats * sizeof(float)));
+    E2EMV_HIP(ctx, hipMalloc((void**)&t->d_raw, t->raw_floats * sizeof(float)));
+    E2EMV_HIP(ctx, hipMalloc((void**)&t->d_graw, t->raw_floats * sizeof(float)));
+    E2EMV_HIP(ctx, hipMemcpy(t->d_w, pk.host.data(), t->w_floats * sizeof(float), hipMemcpyHostToDevice));
+    E2EMV_HIP(ctx, hipMemcpy(t->d_raw, raw.host.data(), t->raw_floats * sizeof(float), hipMemcpyHostToDevice));
+    E2EMV_HIP(ctx, hipMemset(t->d_graw, 0, t->raw_floats * sizeof(float)));
+    std::vector<int> map(D);
+    for (int h = 0; h < H; ++h)
+        for (int dd = 0; dd < d; ++dd) map[dd * H + h] = h * d + dd;
+    E2EMV_HIP(ctx, hipMalloc((void**)&t->d_maps, D * sizeof(int)));
+    E2EMV_HIP(ctx, hipMemcpy(t->d_maps, map.data(), D * sizeof(int), hipMemcpyHostToDevice));
+    return E2EMV_OK;
+}
+
+static size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
+
+extern "C" int e2emv_matcher_forward_train(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const float* const* d_kpts, const float* const* d_kscores,
+                                           const void* const* d_desc, float* const* d_logZ, void* stream) {
+    if (!ctx || !fd || !d_kpts || !d_kscores || !d_desc || !d_logZ) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    TrainState* t = ts_of(ctx);
+    if (!t) return set_err(ctx, E2EMV_ESTATE, "matcher_forward_train: e2emv_train_commit first");
+    const int B = fd->batch, T = fd->tuple_size, N = fd->n_kpts;
+    const int D = t->model.desc_dim, H = t->model.num_heads, L = (int)t->layers.size();
+    if (B <= 0 || T < 2 || T > E2EMV_MAX_TUPLE || N <= 0 || N > 2048) return set_err(ctx, E2EMV_ESHAPE, "matcher_forward_train: batch=%d tuple_size=%d n_kpts=%d", B, T, N);
+    if (T > 2 && !(fd->flags & E2EMV_FLAG_MULTI_FRAME)) return set_err(ctx, E2EMV_ESHAPE, "matcher_forward_train: tuples of more than 2 images need multi_frame_matching");
+    for (int i = 0; i < T; ++i)
+        if (fd->n_kpts_img[i] > 0 && fd->n_kpts_img[i] != N) return set_err(ctx, E2EMV_ESHAPE, "matcher_forward_train: all images of a call carry the same number of keypoints");
+    if (fd->sinkhorn_iters < 0) return set_err(ctx, E2EMV_EINVAL, "negative sinkhorn_iters");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int n_rows = (N + 127) / 128 * 128, n_img = B * T, P = T * (T - 1) / 2, iters = fd->sinkhorn_iters, ldS = (N + 3) / 4 * 4;
+    const int64_t Mtot = (int64_t)n_img * n_rows;
+    const int nk = (int)t->kdims.size() - 1;
+    // ---- tape ----
+    size_t need = al256((size_t)Mtot * 4 * 4);
+    for (int i = 1; i < nk; ++i) need += al256((size_t)Mtot * t->kdims[i] * 4);
+    need += (size_t)(L + 1) * al256((size_t)Mtot * D * 4) + (size_t)L * (al256((size_t)Mtot * 3 * D * 4) + 2 * al256((size_t)Mtot * D * 4) + al256((size_t)Mtot * 2 * D * 4));
+    need += al256((size_t)Mtot * D * 4) + al256((size_t)P * B * N * ldS * 4) + al256((size_t)P * B * (iters + 1) * 2 * (N + 1) * 4);
+    if (need > t->tape_bytes) {
+        E2EMV_HIP(ctx, hipDeviceSynchronize());
+        if (t->d_tape) E2EMV_HIP(ctx, hipFree(t->d_tape));
+        t->d_tape = nullptr;
+        t->tape_bytes = 0;
+        if (hipMalloc((void**)&t->d_tape, need) != hipSuccess) {
+            (void)hipGetLastError();
+            return set_err(ctx, E2EMV_ENOMEM, "matcher_forward_train: tape of %zu bytes", need);
+        }
+        t->tape_bytes = need;
+    }
+    E2EMV_HIP(ctx, hipMemsetAsync(t->d_tape, 0, need, s));  // padded rows must be finite zeros wherever a GEMM does not write them
+    char* w = t->d_tape;
+    auto take = [&](size_t bytes) { float* p = (float*)w; w += al256(bytes); return p; };
+    t->t_inp = take((size_t)Mtot * 4 * 4);
+    t->t_kh.assign(nk, nullptr);
+    for (int i = 1; i < nk; ++i) t->t_kh[i] = take((size_t)Mtot * t->kdims[i] * 4);  // t_kh[i]: output of encoder layer i - 1 (width kdims[i])
+    t->t_x.assign(L + 1, nullptr);
+    for (int l = 0; l <= L; ++l) t->t_x[l] = take((size_t)Mtot * D * 4);
+    t->t_qkv.assign(L, nullptr); t->t_att.assign(L, nullptr); t->t_msg.assign(L, nullptr); t->t_h.assign(L, nullptr);
+    for (int l = 0; l < L; ++l) {
+        t->t_qkv[l] = take((size_t)Mtot * 3 * D * 4);
+        t->t_att[l] = take((size_t)Mtot * D * 4);
+        t->t_msg[l] = take((size_t)Mtot * D * 4);
+        t->t_h[l] = take((size_t)Mtot * 2 * D * 4);
+    }
+    t->t_mdesc = take((size_t)Mtot * D * 4);
+    t->t_S = take((size_t)P * B * N * ldS * 4);
+    t->t_uv = take((size_t)P * B * (iters + 1) * 2 * (N + 1) * 4);
+    t->B = B; t->T = T; t->N = N; t->n_rows = n_rows; t->iters = iters; t->P = P; t->ldS = ldS; t->Mtot = Mtot;
+    t->have_tape = false;
+
+    // ---- ingest: descriptors -> x_0 (desc part), keypoints -> encoder layer 0 ----
+    int Nt[E2EMV_MAX_TUPLE] = {0};
+    IngestParams ip{};
+    for (int i = 0; i < T; ++i) {
+        if (!d_kpts[i] || !d_kscores[i] || !d_desc[i]) return set_err(ctx, E2EMV_EINVAL, "matcher_forward_train: null input for image %d", i);
+        ip.kpts[i] = d_kpts[i]; ip.ksc[i] = d_kscores[i]; ip.desc[i] = d_desc[i];
+        ip.img_w[i] = fd->img_w[i]; ip.img_h[i] = fd->img_h[i];
+        ip.Nimg[i] = N; Nt[i] = N;
+    }
+    ip.B = B; ip.T = T; ip.n_rows = n_rows; ip.D = D; ip.c0 = t->kdims[1]; ip.f16 = fd->desc_dtype == E2EMV_DESC_F16;
+    ip.w0 = t->d_w + t->kw[0]; ip.b0 = t->d_w + t->kb[0]; ip.x0 = t->t_x[0]; ip.h0 = t->t_kh[1]; ip.inp = t->t_inp;
+    hipLaunchKernelGGL(ingest_transpose, dim3(n_rows / 64, D / 64, n_img), dim3(256), 0, s, ip);
+    hipLaunchKernelGGL(ingest_kenc0, dim3((n_rows + 255) / 256, n_img), dim3(256), 0, s, ip);
+    E2EMV_CHECK_LAUNCH(ctx, "ingest kernels");
+    int rc;
+    // encoder layers 1 .. nk-1; the last adds the descriptors (x_0 = desc + kenc)
+    for (int i = 1; i < nk; ++i) {
+        const int cin = t->kdims[i], cout = t->kdims[i + 1];
+        const bool last = i == nk - 1;
+        GemmArgs g;
+        g.M = (int)Mtot; g.N = cout; g.K = cin; g.K1 = cin; g.A = t->t_kh[i]; g.lda = cin;
+        g.W = t->d_w + t->kw[i]; g.ldw = cin; g.bias = t->d_w + t->kb[i]; g.relu = !last;
+        if (last) { g.R = t->t_x[0]; g.ldr = D; g.C = t->t_x[0]; g.ldc = D; }
+        else { g.C = t->t_kh[i + 1]; g.ldc = cout; }
+        if ((rc = launch_gemm_nt(ctx, g, s))) return rc;
+    }
+    // ---- attentional GNN (merge NOT folded: its parameters get their own gradients) ----
+    for (int l = 0; l < L; ++l) {
+        const TrainLayer& Lw = t->layers[l];
+        GemmArgs g;
+        g.M = (int)Mtot; g.N = 3 * D; g.K = D; g.K1 = D; g.A = t->t_x[l]; g.lda = D; g.W = t->d_w + Lw.wqkv; g.ldw = D; g.bias = t->d_w + Lw.bqkv;
+        g.C = t->t_qkv[l]; g.ldc = 3 * D;
+        if ((rc = launch_gemm_nt(ctx, g, s))) return rc;
+        if ((rc = launch_attention(ctx, B, T, n_rows, Nt, D, H, t->t_qkv[l], Lw.type, t->t_att[l], s))) return rc;
+        g = GemmArgs();
+        g.M = (int)Mtot; g.N = D; g.K = D; g.K1 = D; g.A = t->t_att[l]; g.lda = D; g.W = t->d_w + Lw.wm; g.ldw = D; g.bias = t->d_w + Lw.bm;
+        g.C = t->t_msg[l]; g.ldc = D;
+        if ((rc = launch_gemm_nt(ctx, g, s))) return rc;
+        g = GemmArgs();
+        g.M = (int)Mtot; g.N = 2 * D; g.K = 2 * D; g.K1 = D; g.A = t->t_x[l]; g.lda = D; g.A2 = t->t_msg[l]; g.lda2 = D;
+        g.W = t->d_w + Lw.w0; g.ldw = 2 * D; g.bias = t->d_w + Lw.b0; g.relu = true; g.C = t->t_h[l]; g.ldc = 2 * D;
+        if ((rc = launch_gemm_nt(ctx, g, s))) return rc;
+        g = GemmArgs();
+        g.M = (int)Mtot; g.N = D; g.K = 2 * D; g.K1 = 2 * D; g.A = t->t_h[l]; g.lda = 2 * D; g.W = t->d_w + Lw.w1; g.ldw = 2 * D; g.bias = t->d_w + Lw.b1;
+        g.R = t->t_x[l]; g.ldr = D; g.C = t->t_x[l + 1]; g.ldc = D;
+        if ((rc = launch_gemm_nt(ctx, g, s))) return rc;
+    }
+    {
+        GemmArgs g;
+        g.M = (int)Mtot; g.N = D; g.K = D; g.K1 = D; g.A = t->t_x[L]; g.lda = D; g.W = t->d_w + t->wf; g.ldw = D; g.bias = t->d_w + t->bf;
+        g.C = t->t_mdesc; g.ldc = D;
+        if ((rc = launch_gemm_nt(ctx, g, s))) return rc;
+    }
+    // ---- scores, Sinkhorn (log domain, u_t / v_t of every iteration kept), log assignment ----
+    const int64_t tuple_stride = (int64_t)T * n_rows * D;
+    SkT sk{};
+    sk.ldS = ldS; sk.M = N; sk.N = N; sk.alpha = t->bin_score; sk.norm = -logf((float)(2 * N)); sk.logM = logf((float)N); sk.logN = logf((float)N);
+    const int64_t uvs = (int64_t)(iters + 1) * 2 * (N + 1);  // per problem
+    int pidx = 0;
+    for (int j = 0; j < T; ++j)
+        for (int i = 0; i < j; ++i, ++pidx) {
+            float* S = t->t_S + (int64_t)pidx * B * N * ldS;
+            GemmArgs g;
+            g.batch = B; g.M = N; g.N = N; g.K = D; g.K1 = D;
+            g.A = t->t_mdesc + (int64_t)i * n_rows * D; g.lda = D; g.sA = tuple_stride;
+            g.W = t->t_mdesc + (int64_t)j * n_rows * D; g.ldw = D; g.sW = tuple_stride;
+            g.C = S; g.ldc = ldS; g.sC = (int64_t)N * ldS;
+            g.scale = 1.0f / sqrtf((float)D);
+            if ((rc = launch_gemm_nt(ctx, g, s))) return rc;
+            sk.S = S;
+            float* uv = t->t_uv + (int64_t)pidx * B * uvs;  // [b][t][{u, v}][N + 1]
+            for (int it = 1; it <= iters; ++it) {
+                float* u_t = uv + (int64_t)it * 2 * (N + 1);
+                float* v_t = u_t + (N + 1);
+                const float* v_p = uv + (int64_t)(it - 1) * 2 * (N + 1) + (N + 1);
+                hipLaunchKernelGGL(skt_row_kernel, dim3((N + 1 + 3) / 4, B), dim3(256), 0, s, sk, v_p, u_t, uvs, uvs);
+                hipLaunchKernelGGL(skt_col_kernel, dim3((N + 1 + 255) / 256, B), dim3(256), 0, s, sk, (const float*)u_t, v_t, uvs, uvs);
+            }
+            if (!d_logZ[pidx]) return set_err(ctx, E2EMV_EINVAL, "matcher_forward_train: null logZ for pair %d", pidx);
+            const float* u_T = uv + (int64_t)iters * 2 * (N + 1);
+            hipLaunchKernelGGL(skt_out_kernel, dim3(ew_grid((int64_t)(N + 1) * (N + 1)), B), dim3(256), 0, s, sk, u_T, u_T + (N + 1), uvs, uvs, d_logZ[pidx]);
+            E2EMV_CHECK_LAUNCH(ctx, "sinkhorn training kernels");
+        }
+    t->have_tape = true;
+    return E2EMV_OK;
+}
+
+// attention backward of one layer: d att [Mtot][D] -> dqkv [Mtot][3D] (zeroed here); P / dP: scratch [B*H][N][ldP] each
+static int attention_backward(e2emv_ctx* ctx, TrainState* t, int l, const float* datt, float* dqkv, float* Pb, float* dPb, hipStream_t s) {
+    const int B = t->B, T = t->T, N = t->N, n_rows = t->n_rows, D = t->model.desc_dim, H = t->model.num_heads;
+    const bool cross = t->layers[l].type != 0;
+    const float* qkv = t->t_qkv[l];
+    const int n_src = cross ? T - 1 : 1;
+    const int64_t ldP = (int64_t)n_src * N;
+    const int64_t img3 = (int64_t)n_rows * 3 * D, img1 = (int64_t)n_rows * D;
+    E2EMV_HIP(ctx, hipMemsetAsync(dqkv, 0, (size_t)t->Mtot * 3 * D * sizeof(float), s));
+    int rc;
+    for (int tq = 0; tq < T; ++tq) {
+        auto src_of = [&](int si) { return !cross ? tq : (si < tq ? si : si + 1); };
+        for (int pass = 0; pass < 2; ++pass)  // P = q k^T / 8 (pass 0), dP = dO v^T (pass 1)
+            for (int si = 0; si < n_src; ++si) {
+                const int ts = src_of(si);
+                GG g;
+                g.batch = B * H; g.inner = H; g.M = N; g.N = N; g.K = 64;
+                if (pass == 0) { g.A = qkv + tq * img3; g.am = 3 * D; g.az0 = T * img3; g.az1 = 64; g.alpha = 0.125f; }
+                else { g.A = datt + tq * img1; g.am = D; g.az0 = T * img1; g.az1 = 64; }
+                g.ak = 1;
+                g.B = qkv + ts * img3 + (pass == 0 ? D : 2 * D); g.bk = 1; g.bn = 3 * D; g.bz0 = T * img3; g.bz1 = 64;
+                g.C = (pass == 0 ? Pb : dPb) + (int64_t)si * N; g.ldc = ldP; g.cz0 = (int64_t)H * N * ldP; g.cz1 = (int64_t)N * ldP;
+                if ((rc = launch_gg(ctx, g, s))) return rc;
+            }
+        hipLaunchKernelGGL(softmax_rows_kernel, dim3((N + 3) / 4, B * H), dim3(256), 0, s, Pb, N, (int)ldP, ldP, (int64_t)N * ldP);
+        hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((N + 3) / 4, B * H), dim3(256), 0, s, (const float*)Pb, dPb, N, (int)ldP, ldP, (int64_t)N * ldP, 0.125f);
+        E2EMV_CHECK_LAUNCH(ctx, "softmax backward kernels");
+        for (int si = 0; si < n_src; ++si) {
+            const int ts = src_of(si);
+            GG g;  // dq += dS k
+            g.batch = B * H; g.inner = H; g.M = N; g.N = 64; g.K = N;
+            g.A = dPb + (int64_t)si * N; g.am = ldP; g.ak = 1; g.az0 = (int64_t)H * N * ldP; g.az1 = (int64_t)N * ldP;
+            g.B = qkv + ts * img3 + D; g.bk = 3 * D; g.bn = 1; g.bz0 = T * img3; g.bz1 = 64;
+            g.C = dqkv + tq * img3; g.ldc = 3 * D; g.cz0 = T * img3; g.cz1 = 64; g.mode = 1;
+            if ((rc = launch_gg(ctx, g, s))) return rc;
+            g = GG();  // dk += dS^T q
+            g.batch = B * H; g.inner = H; g.M = N; g.N = 64; g.K = N;
+            g.A = dPb + (int64_t)si * N; g.am = 1; g.ak = ldP; g.az0 = (int64_t)H * N * ldP; g.az1 = (int64_t)N * ldP;
+            g.B = qkv + tq * img3; g.bk = 3 * D; g.bn = 1; g.bz0 = T * img3; g.bz1 = 64;
+            g.C = dqkv + ts * img3 + D; g.ldc = 3 * D; g.cz0 = T * img3; g.cz1 = 64; g.mode = 1;
+            if ((rc = launch_gg(ctx, g, s))) return rc;
+            g = GG();  // dv += P^T dO
+            g.batch = B * H; g.inner = H; g.M = N; g.N = 64; g.K = N;
+            g.A = Pb + (int64_t)si * N; g.am = 1; g.ak = ldP; g.az0 = (int64_t)H * N * ldP; g.az1 = (int64_t)N * ldP;
+            g.B = datt + tq * img1; g.bk = D; g.bn = 1; g.bz0 = T * img1; g.bz1 = 64;
+            g.C = dqkv + ts * img3 + 2 * D; g.ldc = 3 * D; g.cz0 = T * img3; g.cz1 = 64; g.mode = 1;
+            if ((rc = launch_gg(ctx, g, s))) return rc;
+        }
+    }
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_matcher_backward(e2emv_ctx* ctx, const float* const* d_dlogZ, void* stream) {
+    if (!ctx || !d_dlogZ) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    TrainState* t = ts_of(ctx);
+    if (!t || !t->have_tape) return set_err(ctx, E2EMV_ESTATE, "matcher_backward: no tape - e2emv_matcher_forward_train first");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int B = t->B, T = t->T, N = t->N, n_rows = t->n_rows, iters = t->iters, P = t->P, ldS = t->ldS;
+    const int D = t->model.desc_dim, H = t->model.num_heads, L = (int)t->layers.size();
+    const int64_t Mtot = t->Mtot;
+    const int nk = (int)t->kdims.size() - 1;
+    const int n_src_max = T > 2 ? T - 1 : 1;
+    // ---- workspace ----
+    const size_t sz_x = al256((size_t)Mtot * D * 4), sz_2 = al256((size_t)Mtot * 2 * D * 4), sz_3 = al256((size_t)Mtot * 3 * D * 4);
+    const size_t sz_C = al256((size_t)B * (N + 1) * (N + 1) * 4), sz_v = al256((size_t)B * (N + 1) * 4);
+    const size_t sz_P = al256((size_t)B * H * N * n_src_max * N * 4);
+    const size_t need = 3 * sz_x + 2 * sz_2 + sz_3 + sz_C + 3 * sz_v + 2 * sz_P + 4096;
+    int rc = ws_reserve(ctx, need);
+    if (rc) return rc;
+    char* w = ctx->d_ws;
+    auto take = [&](size_t bytes) { float* p = (float*)w; w += bytes; return p; };
+    float* dx = take(sz_x);
+    float* datt = take(sz_x);
+    float* dmd = take(sz_x);
+    float* dh = take(sz_2);
+    float* dcat = take(sz_2);
+    float* dqkv = take(sz_3);
+    float* dC = take(sz_C);
+    float* du = take(sz_v);
+    float* dv = take(sz_v);
+    float* dv2 = take(sz_v);
+    float* Pb = take(sz_P);
+    float* dPb = take(sz_P);
+    float* gw = t->d_gw;
+    const float* W = t->d_w;
+    E2EMV_HIP(ctx, hipMemsetAsync(gw, 0, t->w_floats * sizeof(float), s));
+    E2EMV_HIP(ctx, hipMemsetAsync(dmd, 0, (size_t)Mtot * D * sizeof(float), s));
+    // ---- Sinkhorn reverse sweep and the score matrix, per pair ----
+    const int64_t tuple_stride = (int64_t)T * n_rows * D;
+    SkT sk{};
+    sk.ldS = ldS; sk.M = N; sk.N = N; sk.alpha = t->bin_score; sk.norm = -logf((float)(2 * N)); sk.logM = logf((float)N); sk.logN = logf((float)N);
+    const int64_t uvs = (int64_t)(iters + 1) * 2 * (N + 1);
+    const int64_t per = (int64_t)(N + 1) * (N + 1);
+    int pidx = 0;
+    for (int j = 0; j < T; ++j)
+        for (int i = 0; i < j; ++i, ++pidx) {
+            if (!d_dlogZ[pidx]) continue;  // no gradient reaches this pair's scores
+            sk.S = t->t_S + (int64_t)pidx * B * N * ldS;
+            const float* uv = t->t_uv + (int64_t)pidx * B * uvs;
+            E2EMV_HIP(ctx, hipMemsetAsync(dv, 0, (size_t)B * (N + 1) * sizeof(float), s));
+            hipLaunchKernelGGL(skb_init_kernel, dim3((N + 1 + 3) / 4, B), dim3(256), 0, s, N, N, d_dlogZ[pidx], dC, du, dv, (int64_t)(N + 1), (int64_t)(N + 1));
+            float* dv_cur = dv;
+            float* dv_nxt = dv2;
+            for (int it = iters; it >= 1; --it) {
+                const float* u_t = uv + (int64_t)it * 2 * (N + 1);
+                const float* v_t = u_t + (N + 1);
+                const float* v_p = uv + (int64_t)(it - 1) * 2 * (N + 1) + (N + 1);
+                hipLaunchKernelGGL(skb_vhalf_kernel, dim3((N + 1 + 3) / 4, B), dim3(256), 0, s, sk, u_t, v_t, (const float*)dv_cur, du, dC, uvs, uvs, (int64_t)(N + 1));
+                hipLaunchKernelGGL(skb_uhalf_kernel, dim3((N + 1 + 255) / 256, B), dim3(256), 0, s, sk, u_t, v_p, (const float*)du, dv_nxt, dC, uvs, uvs, (int64_t)(N + 1));
+                E2EMV_HIP(ctx, hipMemsetAsync(du, 0, (size_t)B * (N + 1) * sizeof(float), s));
+                std::swap(dv_cur, dv_nxt);
+            }
+            E2EMV_CHECK_LAUNCH(ctx, "sinkhorn backward kernels");
+            hipLaunchKernelGGL(skb_alpha_kernel, dim3(B), dim3(256), 0, s, N, N, (const float*)dC, gw + t->alpha);
+            // scores = md_i md_j^T / sqrt(D):  d md_i += dS md_j / sqrt(D),  d md_j += dS^T md_i / sqrt(D)
+            const float sc = 1.0f / sqrtf((float)D);
+            GG g;
+            g.batch = B; g.M = N; g.N = D; g.K = N;
+            g.A = dC; g.am = N + 1; g.ak = 1; g.az0 = per;
+            g.B = t->t_mdesc + (int64_t)j * n_rows * D; g.bk = D; g.bn = 1; g.bz0 = tuple_stride;
+            g.C = dmd + (int64_t)i * n_rows * D; g.ldc = D; g.cz0 = tuple_stride; g.alpha = sc; g.mode = 1;
+            if ((rc = launch_gg(ctx, g, s))) return rc;
+            g = GG();
+            g.batch = B; g.M = N; g.N = D; g.K = N;
+            g.A = dC; g.am = 1; g.ak = N + 1; g.az0 = per;
+            g.B = t->t_mdesc + (int64_t)i * n_rows * D; g.bk = D; g.bn = 1; g.bz0 = tuple_stride;
+            g.C = dmd + (int64_t)j * n_rows * D; g.ldc = D; g.cz0 = tuple_stride; g.alpha = sc; g.mode = 1;
+            if ((rc = launch_gg(ctx, g, s))) return rc;
+        }
+    // ---- final_proj ----
+    if ((rc = wgrad(ctx, dmd, D, D, t->t_x[L], D, D, Mtot, gw + t->wf, D, s))) return rc;
+    if ((rc = colsum(ctx, dmd, Mtot, D, D, gw + t->bf, s))) return rc;
+    if ((rc = dgrad(ctx, dmd, D, D, W + t->wf, D, D, Mtot, dx, D, false, s))) return rc;
+    // ---- GNN layers, last to first; dx = d x_{l+1} on entry, d x_l on exit ----
+    for (int l = L - 1; l >= 0; --l) {
+        const TrainLayer& Lw = t->layers[l];
+        // x_{l+1} = x_l + W1 h + b1
+        if ((rc = dgrad(ctx, dx, D, D, W + Lw.w1, 2 * D, 2 * D, Mtot, dh, 2 * D, false, s))) return rc;
+        if ((rc = wgrad(ctx, dx, D, D, t->t_h[l], 2 * D, 2 * D, Mtot, gw + Lw.w1, 2 * D, s))) return rc;
+        if ((rc = colsum(ctx, dx, Mtot, D, D, gw + Lw.b1, s))) return rc;
+        // h = relu(W0 [x_l | msg] + b0)
+        hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(Mtot * 2 * D)), dim3(256), 0, s, dh, (const float*)t->t_h[l], Mtot * 2 * D);
+        if ((rc = dgrad(ctx, dh, 2 * D, 2 * D, W + Lw.w0, 2 * D, 2 * D, Mtot, dcat, 2 * D, false, s))) return rc;
+        if ((rc = wgrad(ctx, dh, 2 * D, 2 * D, t->t_x[l], D, D, Mtot, gw + Lw.w0, 2 * D, s))) return rc;
+        if ((rc = wgrad(ctx, dh, 2 * D, 2 * D, t->t_msg[l], D, D, Mtot, gw + Lw.w0 + D, 2 * D, s))) return rc;
+        if ((rc = colsum(ctx, dh, Mtot, 2 * D, 2 * D, gw + Lw.b0, s))) return rc;
+        hipLaunchKernelGGL(add2d_kernel, dim3(ew_grid(Mtot * D)), dim3(256), 0, s, dx, (int64_t)D, (const float*)dcat, (int64_t)2 * D, Mtot, D);
+        // msg = Wm att + bm   (d msg = dcat[:, D:])
+        if ((rc = dgrad(ctx, dcat + D, 2 * D, D, W + Lw.wm, D, D, Mtot, datt, D, false, s))) return rc;
+        if ((rc = wgrad(ctx, dcat + D, 2 * D, D, t->t_att[l], D, D, Mtot, gw + Lw.wm, D, s))) return rc;
+        if ((rc = colsum(ctx, dcat + D, Mtot, D, 2 * D, gw + Lw.bm, s))) return rc;
+        // att = attention(q|k|v)
+        if ((rc = attention_backward(ctx, t, l, datt, dqkv, Pb, dPb, s))) return rc;
+        // q|k|v = Wqkv x_l + b
+        if ((rc = dgrad(ctx, dqkv, 3 * D, 3 * D, W + Lw.wqkv, D, D, Mtot, dx, D, true, s))) return rc;
+        if ((rc = wgrad(ctx, dqkv, 3 * D, 3 * D, t->t_x[l], D, D, Mtot, gw + Lw.wqkv, D, s))) return rc;
+        if ((rc = colsum(ctx, dqkv, Mtot, 3 * D, 3 * D, gw + Lw.bqkv, s))) return rc;
+        E2EMV_CHECK_LAUNCH(ctx, "layer backward kernels");
+    }
+    // ---- keypoint encoder: x_0 = desc + kenc(keypoints); dx = d kenc output ----
+    {
+        float* cur = dx;  // gradient w.r.t. the output of encoder layer i (width kdims[i + 1])
+        float* bufs[2] = {dh, dcat};
+        int bi = 0;
+        for (int i = nk - 1; i >= 1; --i) {
+            const int cin = t->kdims[i], cout = t->kdims[i + 1];
+            if (i < nk - 1) hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(Mtot * cout)), dim3(256), 0, s, cur, (const float*)t->t_kh[i + 1], Mtot * cout);
+            if ((rc = wgrad(ctx, cur, cout, cout, t->t_kh[i], cin, cin, Mtot, gw + t->kw[i], cin, s))) return rc;
+            if ((rc = colsum(ctx, cur, Mtot, cout, cout, gw + t->kb[i], s))) return rc;
+            if ((rc = dgrad(ctx, cur, cout, cout, W + t->kw[i], cin, cin, Mtot, bufs[bi], cin, false, s))) return rc;
+            cur = bufs[bi];
+            bi ^= 1;
+        }
+        // layer 0: 3 -> c0 (+ BN folded, ReLU); its input is re-derived from the keypoints: not kept, the gradient w.r.t. it is not needed
+        const int c0 = t->kdims[1];
+        hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(Mtot * c0)), dim3(256), 0, s, cur, (const float*)t->t_kh[1], Mtot * c0);
+        if ((rc = wgrad(ctx, cur, c0, c0, t->t_inp, 4, 3, Mtot, gw + t->kw[0], 3, s))) return rc;
+        if ((rc = colsum(ctx, cur, Mtot, c0, c0, gw + t->kb[0], s))) return rc;
+        E2EMV_CHECK_LAUNCH(ctx, "encoder backward kernels");
+    }
+    // ---- folded gradients -> gradients of the upstream parameters ----
+    auto ref = [&](const std::string& k) -> float* { auto it = t->raw.find(k); return it == t->raw.end() ? nullptr : t->d_raw + it->second.off; };
+    auto gref = [&](const std::string& k) -> float* { auto it = t->raw.find(k); return it == t->raw.end() ? nullptr : t->d_graw + it->second.off; };
+    auto unfold = [&](const std::string& conv, const std::string& bn, const float* dWf, const float* dbf, int64_t ldwf, int col0, int rows, int cols, const int* rmap,
+                      int rbase, const int* cmap) {
+        UnfoldArgs a{};
+        a.dWf = dWf + (int64_t)rbase * ldwf; a.dbf = dbf + rbase; a.ldwf = ldwf; a.col0 = col0;
+        a.W = ref(conv + ".weight"); a.b = ref(conv + ".bias");
+        if (!bn.empty() && ref(bn + ".running_mean")) {
+            a.gamma = ref(bn + ".weight"); a.beta = ref(bn + ".bias"); a.mean = ref(bn + ".running_mean"); a.var = ref(bn + ".running_var");
+            a.dgamma = gref(bn + ".weight"); a.dbeta = gref(bn + ".bias");
+        }
+        a.rmap = rmap; a.cmap = cmap; a.rows = rows; a.cols = cols;
+        a.dW = gref(conv + ".weight"); a.db = gref(conv + ".bias");
+        hipLaunchKernelGGL(unfold_kernel, dim3(rows), dim3(256), 0, s, a);
+    };
+    for (int i = 0; i < nk; ++i)
+        unfold("kenc.encoder." + std::to_string(3 * i), i < nk - 1 ? "kenc.encoder." + std::to_string(3 * i + 1) : std::string(), gw + t->kw[i], gw + t->kb[i], t->kdims[i],
+               0, t->kdims[i + 1], t->kdims[i], nullptr, 0, nullptr);
+    for (int l = 0; l < L; ++l) {
+        const TrainLayer& Lw = t->layers[l];
+        const std::string base = "gnn.layers." + std::to_string(l);
+        for (int p = 0; p < 3; ++p) unfold(base + ".attn.proj." + std::to_string(p), "", gw + Lw.wqkv, gw + Lw.bqkv, D, 0, D, D, t->d_maps, p * D, nullptr);
+        unfold(base + ".attn.merge", "", gw + Lw.wm, gw + Lw.bm, D, 0, D, D, nullptr, 0, t->d_maps);
+        unfold(base + ".mlp.0", base + ".mlp.1", gw + Lw.w0, gw + Lw.b0, 2 * D, 0, 2 * D, 2 * D, nullptr, 0, nullptr);
+        unfold(base + ".mlp.3", "", gw + Lw.w1, gw + Lw.b1, 2 * D, 0, D, 2 * D, nullptr, 0, nullptr);
+    }
+    unfold("final_proj", "", gw + t->wf, gw + t->bf, D, 0, D, D, nullptr, 0, nullptr);
+    E2EMV_HIP(ctx, hipMemcpyAsync(gref("bin_score"), gw + t->alpha, sizeof(float), hipMemcpyDeviceToDevice, s));
+    E2EMV_CHECK_LAUNCH(ctx, "unfold kernels");
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_get_grad(e2emv_ctx* ctx, const char* key, float* d_dst, int64_t numel, void* stream) {
+    if (!ctx || !key || !d_dst) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    TrainState* t = ts_of(ctx);
+    if (!t) return set_err(ctx, E2EMV_ESTATE, "get_grad: e2emv_train_commit first");
+    std::string k(key);
+    if (k.rfind("module.", 0) == 0) k = k.substr(7);
+    auto it = t->raw.find(k);
+    if (it == t->raw.end()) return set_err(ctx, E2EMV_EINVAL, "get_grad: no gradient for '%s'", key);
+    if ((int64_t)it->second.numel != numel) return set_err(ctx, E2EMV_ESHAPE, "get_grad: '%s' has %zu elements, not %lld", key, it->second.numel, (long long)numel);
+    E2EMV_HIP(ctx, hipMemcpyAsync(d_dst, t->d_graw + it->second.off, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return E2EMV_OK;
+}

@@ -19,7 +19,12 @@ The reference imports it from an absent submodule (``train.py:18``, ``eval_pairs
 The sub-modules below are parameter CONTAINERS only - their torch ``forward`` is never
 called.  ``forward`` hands the weights to libe2emv.so (BN folding / head re-ordering happen
 there) and runs the hand-written HIP path; without the library or an MI355X it raises.
-Inference only: outputs carry no autograd graph (backward is out of scope).
+
+Training, first slice: in ``.train()`` mode with gradients enabled the ``scores_{i}_{j}`` carry an autograd
+graph (``_MatchScores``: the library's fp32 forward with a tape and its hand-written backward, csrc/train.hip), so the
+reference's stage-1 step ``match_loss(...).backward(); optimizer.step()`` (``train.py:406-425``) works unchanged.
+BatchNorm layers normalise with their running statistics there (they are not updated); ``conf_mlp`` and the pose loss
+through the weighted 8-point solve get no gradient yet.
 """
 import ctypes
 
@@ -46,7 +51,57 @@ DEFAULT_CONFIG = {
     # True: forward() synchronises and raises if the device reported non-finite scores (off by default: the reference's
     # forward is asynchronous too, and the NaN / inf is in the outputs either way)
     "check_finite": False,
+    # None: scores are differentiable whenever the module is in .train() mode, autograd is enabled and a parameter requires
+    # grad (fp32 training path).  False: always the inference path (no graph).
+    "autograd": None,
 }
+
+
+class _MatchScores(torch.autograd.Function):
+    """scores_{i}_{j} = f(parameters): e2emv_matcher_forward_train / e2emv_matcher_backward behind torch.autograd.
+
+    The context keeps the tape of its LAST training forward only: backward() of an older graph raises."""
+
+    @staticmethod
+    def forward(fctx, module, ctx, fd, kpts, scores, descs, shapes, names, *params):
+        dev = params[0].device
+        logZ = [torch.empty(s, dtype=torch.float32, device=dev) for s in shapes]
+        keep, args = [], []
+        for lst in (kpts, scores, descs, logZ):
+            p, arr = _lib.ptr_array(lst)
+            keep.append(arr)
+            args.append(p)
+        with torch.cuda.device(dev):
+            ctx.call("e2emv_matcher_forward_train", ctypes.byref(fd), *args, _lib.stream_ptr(dev))
+        ctx.train_generation += 1
+        fctx.lib_ctx, fctx.generation, fctx.names, fctx.dev = ctx, ctx.train_generation, names, dev
+        fctx.shapes = shapes
+        fctx.param_shapes = [p.shape for p in params]
+        fctx.set_materialize_grads(False)
+        return tuple(logZ)
+
+    @staticmethod
+    def backward(fctx, *grads):
+        ctx, dev = fctx.lib_ctx, fctx.dev
+        if ctx.train_generation != fctx.generation:
+            raise RuntimeError("MultiViewMatcher: backward() of a forward that is not the last training forward on this device "
+                               "(the library keeps one tape per context)")
+        g = [None if x is None else x.to(torch.float32).contiguous() for x in grads]
+        p, arr = _lib.ptr_array(g)
+        out = [None] * 8
+        with torch.cuda.device(dev):
+            ctx.call("e2emv_matcher_backward", p, _lib.stream_ptr(dev))
+            for n, (name, shape) in enumerate(zip(fctx.names, fctx.param_shapes)):
+                if not fctx.needs_input_grad[8 + n]:
+                    out.append(None)
+                    continue
+                if name.startswith("conf_mlp."):
+                    out.append(torch.zeros(shape, dtype=torch.float32, device=dev))  # not on the match-loss path
+                    continue
+                t = torch.empty(shape, dtype=torch.float32, device=dev)
+                ctx.call("e2emv_get_grad", name.encode(), ctypes.c_void_p(t.data_ptr()), t.numel(), _lib.stream_ptr(dev))
+                out.append(t)
+        return tuple(out)
 
 
 def _mlp(channels, do_bn=True):
@@ -145,6 +200,18 @@ class MultiViewMatcher(nn.Module):
         ctx.call("e2emv_commit_weights", ctypes.byref(md))
         ctx.weights_owner = owner
 
+    def _push_train_weights(self, ctx):
+        self._push_weights(ctx)
+        if ctx.train_owner != ctx.weights_owner:
+            md = self._model_desc()
+            ctx.call("e2emv_train_commit", ctypes.byref(md))
+            ctx.train_owner = ctx.weights_owner
+
+    def _differentiable(self):
+        if self.config.get("autograd", None) is False or not self.training or not torch.is_grad_enabled():
+            return False
+        return any(p.requires_grad for p in self.parameters())
+
     # ------------------------------------------------------------------ forward
     @staticmethod
     def _tuple_size(data):
@@ -219,6 +286,19 @@ class MultiViewMatcher(nn.Module):
         fd.desc_dtype = _lib.DESC_F16 if descs[0].dtype == torch.float16 else _lib.DESC_F32
         fd.flags = (_lib.FLAG_FULL_OUTPUT if full else 0) | (_lib.FLAG_MULTI_FRAME if cfg["multi_frame_matching"] else 0)
         P = len(pairs)
+        graph_scores = None
+        if self._differentiable():
+            if len(set(Ns)) != 1:
+                raise NotImplementedError("training path: all images of a call must carry the same number of keypoints "
+                                          "(the reference's training batches do, datasets pad to max_keypoints)")
+            if T > 2 and not cfg["multi_frame_matching"]:
+                raise NotImplementedError("training path: tuples of more than two images need multi_frame_matching")
+            self._push_train_weights(ctx)
+            named = [(k, p) for k, p in self.named_parameters()]
+            graph_scores = _MatchScores.apply(self, ctx, fd, kpts, scores, descs, [(B, N + 1, N + 1)] * P,
+                                              [k for k, _ in named], *[p for _, p in named])
+            if not full:
+                return {f"scores_{i}_{j}": graph_scores[p] for p, (i, j) in enumerate(pairs)}
         logZ = [torch.empty((B, Ns[i] + 1, Ns[j] + 1), dtype=torch.float32, device=dev) for i, j in pairs]
         none = [None] * P
         if full:
@@ -242,7 +322,7 @@ class MultiViewMatcher(nn.Module):
                 # range of the arithmetic mode (the scores of that call are NaN / inf either way)
                 ctx.call("e2emv_sync", _lib.stream_ptr(dev))
         for p, (i, j) in enumerate(pairs):
-            out[f"scores_{i}_{j}"] = logZ[p]
+            out[f"scores_{i}_{j}"] = logZ[p] if graph_scores is None else graph_scores[p]
             if full:
                 out[f"matches{i}_{i}_{j}"] = m0[p]
                 out[f"matches{j}_{i}_{j}"] = m1[p]

@@ -359,6 +359,30 @@ int e2emv_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, in
  * reports them; after the first such event the context runs the log-domain launch chain).  Host-synchronising. */
 int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset);
 
+/* ---- training, first slice: the matcher with a tape and the backward of the match loss ---------------------------------
+ * Replaces, for stage-1 training (match loss only), what torch.autograd does under the reference's
+ *   pred = run_matcher(...); train_loss.backward()        (/root/reference/helpers.py:243-260, train.py:406-425)
+ * with the reference's own arithmetic (fp32).  Differentiated: keypoint encoder, every GNN layer (projections, attention,
+ * merge, MLP), final_proj, the score matrix, bin_score and the unrolled log-domain Sinkhorn (SuperGlue's
+ * log_optimal_transport, models/superglue.py:156-186 upstream).  BatchNorm layers use their running statistics (frozen) and
+ * still hand back gradients for their affine parameters.  Forward-only in this slice: conf_mlp, the pose loss through the
+ * weighted 8-point solve, batch-statistics BatchNorm, images with differing keypoint counts.
+ *
+ * e2emv_train_commit        folds the weights handed over with e2emv_set_weight into the training arena (call again after
+ *                           every optimiser step, after re-sending the changed tensors).
+ * e2emv_matcher_forward_train   same inputs as e2emv_matcher_forward (fd->n_kpts keypoints in every image); outputs the
+ *                           log assignment matrices d_logZ[pair] = [batch][n_kpts + 1][n_kpts + 1] fp32, pairs in the
+ *                           order (0,1), (0,2), (1,2), ... and keeps the tape of this call in the context.
+ * e2emv_matcher_backward    d_dlogZ[pair] = dLoss / dlogZ of the last forward_train (same layout; a null entry = zero):
+ *                           leaves the gradient of every upstream parameter in the context.
+ * e2emv_get_grad            copies the gradient of parameter `key` (the reference's state_dict name, an optional "module."
+ *                           prefix is ignored) into d_dst (device, fp32, numel elements); stream-ordered.                 */
+int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* model);
+int e2emv_matcher_forward_train(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const float* const* d_kpts, const float* const* d_kscores,
+                                const void* const* d_desc, float* const* d_logZ, void* stream);
+int e2emv_matcher_backward(e2emv_ctx* ctx, const float* const* d_dlogZ, void* stream);
+int e2emv_get_grad(e2emv_ctx* ctx, const char* key, float* d_dst, int64_t numel, void* stream);
+
 /* ---- timing hooks used by bench.py (HIP events on the caller's stream) -------------
  * After e2emv_profile(ctx, 1) every kernel family launched by the library is bracketed by
  * HIP events on its stream; e2emv_profile_read returns accumulated milliseconds and launch

@@ -37,6 +37,9 @@ DEFAULT_CONFIG = {
     "tuple_size": 2,
     "conf_mlp": False,
     "full_output": True,
+    # True: keep the autograd graph (the state_dict's tensors may require grad) - the checker of the training path's
+    # gradients (tests/test_gpu_backward.py).  BatchNorm stays on its running statistics either way.
+    "grad": False,
 }
 
 BN_EPS = 1e-5
@@ -165,7 +168,7 @@ def matcher_forward(data, sd, config=None):
     heads = cfg["num_heads"]
     T = count_images(data)
     out = {}
-    with torch.no_grad():
+    with torch.set_grad_enabled(bool(cfg.get("grad", False))):
         enc = [encode(data, sd, cfg, m) for m in range(T)]
         if cfg["multi_frame_matching"] or T == 2:
             descs = gnn(enc, sd, cfg["GNN_layers"], heads)
