@@ -144,9 +144,13 @@ class HipWorkload:
     def __init__(self, args, rank, local_rank):
         import torch
         assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
+        # E2EMV_BENCH_SHARE_GPU=1 (tests only, never a reported number): ranks beyond the box's GPUs share them round-robin,
+        # each with its own process and library context, so the N > 1 branch runs the real kernels on a 1-GPU box
+        if os.environ.get("E2EMV_BENCH_SHARE_GPU"):
+            local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         self.torch = torch
-        self.dev = torch.device("cuda", local_rank)
+        self.dev = self.coll_dev = torch.device("cuda", local_rank)
         self.args = args
 
     def setup(self, rank):
@@ -214,7 +218,7 @@ class StubWorkload:
     be exercised on CPU over gloo (tests/test_bench_distributed.py).  Never used for a reported number."""
 
     def __init__(self, args, rank, local_rank):
-        self.args, self.rank, self.dev = args, rank, None
+        self.args, self.rank, self.dev, self.coll_dev = args, rank, None, None
         self.pairs = [(i, j) for j in range(args.tuple_size) for i in range(j)]
 
     def setup(self, rank):
@@ -360,6 +364,8 @@ def run(args):
         # barrier()/collectives from guessing it
         dist.init_process_group(backend, init_method="env://", **kw)
         assert dist.get_world_size() == world
+        if backend != "nccl":
+            wl.coll_dev = None  # gloo: the few-KB metric collectives go through host tensors
 
     from e2e_multi_view_matching_amd.distributed import gather_pair_errors, reduce_max_seconds
     from e2e_multi_view_matching_amd.metrics import pose_auc
@@ -381,7 +387,7 @@ def run(args):
             wl.step()
         wl.sync()
         barrier()
-        return reduce_max_seconds(time.perf_counter() - t0, device=wl.dev)  # MAX over ranks
+        return reduce_max_seconds(time.perf_counter() - t0, device=wl.coll_dev)  # MAX over ranks
 
     for _ in range(args.warmup):
         wl.step()
@@ -446,7 +452,7 @@ def run(args):
             step_images()
         wl.sync()
         barrier()
-        fe = reduce_max_seconds(time.perf_counter() - f0, device=wl.dev)
+        fe = reduce_max_seconds(time.perf_counter() - f0, device=wl.coll_dev)
         image_in = {"ms_per_step": round(1000.0 * fe / args.steps, 3), "value": round(B * P * world * args.steps / fe, 2),
                     "unit": "pairs/s", "note": f"{T * B} random 480x640 images per GPU and step through the SuperPoint front-end "
                     f"(random weights, padded to {N} keypoints) -> matcher -> w8pt"}
@@ -470,7 +476,7 @@ def run(args):
 
     # ---- AUC leg (not timed): identity-like weights give real matches; errors gathered over ranks
     e_deg = wl.auc_errors()
-    e_all = gather_pair_errors(e_deg, device=wl.dev)  # the path's only data collective (RCCL over xGMI), B*P floats per rank
+    e_all = gather_pair_errors(e_deg, device=wl.coll_dev)  # the path's only data collective (RCCL over xGMI), B*P floats per rank
     auc = [100.0 * a for a in pose_auc(e_all, [5, 10, 20])]
 
     if rank != 0:

@@ -256,11 +256,11 @@ int launch_attention(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, in
     p.gper = (p.groups + 7) / 8;
     dim3 grid(8 * p.gper * p.nq);
     static int dbg = -1;  // E2EMV_ATTN_DEBUG: ablation variants for profiling only (results are wrong when != 0)
-    if (dbg < 0) { const char* e = getenv("E2EMV_ATTN_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = dbg_knob("E2EMV_ATTN_DEBUG", 0);
     // Small problems (batch 1-2 of the reference's eval loop): one workgroup per (image, head, 128 queries) leaves most CUs
     // idle while each workgroup walks all key tiles serially.  Split the key tiles over up to 8 workgroups + a merge pass.
     static int split_env = -1;  // E2EMV_ATTN_SPLIT: 0 off, n > 1 forces n
-    if (split_env < 0) { const char* e = getenv("E2EMV_ATTN_SPLIT"); split_env = e ? atoi(e) : -1; }
+    if (split_env < 0) split_env = dbg_knob("E2EMV_ATTN_SPLIT", -1);
     p.ksplit = 1; p.part_o = nullptr; p.part_ml = nullptr;
     {
         int min_tiles = 1 << 30;  // key tiles a query walks (smallest over the images)

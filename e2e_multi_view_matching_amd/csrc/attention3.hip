@@ -715,7 +715,7 @@ int launch_attention3f(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv, 
     p.q_scale = 0.125f * 1.4426950408889634f;  // log2(e) / sqrt(64)
     if (h2) {
         static int nw_env = -1;  // E2EMV_A3_NW=4|8 forces the workgroup size
-        if (nw_env < 0) { const char* e = getenv("E2EMV_A3_NW"); nw_env = e ? atoi(e) : 0; }
+        if (nw_env < 0) nw_env = dbg_knob("E2EMV_A3_NW", 0);
         const int nw = nw_env == 4 || nw_env == 8 ? nw_env : (n_valid > 1024 ? 8 : 4);  // measured: equal at 1024 keys, 4-5 % at 2048
         if (nw == 8) {
             p.nq = (n_valid + 255) / 256;

@@ -182,6 +182,17 @@ struct CallGuard {
 // workspace: makes ctx->d_ws at least `bytes` large, growing the arena (synchronising) when needed; each
 // top-level entry point carves it with 256-byte aligned offsets.
 int ws_reserve(e2emv_ctx* ctx, size_t bytes);
+
+// Ablation / profiling knobs (forced tile shapes, kernels with a phase removed - results may be wrong) exist only in the
+// measurement build (-DE2EMV_STAMPS: `python tools/p2_stamps.py --build` makes libe2emv_stamps.so).  The release library
+// compiles them to their defaults and never reads these environment variables.
+#ifdef E2EMV_STAMPS
+inline int dbg_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+inline const char* dbg_env(const char* name) { return getenv(name); }
+#else
+constexpr int dbg_knob(const char*, int dflt) { return dflt; }
+constexpr const char* dbg_env(const char*) { return nullptr; }
+#endif
 void train_free(e2emv_ctx* ctx);  // train.hip
 // ctx->d_flags (device words: [0] Sinkhorn give-up flag, [1] its sticky count, [2] plane blocks that needed a tile exponent)
 int ensure_flags(e2emv_ctx* ctx);

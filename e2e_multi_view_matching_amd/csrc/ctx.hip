@@ -162,8 +162,8 @@ int e2emv_create(e2emv_ctx** out, int device) {
     if (!ctx) return E2EMV_ENOMEM;
     ctx->device = device;
     ctx->num_cus = p.multiProcessorCount;
-    if (const char* e = getenv("E2EMV_NO_FUSE_MERGE")) ctx->fuse_merge = !(e[0] == '1');
-    if (const char* e = getenv("E2EMV_B3_PLANES")) ctx->b3_planes = e[0] == '1';
+    if (dbg_knob("E2EMV_NO_FUSE_MERGE", 0) == 1) ctx->fuse_merge = false;
+    if (dbg_knob("E2EMV_B3_PLANES", 0) == 1) ctx->b3_planes = true;
     if (const char* e = getenv("E2EMV_F16X2_KERNELS")) ctx->h2_legacy = strcmp(e, "r2") == 0;  // round-2 f16x2 kernels (A/B measurements)
     // default arithmetic of the dense GNN contractions: the split-operand fp16 x 2 path (22-bit operands, fp32 accumulate;
     // every parity test runs in all three modes at the same bar); E2EMV_PRECISION=bf16x3 selects the 24-bit bf16 x 3

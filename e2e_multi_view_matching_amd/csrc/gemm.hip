@@ -394,7 +394,7 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
     // latency shape: when 128 x 128 tiles would leave most CUs idle (batch 1-4 of the reference's eval loop), 64 x 64 tiles
     // make 4x more, 4x shorter work items (E2EMV_GEMM_SMALL=0 disables)
     static int small_env = -1;
-    if (small_env < 0) { const char* e = getenv("E2EMV_GEMM_SMALL"); small_env = e ? atoi(e) : 1; }
+    if (small_env < 0) small_env = dbg_knob("E2EMV_GEMM_SMALL", 1);
     const bool plain = a.conv_c == 0 && !a.C3 && !a.Vt && a.q_cols == 0;
     const int64_t tiles128 = (int64_t)a.batch * ((a.M + 127) / 128) * ((a.N + 127) / 128);
     const bool small = small_env && plain && tiles128 * 2 <= ctx->num_cus;
@@ -411,9 +411,9 @@ int launch_gemm_nt(e2emv_ctx* ctx, const GemmArgs& a, hipStream_t s) {
         return set_err(ctx, E2EMV_ESHAPE, "gemm: the bf16x3 side output needs the vector epilogue and batch 1");
     const int per_xcd = (p.total + 7) / 8;
     static int dbg = -1, wg = -1, bk_env = -1;  // profiling knobs: E2EMV_GEMM_DEBUG (bit0: s_setprio), _WG_PER_CU, _BK
-    if (dbg < 0) { const char* e = getenv("E2EMV_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
-    if (wg < 0) { const char* e = getenv("E2EMV_GEMM_WG_PER_CU"); wg = e ? atoi(e) : 0; }
-    if (bk_env < 0) { const char* e = getenv("E2EMV_GEMM_BK"); bk_env = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = dbg_knob("E2EMV_GEMM_DEBUG", 0);
+    if (wg < 0) wg = dbg_knob("E2EMV_GEMM_WG_PER_CU", 0);
+    if (bk_env < 0) bk_env = dbg_knob("E2EMV_GEMM_BK", 0);
     const bool ext = p.C3 || a.Vt || a.q_cols > 0;
     // K tile: 32.  A 64-deep tile (half the barrier / staging episodes per MFMA, 2 workgroups per CU) was measured
     // 1-5 % SLOWER at every shape; so were 1 or 2 workgroups per CU and s_setprio around the MFMA block: the main

@@ -339,8 +339,8 @@ int launch_gemm_h2(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* WH, int64_
     // tile shape: 256 x 256 when N fills it (per MAC 4/256 + 4/256 B cross L2 instead of 4/128 + 4/256), else 256 x 128
     static int nj_env = -1;  // E2EMV_H2_NJ=2|4 forces a shape
     static int dbg = -1;     // profiling knob E2EMV_X3_DEBUG: 1 no MFMA, 2 L2-resident operands only, 8 phase timestamps
-    if (nj_env < 0) { const char* e = getenv("E2EMV_H2_NJ"); nj_env = e ? atoi(e) : 0; }
-    if (dbg < 0) { const char* e = getenv("E2EMV_X3_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (nj_env < 0) nj_env = dbg_knob("E2EMV_H2_NJ", 0);
+    if (dbg < 0) dbg = dbg_knob("E2EMV_X3_DEBUG", 0);
     const int nj = nj_env == 2 || nj_env == 4 ? nj_env : (a.N % 256 == 0 ? 4 : 2);
     const int bn = 64 * nj;
     const int tiles_m = (a.M + H2_BM - 1) / H2_BM;

@@ -236,7 +236,7 @@ int launch_gemm_x3(e2emv_ctx* ctx, const GemmArgs& a, const uint16_t* W3, int64_
     const int sl = std::min(per_xcd, std::max(1, ctx->num_cus * 2 / 8));
     const size_t lds = sizeof(uint16_t) * 6 * X3_PLANE;
     static int dbg = -1;  // profiling knob E2EMV_X3_DEBUG: bit0 no MFMA, bit1 no operand loads after the first K tile
-    if (dbg < 0) { const char* e = getenv("E2EMV_X3_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = dbg_knob("E2EMV_X3_DEBUG", 0);
     if (dbg == 1) hipLaunchKernelGGL(gemm_x3_kernel<1>, dim3(8 * sl), dim3(256), lds, s, p);
     else if (dbg == 2) hipLaunchKernelGGL(gemm_x3_kernel<2>, dim3(8 * sl), dim3(256), lds, s, p);
     else if (dbg == 6) hipLaunchKernelGGL(gemm_x3_kernel<6>, dim3(8 * sl), dim3(256), lds, s, p);

@@ -1042,12 +1042,12 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
         rpar.bufB = (u64*)gw; gw += rp.bytesB;
         rpar.bufU = (u64*)gw; gw += rp.bytesU;
         rpar.timeout = ctx->d_flags;
-        const char* dbg_path = getenv("E2EMV_SKR_DEBUG");
+        const char* dbg_path = dbg_env("E2EMV_SKR_DEBUG");
         unsigned long long* d_dbg = nullptr;
         const size_t dbg_bytes = (size_t)16 * rp.G * 8 * sizeof(unsigned long long);
         if (dbg_path && hipMalloc((void**)&d_dbg, dbg_bytes) == hipSuccess) (void)hipMemsetAsync(d_dbg, 0, dbg_bytes, s);
         rpar.dbg = d_dbg;
-        if (const char* e = getenv("E2EMV_SKR_FLAGS")) rpar.flags = atoi(e);
+        rpar.flags = dbg_knob("E2EMV_SKR_FLAGS", rpar.flags);
         rpar.u = p.u; rpar.v = p.v; rpar.ldV = p.ldV;
         // every polled word starts from 0 in every launch (epochs count from 1)
         E2EMV_HIP(ctx, hipMemsetAsync(w, 0, rp.bytesA + rp.bytesB + rp.bytesU, s));

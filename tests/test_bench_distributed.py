@@ -74,3 +74,18 @@ def test_single_rank_stub_line_is_the_contract():
                 "dtype", "data", "config"):
         assert key in out
     assert out["n_gpus"] == 1 and out["vs_baseline"] is None and out["unit"] == "pairs/s"
+
+
+def test_gpus_8_world_of_eight_ranks_over_gloo():
+    """The driver's `bench.py --gpus 8` shape: eight ranks join one process group, every rank contributes its pairs and its
+    clock, rank 0 prints one line with the whole-job aggregate (stub step - the launch, barriers and collectives are real)."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "3"],
+                       capture_output=True, text=True, timeout=900, env=_env(E2EMV_BENCH_STUB="1", OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["global_pairs"] == 8 * 3 and out["auc_pairs"] == 8 * 3
+    assert out["config"]["parallelism"] == "tuple-sharded x8"
+    assert abs(out["value"] - 8 * 3 * 2 / (out["ms_per_step"] * 2e-3)) < 0.02 * out["value"]

@@ -176,3 +176,14 @@ def test_maximum_size_2048_keypoints_fp16_multi_frame(gpu):
             out = model(dev)
         _compare(out, ref, [(0, 1), (0, 2), (1, 2)])
         assert float((out["matches0_0_1"] >= 0).float().mean()) > 0.5
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_one_pair_at_configs1_exactly(gpu, precision):
+    """BASELINE.json configs[1] as the north star states it - N = 1024 keypoints, D = 256, 18 layers, 100 Sinkhorn
+    iterations, conf_mlp, tuple_size 2 - on one pair (the oracle needs seconds for it), random weights and BatchNorm
+    statistics: scores within 1e-4, assignment indices bit-exact, in every arithmetic mode."""
+    cfg = {"sinkhorn_iterations": 100, "conf_mlp": True, "match_threshold": 0.2, "mfma_precision": precision}
+    out, ref, _ = _run(cfg, dict(batch=1, tuple_size=2, n_kpts=1024), gpu, seed=33)
+    assert out["scores_0_1"].shape == (1, 1025, 1025)
+    _compare(out, ref, [(0, 1)])

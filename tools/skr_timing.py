@@ -1,7 +1,11 @@
-"""Development aid: per-phase timing of the resident Sinkhorn kernel (E2EMV_SKR_DEBUG timestamps, 100 MHz clock)."""
+"""Development aid: per-phase timing of the resident Sinkhorn kernel (E2EMV_SKR_DEBUG timestamps, 100 MHz clock).
+Needs the measurement build (`python tools/p2_stamps.py --build`): the release library compiles these knobs out."""
 import os
 import sys
 import time
+
+os.environ.setdefault("E2EMV_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                    "e2e_multi_view_matching_amd", "libe2emv_stamps.so"))
 
 import numpy as np
 import torch
