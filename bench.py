@@ -503,7 +503,7 @@ def run(args):
         # the default arithmetic has no out-of-range fallback to take (tile exponents): `fallbacks` is 0 by
         # construction; rescaled_blocks = plane blocks outside the exponents' dead zone (0 for an ordinary network),
         # sinkhorn_reports = problems the exponential-domain Sinkhorn reported non-finite
-        out["range"] = {"fallbacks": 0, "rescaled_blocks": st["rescaled_blocks"], "sinkhorn_reports": st["sinkhorn_bad"]}
+        out["range"] = {"fallbacks": st["sinkhorn_rescued"], "rescaled_blocks": st["rescaled_blocks"], "sinkhorn_reports": st["sinkhorn_bad"]}
     if bare is not None:
         out["ms_per_step_without_event_brackets"] = round(1000.0 * bare / args.steps, 3)
     if alts:

@@ -174,6 +174,10 @@ class Context:
         # alternating on one device (checkpoint comparison, EMA copy) re-push instead of running on each other's weights.
         self.weights_owner = None
         self.sp_weights_owner = None
+        # held across "push my weights -> select my arithmetic -> enqueue my forward": two threads running two models on
+        # one device cannot interleave so that one runs on the other's committed weights (the C-side mutex serialises
+        # single calls only)
+        self.py_lock = threading.RLock()
         self.train_owner = None       # (module, fingerprint) whose weights e2emv_train_commit folded last
         self.train_generation = 0     # bumped by every forward_train: the context keeps the tape of the LAST one only
         self.default_precision = self.precision()  # E2EMV_PRECISION at creation time (else f32)
@@ -202,11 +206,12 @@ class Context:
         self.f16x2_kernels = int(generation)
 
     def stats(self, reset=False):
-        """{'rescaled_blocks': plane blocks that needed a non-zero tile exponent, 'sinkhorn_bad': Sinkhorn problems reported
-        non-finite} since the last reset (host-synchronising)."""
-        v = (ctypes.c_uint64 * 2)()
-        self.call("e2emv_get_stats", v, 2, 1 if reset else 0)
-        return {"rescaled_blocks": int(v[0]), "sinkhorn_bad": int(v[1])}
+        """{'rescaled_blocks': plane blocks that needed a non-zero tile exponent, 'sinkhorn_bad': Sinkhorn problems with
+        non-finite scores, 'sinkhorn_rescued': problems re-solved in the log domain behind the resident kernel (correct
+        outputs)} since the last reset (host-synchronising)."""
+        v = (ctypes.c_uint64 * 3)()
+        self.call("e2emv_get_stats", v, 3, 1 if reset else 0)
+        return {"rescaled_blocks": int(v[0]), "sinkhorn_bad": int(v[1]), "sinkhorn_rescued": int(v[2])}
 
     def set_split_min_rows(self, min_rows=-1):
         """Calls with fewer keypoint rows than this run the fp32-MFMA kernels even in a split-operand mode

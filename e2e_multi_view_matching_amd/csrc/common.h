@@ -121,7 +121,8 @@ struct e2emv_ctx {
     size_t attn_part_bytes = 0;
     // device flags: [0] give-up flag of the running resident Sinkhorn launch, [1] sticky count of give-ups
     unsigned* d_flags = nullptr;
-    uint64_t stat_sinkhorn_bad = 0;  // Sinkhorn problems reported non-finite / timed out so far (e2emv_get_stats)
+    uint64_t stat_sinkhorn_bad = 0;      // Sinkhorn problems with non-finite scores so far (e2emv_get_stats)
+    uint64_t stat_sinkhorn_rescued = 0;  // problems the log-domain rescue pass re-solved behind the resident kernel
     bool sinkhorn_stream = false;    // set by the first such report: later calls run the log-domain launch chain
     char* d_dummy = nullptr;  // 4 KB scratch line: target of masked-out stores of kernels that must issue a fixed number of stores (gemm_p2.hip)
     // workspace arena

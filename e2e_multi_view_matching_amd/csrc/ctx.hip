@@ -233,17 +233,23 @@ int e2emv_sync(e2emv_ctx* ctx, void* stream) {
     if (!ctx) return E2EMV_EINVAL;
     E2EMV_ENTER(ctx, stream);
     E2EMV_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
-    if (ctx->d_flags) {  // an inter-workgroup exchange that gave up poisoned its outputs with NaN: report it
-        unsigned f[2] = {0, 0};
+    if (ctx->d_flags) {
+        // [1]: Sinkhorn problems whose potentials are non-finite even after the log-domain rescue pass = non-finite scores
+        // [3]: problems the rescue pass re-solved (finite outputs; a context that keeps needing it moves to the log-domain chain)
+        unsigned f[4] = {0, 0, 0, 0};
         E2EMV_HIP(ctx, hipMemcpy(f, ctx->d_flags, sizeof(f), hipMemcpyDeviceToHost));
+        if (f[3]) {
+            unsigned zero = 0;
+            (void)hipMemcpy(ctx->d_flags + 3, &zero, sizeof(zero), hipMemcpyHostToDevice);
+            ctx->stat_sinkhorn_rescued += f[3];
+            ctx->sinkhorn_stream = true;
+        }
         if (f[1]) {
             unsigned zero = 0;
             (void)hipMemcpy(ctx->d_flags + 1, &zero, sizeof(zero), hipMemcpyHostToDevice);
             ctx->stat_sinkhorn_bad += f[1];
-            ctx->sinkhorn_stream = true;  // this model's scores leave the exponential-domain kernel's range: from now on the log-domain launch chain
-            return set_err(ctx, E2EMV_EHIP, "sinkhorn (resident kernel): scores left the exponential-domain kernel's range or an inter-workgroup "
-                           "wait gave up (%u workgroup reports) - the outputs of those problems are NaN/inf; this context runs the "
-                           "log-domain launch chain from now on", f[1]);
+            return set_err(ctx, E2EMV_EHIP, "sinkhorn: %u problem(s) with non-finite scores (an activation left the range of the arithmetic "
+                           "mode, or the inputs were non-finite) - the outputs of those problems are NaN/inf", f[1]);
         }
     }
     return E2EMV_OK;
@@ -572,17 +578,19 @@ int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset) {
     unsigned f[4] = {0, 0, 0, 0};
     if (ctx->d_flags) E2EMV_HIP(ctx, hipMemcpy(f, ctx->d_flags, sizeof(f), hipMemcpyDeviceToHost));
     ctx->stat_sinkhorn_bad += f[1];
-    const uint64_t v[2] = {(uint64_t)f[2], ctx->stat_sinkhorn_bad};
-    for (int i = 0; i < n; ++i) stats[i] = i < 2 ? v[i] : 0;
+    ctx->stat_sinkhorn_rescued += f[3];
+    const uint64_t v[3] = {(uint64_t)f[2], ctx->stat_sinkhorn_bad, ctx->stat_sinkhorn_rescued};
+    for (int i = 0; i < n; ++i) stats[i] = i < 3 ? v[i] : 0;
+    if (ctx->d_flags && (f[1] || f[3])) {  // the device counts moved into the host-side totals
+        E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 1, 0, sizeof(unsigned)));
+        E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 3, 0, sizeof(unsigned)));
+        if (f[3]) ctx->sinkhorn_stream = true;  // this model keeps leaving the exponential-domain kernel's range: log-domain chain from now on
+    }
     if (reset) {
         ctx->stat_sinkhorn_bad = 0;
+        ctx->stat_sinkhorn_rescued = 0;
         ctx->sinkhorn_stream = false;  // (a reset also returns the Sinkhorn to the resident kernel)
         if (ctx->d_flags) E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 2, 0, sizeof(unsigned)));
-    }
-    if (ctx->d_flags && f[1]) {  // the Sinkhorn count moves into the host-side total (e2emv_sync reports and clears it the same way)
-        unsigned zero = 0;
-        E2EMV_HIP(ctx, hipMemcpy(ctx->d_flags + 1, &zero, sizeof(zero), hipMemcpyHostToDevice));
-        if (!reset) ctx->sinkhorn_stream = true;
     }
     return E2EMV_OK;
 }

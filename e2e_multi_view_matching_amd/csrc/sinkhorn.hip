@@ -615,7 +615,7 @@ __device__ __forceinline__ bool granule_wait(const u64* base, const int (&off)[N
                                                     __HIP_MEMORY_SCOPE_AGENT);
             if (flag || spins >= SKR_SPIN_LIMIT) {
                 if ((threadIdx.x & 63) == 0) {
-                    if (!flag) atomicAdd(timeout + 1, 1u);  // sticky count of give-ups, read by e2emv_sync
+                    if (!flag) atomicAdd(timeout + 4, 1u);  // diagnostic count of give-ups (the rescue pass below re-solves the problem)
                     atomicOr(timeout, 1u);
                 }
                 dead = true;
@@ -874,9 +874,72 @@ __global__ __launch_bounds__(512, KT <= 4 ? 4 : 2) void sinkhorn_resident(SkResP
                 bad = bad || !(aM > 0.f) || !(aM < INFINITY);
                 if (tid == 0) ub[M] = dead ? qnan : __logf(aM) - p.alpha;
             }
-            if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicAdd(p.timeout + 1, 1u);  // also: LDS is reused by the next problem
+            if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicAdd(p.timeout + 4, 1u);  // also: LDS is reused by the next problem
         }
     }
+}
+
+
+// ---- rescue pass behind the resident kernel -----------------------------------------------------------------------------
+// One workgroup per problem looks at the potentials the resident kernel left.  All finite (every call of an ordinary
+// network): return - the pass costs one launch of B idle workgroups.  Otherwise (a scaling left fp32's range in the
+// exponential domain, or an inter-workgroup wait gave up under contention) this workgroup re-solves ITS problem alone in
+// the log domain, upstream's u = log_mu - LSE_j(C + v), v = log_nu - LSE_i(C + u): no range limit, no inter-workgroup
+// wait, scores streamed from L2 / HBM twice per iteration (milliseconds per problem - a rare path).  flags[3] counts the
+// rescued problems; flags[1] the problems whose potentials are non-finite even so (non-finite scores: a real error,
+// reported by e2emv_sync).
+__global__ __launch_bounds__(1024) void sinkhorn_rescue(SkParams p, int iters, unsigned* flags) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = p.M, N = p.N;
+    float* ub = p.u + (int64_t)b * (M + 1);
+    float* vb = p.v + (int64_t)b * p.ldV;
+    bool bad = false;
+    for (int i = tid; i <= M; i += 1024) bad = bad || !(fabsf(ub[i]) < INFINITY);
+    for (int j = tid; j <= N; j += 1024) bad = bad || !(fabsf(vb[j]) < INFINITY);
+    if (!__syncthreads_or(bad ? 1 : 0)) return;
+    float* su = lds;            // [M + 1]
+    float* sv = lds + (M + 1);  // [N + 1]
+    const float* Sb = p.S + (int64_t)b * M * p.ldS;
+    for (int j = tid; j <= N; j += 1024) sv[j] = 0.f;
+    __syncthreads();
+    const float log_mu_bin = __logf((float)N) + p.norm, log_nu_bin = __logf((float)M) + p.norm;
+    for (int it = 0; it < iters; ++it) {
+        for (int i = wave; i <= M; i += 16) {  // one wave per row
+            float mx = -INFINITY;
+            for (int j = lane; j <= N; j += 64) mx = fmaxf(mx, ((i < M && j < N) ? Sb[(int64_t)i * p.ldS + j] : p.alpha) + sv[j]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float sm = 0.f;
+            for (int j = lane; j <= N; j += 64) sm += __expf(((i < M && j < N) ? Sb[(int64_t)i * p.ldS + j] : p.alpha) + sv[j] - mx);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+            if (lane == 0) su[i] = (i < M ? p.norm : log_mu_bin) - (mx + __logf(sm));
+        }
+        __syncthreads();
+        for (int j = tid; j <= N; j += 1024) {  // one thread per column, running maximum
+            float mx = -INFINITY, sm = 0.f;
+            for (int i = 0; i <= M; ++i) {
+                const float x = ((i < M && j < N) ? Sb[(int64_t)i * p.ldS + j] : p.alpha) + su[i];
+                if (x > mx) { sm = sm * __expf(mx - x) + 1.f; mx = x; } else { sm += __expf(x - mx); }
+            }
+            sv[j] = (j < N ? p.norm : log_nu_bin) - (mx + __logf(sm));
+        }
+        __syncthreads();
+    }
+    if (iters <= 0) {
+        for (int i = tid; i <= M; i += 1024) su[i] = 0.f;
+        __syncthreads();
+    }
+    bad = false;
+    for (int i = tid; i <= M; i += 1024) { ub[i] = su[i]; bad = bad || !(fabsf(su[i]) < INFINITY); }
+    for (int j = tid; j < p.ldV; j += 1024) {
+        const float x = j <= N ? sv[j] : 0.f;
+        vb[j] = x;
+        bad = bad || !(fabsf(x) < INFINITY);
+    }
+    const int still = __syncthreads_or(bad ? 1 : 0);
+    if (tid == 0) atomicAdd(flags + (still ? 1 : 3), 1u);
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -1054,6 +1117,9 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
         E2EMV_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, 4, s));
         hipLaunchKernelGGL_ptr(kfn, dim3((unsigned)(rp.n_res * rp.G)), dim3(512), res_lds, s, rpar);
         E2EMV_CHECK_LAUNCH(ctx, "sinkhorn_resident");
+        // problems the exponential-domain kernel could not finish are re-solved in the log domain before anything reads u, v
+        hipLaunchKernelGGL(sinkhorn_rescue, dim3(B), dim3(1024), sizeof(float) * (size_t)(M + N + 2), s, p, iters, ctx->d_flags);
+        E2EMV_CHECK_LAUNCH(ctx, "sinkhorn_rescue");
         if (d_dbg) {  // development aid: per-phase timestamps of resident problem 0, appended as text
             std::vector<unsigned long long> h(dbg_bytes / 8);
             (void)hipStreamSynchronize(s);

@@ -230,6 +230,11 @@ class MultiViewMatcher(nn.Module):
             raise RuntimeError("MultiViewMatcher runs only on an MI355X: call .cuda() first (there is no CPU path; "
                                "the CPU oracle lives in oracle/ and is test infrastructure)")
         ctx = _lib.context(dev)
+        with ctx.py_lock:
+            return self._forward_locked(ctx, data, T, dev)
+
+    def _forward_locked(self, ctx, data, T, dev):
+        cfg = self.config
         self._push_weights(ctx)
         # the precision switch is context-global and sticky: resolve it on EVERY call (None = the context's explicit
         # override, else the library default), so a model never inherits what the previous model selected

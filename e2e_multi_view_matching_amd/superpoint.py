@@ -82,7 +82,8 @@ class SuperPoint(nn.Module):
             desc = torch.empty((B, 256, K), dtype=torch.float32, device=dev)
             count = torch.empty((B,), dtype=torch.int32, device=dev)
             smap = torch.empty((B, H, W), dtype=torch.float32, device=dev) if cfg.get("return_score_map") else None
-            with torch.cuda.device(dev):
+            with torch.cuda.device(dev), ctx.py_lock:
+                self._upload(ctx)  # (again, now under the lock: another thread's model may have taken the context's weight set)
                 ctx.call("e2emv_superpoint_forward", ctypes.byref(d), _lib.ptr(img), _lib.ptr(kpts), _lib.ptr(scores), _lib.ptr(desc),
                          _lib.ptr(count), _lib.ptr(smap), _lib.stream_ptr(dev))
             n = count.tolist()

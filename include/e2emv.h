@@ -355,8 +355,11 @@ int e2emv_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, in
  * The f16x2 mode keeps its fp16 planes inside fp16's range with one exponent per block of 64 x 64 activations (see
  * DESIGN.md 4d): there is no out-of-range fallback to take.  stats[0] = plane blocks that needed a non-zero exponent since
  * the last reset (0 for an ordinary network: every block sat inside the dead zone and took the plain paths), stats[1] =
- * Sinkhorn problems that left fp32's range or gave up an inter-workgroup wait (their outputs are NaN and e2emv_sync
- * reports them; after the first such event the context runs the log-domain launch chain).  Host-synchronising. */
+ * Sinkhorn problems whose scores were non-finite (their outputs are NaN / inf and e2emv_sync reports them), stats[2] =
+ * Sinkhorn problems the exponential-domain resident kernel could not finish (a scaling left fp32's range, or an
+ * inter-workgroup wait gave up under contention) and the rescue pass behind it re-solved in the log domain inside the same
+ * call: their outputs are correct, nothing is raised; once the host has seen such an event (here or in e2emv_sync) the
+ * context runs the log-domain launch chain for every later call.  Host-synchronising. */
 int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset);
 
 /* ---- training, first slice: the matcher with a tape and the backward of the match loss ---------------------------------

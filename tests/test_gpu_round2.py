@@ -273,7 +273,7 @@ def test_f16x2_out_of_range_activations(gpu, split_always):
     with torch.no_grad():
         out = model(dg)
     assert not bool(torch.isfinite(out["scores_0_1"]).all())
-    assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.EHIP and b"range" in ctx.lib.e2emv_last_error(ctx.h)
+    assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.EHIP and b"range" in ctx.lib.e2emv_last_error(ctx.h)  # non-finite scores
     assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK                # the report is consumed once
     ctx.stats(reset=True)                                            # (the report moved the context's Sinkhorn to the log-domain chain: undo)
     model.config["check_finite"] = True                              # the same report as an exception from forward()

@@ -32,3 +32,16 @@ def test_bench_two_ranks_real_kernels(gpu):
     assert out["value"] > 0 and out["range"]["fallbacks"] == 0
     # both ranks ran the identity-like model on their own tuples (seed 1000 + rank): matches are real, poses are good
     assert out["auc_5_10_20"][2] > 50.0, out["auc_5_10_20"]
+    # ... and the gathered metric equals what ONE process / one context computes over rank 0's then rank 1's tuples
+    sys.path.insert(0, ROOT)
+    import bench
+    import numpy as np
+    from e2e_multi_view_matching_amd.metrics import pose_auc
+    args = bench.parse_args(["--steps", "2", "--warmup", "1", "--batch", "4", "--kpts", "512"])
+    errs = []
+    for rk in range(2):
+        wl = bench.HipWorkload(args, rk, 0)
+        wl.setup(rk)
+        errs.append(wl.auc_errors())
+    ref = [100.0 * a for a in pose_auc(np.concatenate(errs), [5, 10, 20])]
+    assert np.allclose(out["auc_5_10_20"], ref, atol=2e-3), (out["auc_5_10_20"], ref)
