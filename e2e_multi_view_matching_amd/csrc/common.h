@@ -102,6 +102,13 @@ struct e2emv_ctx {
     float* kenc_w0 = nullptr;  // [c0][3] folded
     float* kenc_b0 = nullptr;  // [c0]
     std::vector<float*> kenc_w, kenc_b;  // layers 1..n (folded), [out][in]
+    std::vector<const uint16_t*> kenc_wh;  // the same layers as fp16 x 2 weight planes (null: fan-in < 128, stays on the fp32 kernel)
+    std::vector<float> kenc_hs;
+    const uint16_t* wh_final = nullptr;  // final_proj / conf_mlp.0 as fp16 x 2 weight planes
+    const uint16_t* wh_conf0 = nullptr;
+    const uint16_t* wp_final = nullptr;  // ... and in the plane kernels' weight format (gemm_p2)
+    const uint16_t* wp_conf0 = nullptr;
+    float hs_final = 0.f, hs_conf0 = 0.f, ba_final = 0.f, ba_conf0 = 0.f;
     std::vector<int> kenc_dims;          // [3, c0, c1, ..., D]
     std::vector<e2emv::LayerWeights> layers;
     float* w_final = nullptr;

@@ -379,7 +379,9 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     dims.push_back(D);
     for (size_t i = 1; i + 1 < dims.size(); ++i)
         if (dims[i] % 32 != 0) return set_err(ctx, E2EMV_ESHAPE, "keypoint_encoder width %d not a multiple of 32", dims[i]);
-    std::vector<size_t> kw_off, kb_off;
+    std::vector<uint16_t> pk3;  // split (bf16 x 3 / fp16 x 2) planes of the GEMM weights
+    std::vector<size_t> kw_off, kb_off, kwh_off;
+    std::vector<float> kwh_hs;
     const int nk = (int)dims.size() - 1;
     for (int i = 0; i < nk; ++i) {
         std::string p = "kenc.encoder." + std::to_string(3 * i);
@@ -388,6 +390,8 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
             return rc;
         kw_off.push_back(pk.add(w));
         kb_off.push_back(pk.add(b));
+        kwh_hs.push_back(0.f);
+        kwh_off.push_back(dims[i] >= 128 ? add_split_h2(pk3, w, dims[i + 1], dims[i], &kwh_hs.back()) : (size_t)-1);
     }
     // ---- GNN layers ----
     struct LOff {
@@ -395,7 +399,6 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         size_t w3qkv, w3m0, w3m1, whqkv, whm0, whm1, wpqkv, wpm0, wpm1;
         float hsqkv, hsm0, hsm1, baqkv, bam0, bam1;
     };
-    std::vector<uint16_t> pk3;  // bf16x3 planes of the big GEMM weights
     std::vector<LOff> loff(m->n_layers);
     for (int l = 0; l < m->n_layers; ++l) {
         std::string base = "gnn.layers." + std::to_string(l);
@@ -464,6 +467,12 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     }
     if ((rc = get_conv(ctx, "final_proj", D, D, w, b))) return rc;
     size_t wf = pk.add(w), bf = pk.add(b);
+    float hs_final = 0.f, hs_conf0 = 0.f;
+    const size_t whf = add_split_h2(pk3, w, D, D, &hs_final);
+    const size_t wpf = (D % 32 == 0) ? add_split_p2(pk3, w, D, D, &hs_final) : (size_t)-1;
+    float ba_final = 0.f, ba_conf0 = 0.f;
+    for (float v : b) ba_final = std::max(ba_final, std::fabs(v));
+    size_t whc0 = 0, wpc0 = (size_t)-1;
     const HostTensor* bs = find(ctx, "bin_score");
     if (!bs || bs->data.size() != 1) return set_err(ctx, E2EMV_ESTATE, "missing scalar 'bin_score'");
     size_t wc0 = 0, bc0 = 0, wc1 = 0;
@@ -473,6 +482,9 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         if ((rc = fold_bn(ctx, "conf_mlp.1", D, 2 * D, w, b))) return rc;
         wc0 = pk.add(w);
         bc0 = pk.add(b);
+        whc0 = add_split_h2(pk3, w, D, 2 * D, &hs_conf0);
+        if (D % 32 == 0) wpc0 = add_split_p2(pk3, w, D, 2 * D, &hs_conf0);
+        for (float v : b) ba_conf0 = std::max(ba_conf0, std::fabs(v));
         if ((rc = get_conv(ctx, "conf_mlp.3", 1, D, w, b))) return rc;
         wc1 = pk.add(w);
         bc1 = b[0];
@@ -514,10 +526,22 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     ctx->kenc_b0 = base + kb_off[0];
     ctx->kenc_w.clear();
     ctx->kenc_b.clear();
+    ctx->kenc_wh.clear();
+    ctx->kenc_hs.clear();
     for (int i = 1; i < nk; ++i) {
         ctx->kenc_w.push_back(base + kw_off[i]);
         ctx->kenc_b.push_back(base + kb_off[i]);
+        ctx->kenc_wh.push_back(kwh_off[i] == (size_t)-1 ? nullptr : ctx->d_w3arena + kwh_off[i]);
+        ctx->kenc_hs.push_back(kwh_hs[i]);
     }
+    ctx->wh_final = ctx->d_w3arena + whf;
+    ctx->hs_final = hs_final;
+    ctx->wh_conf0 = m->conf_mlp ? ctx->d_w3arena + whc0 : nullptr;
+    ctx->hs_conf0 = hs_conf0;
+    ctx->wp_final = wpf == (size_t)-1 ? nullptr : ctx->d_w3arena + wpf;
+    ctx->wp_conf0 = (m->conf_mlp && wpc0 != (size_t)-1) ? ctx->d_w3arena + wpc0 : nullptr;
+    ctx->ba_final = ba_final;
+    ctx->ba_conf0 = ba_conf0;
     ctx->layers.assign(m->n_layers, LayerWeights());
     for (int l = 0; l < m->n_layers; ++l) {
         LayerWeights& L = ctx->layers[l];

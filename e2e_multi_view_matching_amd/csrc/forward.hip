@@ -86,6 +86,24 @@ __global__ __launch_bounds__(256) void conf_gather_kernel(int N, int n_rows, int
     for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(src + c);
 }
 
+// f16x2 mode: both halves of the conf MLP's input in one matrix, feat[b][n][:] = [mdesc_i[b][n][:] | mdesc_j[b][max(match,0)][:]]
+// (the fp16 x 2 GEMM takes one un-batched row-major operand)
+__global__ __launch_bounds__(256) void conf_gather2_kernel(int N, int n_rows, int D, const float* mdesc_i, const float* mdesc_j, int64_t tuple_stride,
+                                                           const int64_t* matches, float* out) {
+    const int b = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    int64_t j = row < N ? matches[(int64_t)b * N + row] : 0;
+    if (j < 0) j = 0;
+    const float* si = mdesc_i + b * tuple_stride + (int64_t)row * D;
+    const float* sj = mdesc_j + b * tuple_stride + j * D;
+    float* dst = out + ((int64_t)b * n_rows + row) * 2 * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(si + c);
+        *reinterpret_cast<f32x4*>(dst + D + c) = *reinterpret_cast<const f32x4*>(sj + c);
+    }
+}
+
 // conf head, last step: sigmoid(<hidden, w> + b) for matched keypoints, 0 otherwise;
 // without conf_mlp the confidence is the match score (reference quirk E13)
 __global__ __launch_bounds__(256) void conf_final_kernel(int N, int n_rows, int D, const float* hidden, const float* w, float bias,
@@ -228,7 +246,8 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
             if (last) { g.R = x; g.ldr = D; g.C = x; g.ldc = D; }
             else { g.C = nxt; g.ldc = cout; }
             prof_begin(ctx, PS_GEMM, s);
-            rc = launch_gemm_nt(ctx, g, s);
+            // f16x2 mode: the wide layers (fan-in >= 128) on the fp16 x 2 kernel as well - same parity bar, 3x less matrix-core time
+            rc = (h2 && ctx->kenc_wh[i]) ? launch_gemm_x3(ctx, g, ctx->kenc_wh[i], cin, s, ctx->kenc_hs[i]) : launch_gemm_nt(ctx, g, s);
             prof_end(ctx, s);
             if (rc) return rc;
             cur = nxt;
@@ -278,7 +297,7 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
             m1.M = (int)Mtot; m1.N = D; m1.K = 2 * D; m1.K1 = 2 * D; m1.A = hidp; m1.lda = 2 * D;
             m1.W = L.wp_mlp1; m1.out_scale = L.hs_mlp1; m1.bias = L.b_mlp1; m1.Rp = xp; m1.ldr = D;
             m1.EA = e_hid; m1.ER = e_x; m1.AR = a_x; m1.bias_amax = L.ba_mlp1;
-            if (last) { m1.out = P2_OUT_F32; m1.C32 = x; m1.ldc = D; }
+            if (last && !ctx->wp_final) { m1.out = P2_OUT_F32; m1.C32 = x; m1.ldc = D; }  // (final_proj then runs on the fp32-input kernel)
             else { m1.out = P2_OUT_PLANES; m1.Cp = xp; m1.ldc = D; m1.EC = e_x; m1.AC = a_x; }
             prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_p2(ctx, m1, s); prof_end(ctx, s);
             if (rc) return rc;
@@ -352,11 +371,17 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
 
     // ---- final projection ----
     float* mdesc = att;
-    {
+    if (p2 && ctx->wp_final) {  // x arrives as planes with their tile exponents: any magnitude fp32 holds is fine
+        GemmP2Args q;
+        q.M = (int)Mtot; q.N = D; q.K = D; q.K1 = D; q.A = xp; q.lda = D; q.W = ctx->wp_final; q.out_scale = ctx->hs_final; q.bias = ctx->b_final;
+        q.out = P2_OUT_F32; q.C32 = mdesc; q.ldc = D; q.EA = e_x; q.bias_amax = ctx->ba_final;
+        prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_p2(ctx, q, s); prof_end(ctx, s);
+        if (rc) return rc;
+    } else {
         GemmArgs g;
         g.M = (int)Mtot; g.N = D; g.K = D; g.K1 = D; g.A = x; g.lda = D; g.W = ctx->w_final; g.ldw = D; g.bias = ctx->b_final;
         g.C = mdesc; g.ldc = D;
-        prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
+        prof_begin(ctx, PS_GEMM, s); rc = h2 ? launch_gemm_x3(ctx, g, ctx->wh_final, D, s, ctx->hs_final) : launch_gemm_nt(ctx, g, s); prof_end(ctx, s);
         if (rc) return rc;
     }
 
@@ -417,9 +442,34 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
             if (!want_conf[pidx]) continue;
             const int Ni = Nt[i];
             const bool use_mlp = ctx->model.conf_mlp != 0;
-            float* gathered = msg;          // [B][n_rows][D]
+            float* gathered = msg;          // [B][n_rows][D] ([B][n_rows][2D] in the f16x2 modes)
             float* chid = hid;              // [B][n_rows][D]
-            if (use_mlp) {
+            if (use_mlp && p2 && ctx->wp_conf0) {
+                // plane kernels: [mdesc_i | mdesc_j(match)] -> planes with tile exponents -> conf_mlp.0 (+ BN, ReLU) on gemm_p2
+                prof_begin(ctx, PS_CONF, s);
+                hipLaunchKernelGGL(conf_gather2_kernel, dim3((n_rows + 3) / 4, B), dim3(256), 0, s, Ni, n_rows, D, mdesc + (int64_t)i * n_rows * D,
+                                   mdesc + (int64_t)j * n_rows * D, tuple_stride, pm0[pidx], gathered);
+                prof_end(ctx, s);
+                prof_begin(ctx, PS_INGEST, s);
+                rc = launch_to_planes(ctx, gathered, (int64_t)B * n_rows, 2 * D, 2 * D, qkp, s, e_hid, nullptr);
+                prof_end(ctx, s);
+                if (rc) return rc;
+                GemmP2Args q;
+                q.M = B * n_rows; q.N = D; q.K = 2 * D; q.K1 = 2 * D; q.A = qkp; q.lda = 2 * D; q.W = ctx->wp_conf0; q.out_scale = ctx->hs_conf0;
+                q.bias = ctx->b_conf0; q.relu = true; q.out = P2_OUT_F32; q.C32 = chid; q.ldc = D; q.EA = e_hid; q.bias_amax = ctx->ba_conf0;
+                prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_p2(ctx, q, s); prof_end(ctx, s);
+                if (rc) return rc;
+            } else if (use_mlp && h2 && ctx->wh_conf0) {
+                prof_begin(ctx, PS_CONF, s);
+                hipLaunchKernelGGL(conf_gather2_kernel, dim3((n_rows + 3) / 4, B), dim3(256), 0, s, Ni, n_rows, D, mdesc + (int64_t)i * n_rows * D,
+                                   mdesc + (int64_t)j * n_rows * D, tuple_stride, pm0[pidx], gathered);
+                prof_end(ctx, s);
+                GemmArgs c;
+                c.M = B * n_rows; c.N = D; c.K = 2 * D; c.K1 = 2 * D; c.A = gathered; c.lda = 2 * D;
+                c.bias = ctx->b_conf0; c.relu = true; c.C = chid; c.ldc = D;
+                prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_x3(ctx, c, ctx->wh_conf0, 2 * D, s, ctx->hs_conf0); prof_end(ctx, s);
+                if (rc) return rc;
+            } else if (use_mlp) {
                 prof_begin(ctx, PS_CONF, s);
                 hipLaunchKernelGGL(conf_gather_kernel, dim3((n_rows + 3) / 4, B), dim3(256), 0, s, Ni, n_rows, D,
                                    mdesc + (int64_t)j * n_rows * D, tuple_stride, pm0[pidx], gathered);

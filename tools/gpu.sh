@@ -3,6 +3,7 @@
 #   planes   per-kernel parity of the plane kernels + matcher parity + micro-benchmarks + bench A/B (plane vs round-2 kernels)
 #   tests    the whole -m gpu suite
 #   bench    bench.py lines (c2 default, c4, c5)
+#   kt       rocprofv3 kernel trace of one config / mode
 #   prof     rocprofv3 kernel trace + the three PMC passes of config c2
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r3
@@ -47,6 +48,14 @@ bench)
   timeout 300 python bench.py --config c4 --cpu-pairs 0 > $OUT/bench_c4.json 2> $OUT/bench_c4.err
   timeout 300 python bench.py --config c5 --cpu-pairs 0 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
   show $OUT/bench_c2.json $OUT/bench_c4.json $OUT/bench_c5.json
+  ;;
+kt)
+  cfg=${2:-c2}; mode=${3:-f16x2}
+  args="--config $cfg --precision $mode --steps 2 --warmup 1 --cpu-pairs 0 --no-alt --no-latency --no-profile"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_${cfg}_${mode} -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_${cfg}_${mode}.log 2>&1)
+  db=$(find /tmp/kt_${cfg}_${mode} -name '*.db' | head -1)
+  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r3_kernel_stats_${cfg}_${mode}.md 2>&1
+  head -40 $OUT/r3_kernel_stats_${cfg}_${mode}.md
   ;;
 prof)
   cfg=${2:-c2}; mode=${3:-f16x2}
