@@ -188,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
     //   * every wave issues EXACTLY 32 store instructions per tile (rows / columns beyond the matrix go to a dummy line
     //     instead of being skipped), so the K loop of the next tile can wait with a COUNTED vmcnt for its operand loads,
     //     which were issued before these stores, and leave the stores in flight (see the pipeline below).
-    auto epilogue = [&](int t, int e_run) {
+    auto epilogue = [&](int t, int e_run, int ev) {
         char* sl = smem_p2 + 2 * P2_BUFB + wave * P2_SLABB;
         const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
         const int o_r = lane >> 2, o_c = (lane & 3) * 8;  // row-contiguous view: 16 rows per pass, 8 columns per lane
@@ -205,11 +205,12 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 const int cb = tn * 4 + wc * 2 + ch;  // 64-column block of the output
+                // (the residual block's exponent and max |x| came with the tile's exponent fetch, lanes 32.. - no memory access here)
                 int er = 0;
                 float ar = 0.f;
-                if (HAS_R && erow * 64 < p.M && cb < p.eld_r) {
-                    if (p.ER) er = p.ER[erow * p.eld_r + cb];
-                    ar = p.AR ? p.AR[erow * p.eld_r + cb] : 65536.f * p2_exp2i(er);
+                if (HAS_R && p.ER) {
+                    er = __builtin_amdgcn_readlane(ev, 32 + ch);
+                    ar = p.AR ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(ev, 34 + ch)) : 65536.f * p2_exp2i(er);
                 }
                 rsc[ch] = p2_exp2i(er);
                 int* E = (OUT == P2_OUT_QKV && tn == 2) ? p.EVt : p.EC;
@@ -221,8 +222,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(acc[2 * ch + jj][i][r]));
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+                am = p2_wave_max(am);
                 const float bound = am * os + p.bias_amax + ar;
                 const int e = p2_pick_exponent(bound * cs);
                 osc[ch] = p2_exp2i(-e);
@@ -393,9 +393,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         if (OUT == P2_OUT_PLANES && p.AC) {
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
-                float a = amx[ch];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o));
+                const float a = p2_wave_max(amx[ch]);
                 const int cb = tn * 4 + wc * 2 + ch;
                 if (lane == 0 && erow * 64 < p.M && cb < p.eld_c) p.AC[erow * p.eld_c + cb] = a;
             }
@@ -434,15 +432,28 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
     // they are rescaled (exact: a power of two) - a wave-uniform branch that an ordinary network never takes
     // The exponents of a tile's K blocks are fetched ONCE, by one vector load (lane i: block i of this wave's 64 rows; the
     // next tile's before the epilogue of this one), and read with v_readlane in the loop: no memory operation there.
-    const bool has_e = p.EA != nullptr;
+    // Lanes 32, 33 / 34, 35 of the same load bring the exponents / max |x| of the two residual blocks this wave adds in the
+    // tile's epilogue (a dependent load there would cost an L2 / HBM round trip per tile with the matrix pipe idle).
+    const bool has_e = p.EA != nullptr || (HAS_R && p.ER != nullptr);
     int e_run = 0, cur_kt = 0;
     int ev = 0, ev_next = 0;
     auto fetch_e = [&](int t) {
         int v = 0;
         if (has_e) {
-            const int erow = (t / p.tiles_n) * 4 + wr;
+            const int tm_ = t / p.tiles_n, tn_ = t - tm_ * p.tiles_n;
+            const int erow = tm_ * 4 + wr;
             const int nb1 = nk1 >> 1, nb = (nk + 1) >> 1;
-            if (erow * 64 < p.M && lane < nb) v = lane < nb1 ? p.EA[erow * p.eld_a + lane] : (p.EA2 ? p.EA2[erow * p.eld_a2 + lane - nb1] : 0);
+            if (erow * 64 < p.M) {
+                if (lane < nb) {
+                    if (p.EA) v = lane < nb1 ? p.EA[erow * p.eld_a + lane] : (p.EA2 ? p.EA2[erow * p.eld_a2 + lane - nb1] : 0);
+                } else if (HAS_R && p.ER && lane >= 32 && lane < 36) {
+                    const int cb = tn_ * 4 + wc * 2 + (lane & 1);
+                    if (cb < p.eld_r) {
+                        if (lane < 34) v = p.ER[erow * p.eld_r + cb];
+                        else if (p.AR) v = __builtin_bit_cast(int, p.AR[erow * p.eld_r + cb]);
+                    }
+                }
+            }
         }
         return v;
     };
@@ -467,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (DBG & 8) t1 = clock64();
         if (has_e) {
-            const int e_step = __builtin_amdgcn_readlane(ev, cur_kt >> 1);
+            const int e_step = p.EA ? __builtin_amdgcn_readlane(ev, cur_kt >> 1) : 0;
             if (!decltype(FIRST)::value && e_step != e_run) {
                 const int d = e_run - e_step;
                 const float f = d < -126 ? 0.f : p2_exp2i(d);
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         }
         cur_kt = 0;
         if (has_e && nk < 4 && tile + slots < t_end) ev_next = fetch_e(tile + slots);
-        if (!(DBG & 4)) epilogue(tile, e_run);
+        if (!(DBG & 4)) epilogue(tile, e_run, ev);
         else asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));
         ev = ev_next;
         since = overlap ? 0 : 8;

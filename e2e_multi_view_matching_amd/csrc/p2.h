@@ -85,6 +85,20 @@ constexpr int P2_EMIN = -16, P2_EMAX = 60;
 __host__ __device__ __forceinline__ float p2_exp2i(int e) {  // 2^e, |e| <= 126
     return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
 }
+// max over the 64 lanes of a wave on the DPP cross-lane path (no LDS crossbar round trips); every lane gets the result
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float p2_dpp(float identity, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float p2_wave_max(float v) {  // v >= 0
+    v = fmaxf(v, p2_dpp<0xB1, 0xF>(v, v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, p2_dpp<0x4E, 0xF>(v, v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, p2_dpp<0x141, 0xF>(v, v));   // row_half_mirror
+    v = fmaxf(v, p2_dpp<0x140, 0xF>(v, v));   // row_mirror
+    v = fmaxf(v, p2_dpp<0x142, 0xA>(0.f, v)); // row_bcast:15 into rows 1 and 3
+    v = fmaxf(v, p2_dpp<0x143, 0xC>(0.f, v)); // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ int p2_pick_exponent(float bound) {
     if (!(bound < 3.0e38f)) return 0;  // inf / NaN: the values go through as they are
     const int lg = (int)((__builtin_bit_cast(unsigned, bound) >> 23) & 255u) - 127;  // floor(log2 bound) for normal numbers
