@@ -517,9 +517,11 @@ def run(args):
     def roofline_of(prof_, mode_):
         fl = algorithmic_flops(B, T, N, D, args.layers, True)
         fam = max(("gemm", "attention"), key=lambda k: prof_[k]["ms"])
+        gen3 = mode_ == "f16x2" and getattr(wl, "ctx", None) is not None and wl.ctx.f16x2_kernels == 3
         kname = {"f32": {"gemm": "gemm_nt_kernel", "attention": "attention_kernel"},
                  "bf16x3": {"gemm": "gemm_x3_kernel", "attention": "attention3f_kernel"},
-                 "f16x2": {"gemm": "gemm_h2_kernel", "attention": "attention_h2f_kernel"}}[mode_][fam]
+                 "f16x2": {"gemm": "gemm_p2_kernel" if gen3 else "gemm_h2_kernel",
+                           "attention": "attention_p2_kernel" if gen3 else "attention_h2f_kernel"}}[mode_][fam]
         # f32 mode: exact fp32 MFMA.  bf16x3 mode: every algorithmic flop is 6 bf16-MFMA flops, so the ceiling for
         # ALGORITHMIC flops is the dense bf16 peak / 6.
         # f16x2 mode: 3 fp16-MFMA flops per algorithmic flop.
@@ -540,9 +542,21 @@ def run(args):
             traffic = int(k["read_bytes"] + k["write_bytes"])
         except Exception:
             traffic = None
+        # compulsory HBM bytes of the family per step (activations are 4 bytes per element in every mode: fp32, or a pair of
+        # fp16 planes; the weights stay in L2): the floor the operand / result stream sets next to the matrix-core ceiling
+        Mt, L = B * T * N, len(args.layers)
+        hbm = {"gemm": L * Mt * D * 4 * (1 + 3 + 2 + 2 + 2 + 1 + 1), "attention": L * Mt * D * 4 * (3 + 1)}[fam]
+        floor_ms = hbm / (PEAK_HBM_GBS * 1e9) * 1e3
         main = {"bound": "mfma", "kernel": kname, "mode": mode_,
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command (tools/gpu.sh prof), not measured in this run",
+                "limiter": ("the matrix-core ceiling is the stated peak; what the kernel actually waits for is its operand / result stream "
+                            "(LDS fill from L2 and the synchronized epilogue store burst, DESIGN.md 4d) - see hbm_floor"),
+                "hbm_floor": {"bytes_per_step": int(hbm), "bytes_per_launch": int(hbm // max(n // args.steps, 1)),
+                              "ms_per_step_at_peak_hbm": round(floor_ms, 3), "peak_gbs": PEAK_HBM_GBS,
+                              "frac_of_family_time": round(floor_ms / (ms / args.steps), 4),
+                              "note": "layer GEMMs / attention only (the family's small launches add < 2 %)"},
                 "note": ("algorithmic flops of the family / HIP-event time; " +
                          ("exact fp32 MFMA (v_mfma_f32_32x32x2_f32)" if mode_ == "f32" else
                           f"peak = dense 16-bit MFMA 2500 TFLOP/s / {products} MFMA products per algorithmic flop (split operands)")) +
@@ -559,17 +573,25 @@ def run(args):
         out["roofline"], out["roofline_second"], out["families"] = roofline_of(prof, mode)
         sk = prof["sinkhorn"]
         if sk["ms"] > 0:
-            model_bytes = B * P * (2 * args.sinkhorn_iters + 2) * (N + 1) ** 2 * 4
-            gbs = model_bytes * args.steps / (sk["ms"] * 1e-3) / 1e9
-            physical = B * P * 2 * N * N * 4 + B * P * (N + 1) ** 2 * 4  # scores read by the resident kernel and by the final sweep, logZ written
-            out["sinkhorn_roofline"] = {"bound": "hbm (model) / on-chip exchange latency (resident kernel)", "achieved": round(gbs, 1),
-                                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                        "physical_hbm_gbs": round(physical * args.steps / (sk["ms"] * 1e-3) / 1e9, 1),
-                                        "note": "achieved = SURVEY 8(d) byte model (2 sweeps of the couplings per iteration) / time - "
-                                                "above the HBM peak by construction: the resident kernel keeps exp(S - rowmax) in "
-                                                "registers for all iterations and reads the scores from HBM once (plus once in the "
-                                                "final sweep that writes logZ): physical_hbm_gbs is that traffic / time; the kernel is "
-                                                "bound by the per-iteration exchange between the workgroups of a problem (profiles/)"}
+            # A resident kernel: the scores are read from HBM once (plus once by the final sweep that writes logZ), every
+            # iteration after that is on-chip.  Its floor is iterations x rounds x the exchange between the workgroups of a
+            # problem (two dependent store -> poll hops through the device-coherent level, measured alone on the chip:
+            # profiles/README.md), not a byte rate; the arithmetic (one packed FMA per element per half-iteration) is the rest.
+            ms_call = sk["ms"] / args.steps
+            problems = B * P
+            resident = max(1, min(problems, (2 * 256) // max((N + 31) // 32, 1)))   # 2 workgroups / CU x 256 CUs, 32 rows each
+            rounds = -(-problems // resident)
+            hop_us = 2.75  # one problem alone on the chip: 5.5 us per iteration = 2 dependent exchanges (profiles/README.md)
+            exch_ms = rounds * args.sinkhorn_iters * 2 * hop_us * 1e-3
+            fma_ms = rounds * args.sinkhorn_iters * 2 * (resident * N * N / 2) / (256 * 64 * 2.0e9) * 1e3  # packed fp32 FMA: 2 elements / lane / clk
+            physical = problems * 2 * N * N * 4 + problems * (N + 1) ** 2 * 4
+            out["sinkhorn_bound"] = {"bound": "inter-workgroup exchange latency (resident kernel)", "ms_per_call": round(ms_call, 3),
+                                     "iterations": args.sinkhorn_iters, "problems": problems, "resident_problems": resident, "rounds": rounds,
+                                     "exchange_floor_ms": round(exch_ms, 3), "arithmetic_floor_ms": round(fma_ms, 3),
+                                     "frac": round((exch_ms + fma_ms) / ms_call, 4),
+                                     "physical_hbm_gbs": round(physical / (ms_call * 1e-3) / 1e9, 1),
+                                     "note": "frac = (exchange floor + arithmetic floor) / measured; the SURVEY 8(d) byte model (2 sweeps of the "
+                                             "couplings per iteration from HBM) does not describe a kernel that keeps them in registers"}
     for alt, alt_prof in alts:
         if alt_prof:
             alt["roofline"], alt["roofline_second"], alt["families"] = roofline_of(alt_prof, alt["mode"])

@@ -63,6 +63,74 @@ __device__ void jacobi_dynamic(double* A, double* V, int n) {
     }
 }
 
+// 9 x 9 symmetric eigen-problem on a whole workgroup (>= 81 threads; every thread of the block must call): A (overwritten,
+// eigenvalues on its diagonal), B scratch, V0 / V1 eigenvector ping-pong; returns the buffer that holds the eigenvectors
+// (columns).  Same rotation formulas, thresholds and sweep limit as jacobi_dynamic; round-robin pair order.
+__device__ double* jacobi9_parallel(double* A, double* B, double* V0, double* V1, double* rot, int* part, int tid) {
+    const int i = tid / 9, j = tid - 9 * i;
+    const bool own = tid < 81;
+    if (own) V0[tid] = (i == j) ? 1.0 : 0.0;
+    double* Vc = V0;
+    double* Vn = V1;
+    __syncthreads();
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        if (tid == 0) {
+            double off = 0.0, dg = 0.0;
+            for (int a = 0; a < 9; ++a) {
+                dg += A[a * 9 + a] * A[a * 9 + a];
+                for (int c = a + 1; c < 9; ++c) off += A[a * 9 + c] * A[a * 9 + c];
+            }
+            part[9] = (off <= 1e-60 || off <= 1e-34 * dg) ? 1 : 0;
+        }
+        __syncthreads();
+        if (part[9]) break;
+        for (int r = 0; r < 9; ++r) {
+            if (tid < 4) {
+                const int k = tid + 1;
+                int p = (r + k) % 9, q = (r + 9 - k) % 9;
+                if (p > q) { const int t_ = p; p = q; q = t_; }
+                const double apq = A[p * 9 + q];
+                double c = 1.0, sn = 0.0;
+                if (!(fabs(apq) < 1e-300)) {
+                    const double theta = (A[q * 9 + q] - A[p * 9 + p]) / (2.0 * apq);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0);
+                    sn = t * c;
+                }
+                rot[2 * p] = c; rot[2 * p + 1] = -sn;   // index p:  new_p = c x_p - s x_q
+                rot[2 * q] = c; rot[2 * q + 1] = sn;    // index q:  new_q = c x_q + s x_p
+                part[p] = q;
+                part[q] = p;
+            } else if (tid == 4) {
+                part[r] = -1;
+            }
+            __syncthreads();
+            if (own) {  // columns: B = A J, Vn = Vc J
+                const int pj = part[j];
+                if (pj >= 0) {
+                    const double c = rot[2 * j], sg = rot[2 * j + 1];
+                    B[tid] = c * A[tid] + sg * A[i * 9 + pj];
+                    Vn[tid] = c * Vc[tid] + sg * Vc[i * 9 + pj];
+                } else {
+                    B[tid] = A[tid];
+                    Vn[tid] = Vc[tid];
+                }
+            }
+            __syncthreads();
+            if (own) {  // rows: A = J^T B; the rotated pair's off-diagonal entry is zero by construction
+                const int pi = part[i];
+                double v = B[tid];
+                if (pi >= 0) v = rot[2 * i] * v + rot[2 * i + 1] * B[pi * 9 + j];
+                if (pi == j) v = 0.0;
+                A[tid] = v;
+            }
+            double* t_ = Vc; Vc = Vn; Vn = t_;
+            __syncthreads();
+        }
+    }
+    return Vc;
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -122,7 +190,11 @@ __device__ __forceinline__ double angle_err(const double* R, const double* t, co
 // Kernel 1: one workgroup per pair -> normalised points, weights, essential matrix, candidates.
 __global__ __launch_bounds__(256) void w8pt_fundamental(W8Params p) {
     __shared__ double sG[81];
-    __shared__ double sV[81];
+    __shared__ double sB[81];
+    __shared__ double sV1[81];
+    __shared__ double sV2[81];
+    __shared__ double srot[18];
+    __shared__ int spart[12];
     __shared__ double sred[4 * 48];
     __shared__ double sstat[16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -213,10 +285,15 @@ __global__ __launch_bounds__(256) void w8pt_fundamental(W8Params p) {
         sG[c * 9 + a] = v;
     }
     __syncthreads();
+    // ---- eigen-decomposition of the 9 x 9 Gram matrix: cyclic Jacobi with PARALLEL rotations.  A round rotates the four
+    // disjoint index pairs {(r + k) mod 9, (r - k) mod 9}, k = 1..4 (index r rests; 9 rounds = all 36 pairs = one sweep);
+    // thread (i, j) owns element (i, j) of A and V: columns first (A J, V J), then rows (J^T A), ping-pong buffers, three
+    // barriers per round - the serial form on one thread was 0.1 ms of dependent fp64 LDS traffic per call.
+    double* const V = jacobi9_parallel(sG, sB, sV1, sV2, srot, spart, tid);
     if (tid != 0) return;
 
     // ---- single-thread tail: tiny dense algebra in fp64 ----
-    jacobi_dynamic(sG, sV, 9);
+    double* const sV = V;
     // The reference takes V[..., -1] of torch.svd(X) with X [N,9] (:72-73).  For N >= 9 that is
     // the right singular vector of the smallest singular value; for N == 8 the thin SVD only has
     // 8 columns, so it is the vector of the smallest of the 8 NON-null singular values, not the

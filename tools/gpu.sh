@@ -3,6 +3,7 @@
 #   planes   per-kernel parity of the plane kernels + matcher parity + micro-benchmarks + bench A/B (plane vs round-2 kernels)
 #   tests    the whole -m gpu suite
 #   bench    bench.py lines (c2 default, c4, c5)
+#   one      one short bench line with its roofline / sinkhorn_bound objects printed
 #   kt       rocprofv3 kernel trace of one config / mode
 #   prof     rocprofv3 kernel trace + the three PMC passes of config c2
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -48,6 +49,12 @@ bench)
   timeout 300 python bench.py --config c4 --cpu-pairs 0 > $OUT/bench_c4.json 2> $OUT/bench_c4.err
   timeout 300 python bench.py --config c5 --cpu-pairs 0 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
   show $OUT/bench_c2.json $OUT/bench_c4.json $OUT/bench_c5.json
+  ;;
+one)
+  timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_one.json 2> $OUT/bench_one.err
+  show $OUT/bench_one.json
+  python -c "
+import json; d=json.loads(open('$OUT/bench_one.json').read().strip().splitlines()[-1]); print(json.dumps(d['roofline'], indent=1)); print(json.dumps(d.get('sinkhorn_bound'), indent=1))"
   ;;
 kt)
   cfg=${2:-c2}; mode=${3:-f16x2}
