@@ -159,6 +159,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_p2_kernel(
         // S^T of a 32-key block: 12 MFMAs on one accumulator (the first takes the zero C operand)
         auto qk = [&](int sub) {
             ap_f32x16 S;
+            __builtin_amdgcn_s_setprio(3);  // the matrix-core bursts of a wave go ahead of the other waves' softmax arithmetic (measured: -1.5 %)
             const char* kp = Kt + (sub * 32 + l31) * 256;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_p2_kernel(
                     }
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             return S;
         };
         // online softmax of the block + its P V products
@@ -190,7 +192,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_p2_kernel(
             float mx = S[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            {   // the other half of the key block sits in lane ^ 32: v_permlane32_swap instead of an LDS-crossbar shuffle (-1.5 %).
+                // Inline asm with two distinct registers: after the swap a = [lo, lo], b = [hi, hi] (hipcc 7.2 folds the two
+                // results of the builtin into one when both operands are the same value and loses the upper half).
+                float a = mx, b = mx;
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+                mx = fmaxf(a, b);
+            }
             // S (and m) are in units of 1 / P2_QS of a base-2 logit; P carries the factor 2^AP_PLOG (cancels in O / l).  Lazy
             // running maximum as in attention_h2f_kernel: m_run moves (and O, l are rescaled) only when a row's new maximum
             // exceeds it by more than 2^AP_LAZY; P then stays below 2^(AP_PLOG + AP_LAZY) = 32768, inside fp16's range
@@ -283,6 +291,9 @@ int launch_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv,
     p.cross = cross;
     p.groups = B * T * H;
     p.gper = (p.groups + 7) / 8;
+    static int nw_knob = -1;
+    if (nw_knob < 0) nw_knob = dbg_knob("E2EMV_AP2_NW", 0);
+    if (nw_knob == 4 || nw_knob == 8) ctx->attn_p2_nw = nw_knob;
     const int nw = ctx->attn_p2_nw == 4 || ctx->attn_p2_nw == 8 ? ctx->attn_p2_nw : (n_valid > 256 ? 8 : 4);  // measured: 222 / 224 us at 1024 keys, 202 / 209 at 2048
     const size_t lds = 2 * AP_BUFB;
     const void* fn = nw == 8 ? reinterpret_cast<const void*>(attention_p2_kernel<8>) : reinterpret_cast<const void*>(attention_p2_kernel<4>);
