@@ -44,7 +44,20 @@ def main(sq_db, fetch_db, write_db, out_md, out_json, config="c2", mode="f32", p
             if "SQ_VALU_MFMA_BUSY_CYCLES" in s and s["SQ_VALU_MFMA_BUSY_CYCLES"][1] > 0:
                 busy = f"{100.0 * s['SQ_VALU_MFMA_BUSY_CYCLES'][1] / (gui * 1024):.1f}"  # 256 CUs x 4 SIMDs
         lines.append(f"| {k[-48:]} | {n} | {dur / 1e3:.1f} | {f:.0f} | {rd / 1e6:.1f} | {wt / 1e6:.1f} | {busy} | {clock} |")
-        js["kernels"][k.split("::")[-1].split("<")[0].strip()] = {"read_bytes": rd, "write_bytes": wt, "launches": n}
+        # template variants of one kernel (gemm_p2_kernel<OUT, HAS_R>) share an entry: launch-weighted average; each variant
+        # also keeps its own entry under its full name
+        short = k.split("::")[-1].split("<")[0].strip()
+        full = k.split("::")[-1].strip()
+        if full != short:
+            js["kernels"][full] = {"read_bytes": rd, "write_bytes": wt, "launches": n}
+        e = js["kernels"].get(short)
+        if e is None or n == 0:
+            js["kernels"].setdefault(short, {"read_bytes": rd, "write_bytes": wt, "launches": n})
+        else:
+            tot = e["launches"] + n
+            e["read_bytes"] = (e["read_bytes"] * e["launches"] + rd * n) / tot
+            e["write_bytes"] = (e["write_bytes"] * e["launches"] + wt * n) / tot
+            e["launches"] = tot
     text = "\n".join(lines)
     open(out_md, "w").write("# rocprofv3 --pmc passes (separate runs: SQ+GRBM, FETCH_SIZE, WRITE_SIZE), bench.py --steps 2 --warmup 1\n\n"
                             + text + "\n")
