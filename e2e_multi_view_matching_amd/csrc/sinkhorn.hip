@@ -629,6 +629,51 @@ __device__ __forceinline__ bool granule_wait(const u64* base, const int (&off)[N
 }
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef unsigned skr_u32x4 __attribute__((ext_vector_type(4)));
+
+// Two granules of ADJACENT columns in one 16-byte write-through store / load (aux 16 = sc1): an 8-byte sc1 store is one
+// fabric write, 2.7x the time per byte of a 16-byte one (guide, price list), and the exchange is what the kernel waits for.
+// Each 8-byte half is a self-validating granule {value, tag}: the two halves need not arrive together.
+__device__ __forceinline__ void granule_store2(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned tag, float v0, float v1) {
+    const skr_u32x4 g = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(g, r, byte_off, 0, 16);
+}
+// polls until both granules of every lane-local pair carry `epoch` (same give-up protocol as granule_wait)
+template <int NMAX>
+__device__ __forceinline__ bool granule_wait2(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[NMAX], int n, unsigned epoch, unsigned (&val)[NMAX][2],
+                                              unsigned* timeout, bool& dead, bool nap = true) {
+    if (dead) {
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) { val[i][0] = 0x7fc00000u; val[i][1] = 0x7fc00000u; }
+        return false;
+    }
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i)
+            if (i < n) {
+                const skr_u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(r, off[i], 0, 16);
+                val[i][0] = g[0]; val[i][1] = g[2];
+                ok = ok && g[1] == epoch && g[3] == epoch;
+            }
+        if (__all(ok)) return true;
+        if ((spins & 255u) == 255u) {
+            const unsigned flag = __hip_atomic_load((__attribute__((address_space(1))) unsigned*)(timeout), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+            if (flag || spins >= SKR_SPIN_LIMIT) {
+                if ((threadIdx.x & 63) == 0) {
+                    if (!flag) atomicAdd(timeout + 4, 1u);
+                    atomicOr(timeout, 1u);
+                }
+                dead = true;
+#pragma unroll
+                for (int i = 0; i < NMAX; ++i) { val[i][0] = 0x7fc00000u; val[i][1] = 0x7fc00000u; }
+                return false;
+            }
+        }
+        if (nap) __builtin_amdgcn_s_sleep(1);
+    }
+}
 
 // exp(x) for x <= 0 with the product x*log2(e) carried in two pieces: relative error ~2e-7 also for |x| ~ 80 (the plain
 // fast exp loses |x| * 1e-7).  Runs once per matrix element per call.
@@ -639,7 +684,7 @@ __device__ __forceinline__ float exp_accurate(float x) {
     return __builtin_amdgcn_exp2f(y) * fmaf(r, 0.693147180559945f, 1.0f);
 }
 
-template <int KT, bool FULL>
+template <int KT, bool FULL, bool PAIR = false>
 __global__ __launch_bounds__(512, KT <= 4 ? 4 : 2) void sinkhorn_resident(SkResParams p) {
     constexpr int W = KT * 256;                       // padded column count held by a wave
     constexpr int RW = 4;                             // rows per wave: 64 matrix values per lane (KT <= 4: two workgroups per
@@ -672,6 +717,12 @@ __global__ __launch_bounds__(512, KT <= 4 ? 4 : 2) void sinkhorn_resident(SkResP
         const int c = tid + 512 * i, wc = c / cs, jl = c - wc * cs;
         dstA[i] = (wc * G + w) * cs + jl;
     }
+    // pair mode: a thread owns CPT ADJACENT columns and every granule travels as half of a 16-byte pair (needs an even
+    // column slice per consumer so that a pair never straddles two consumer regions)
+    // (PAIR is chosen by the launcher: KT >= 4 and cs even)
+    constexpr bool pair = PAIR && (CPT % 2 == 0);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(bufA, 0, G * G * cs * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(bufB, 0, G * cs * 8, 0x00020000);
     unsigned round = 0;
     for (int b = grp; b < p.B; b += p.n_res, ++round) {
         const unsigned ebase = round * (unsigned)p.iters;  // epochs run on without a gap: their parity alternates
@@ -768,7 +819,27 @@ __global__ __launch_bounds__(512, KT <= 4 ? 4 : 2) void sinkhorn_resident(SkResP
             if (dbg) dbg[1] = __builtin_amdgcn_s_memrealtime();
             __syncthreads();
             // ---- fold the 8 waves, publish the workgroup's partial column sums (stage A) and its dustbin-column sum
-            {
+            if constexpr (pair) {
+                float fT[CPT];
+#pragma unroll
+                for (int i = 0; i < CPT; ++i) {
+                    const int c = CPT * tq + i;
+                    float T = fold[c];
+#pragma unroll
+                    for (int wv = 1; wv < 8; ++wv) T += fold[wv * W + c];
+                    fT[i] = T;  // (columns >= N hold zeros: K is zero there)
+                }
+#pragma unroll
+                for (int i = 0; i < CPT; i += 2) {
+                    const int c = CPT * tq + i, wc = c / cs, jl = c - wc * cs;
+                    if (FULL || c < N) granule_store2(rsA, (unsigned)((wc * G + w) * cs + jl) * 8u, epoch, fT[i], fT[i + 1]);
+                }
+                if (tq == 0) {
+                    float U = red[0];
+                    for (int wv = 1; wv < 8; ++wv) U += red[wv];
+                    granule_store(bufU + w, epoch, U);
+                }
+            } else {
                 float fT[CPT];
 #pragma unroll
                 for (int i = 0; i < CPT; ++i) {
@@ -794,7 +865,33 @@ __global__ __launch_bounds__(512, KT <= 4 ? 4 : 2) void sinkhorn_resident(SkResP
             }
             if (dbg) dbg[2] = __builtin_amdgcn_s_memrealtime();
             // ---- stage A consume: my slice of columns over all producers -> b_j = nu / (sum + a_M), published as stage B
-            {
+            if constexpr (pair) {
+                const int q = tq & 15, cg = tq >> 4;
+                const unsigned base_b = (unsigned)(w * G * cs) * 8u;  // my consumer region: [producer][cs]
+                for (int j0 = 0; j0 < cs; j0 += 64) {
+                    const int jl = j0 + 2 * cg, c = w * cs + jl;
+                    const bool act = jl < cs && c < N;
+                    float T0 = 0.f, T1 = 0.f;
+                    for (int g0 = 0; g0 < G; g0 += 32) {  // wave-uniform trip count; two 16-byte loads in flight per lane
+                        unsigned off[2];
+                        unsigned val[2][2];
+                        int n = 0;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const int g = g0 + q + 16 * i;
+                            off[i] = base_b;
+                            if (act && g < G) { off[i] = base_b + (unsigned)(g * cs + jl) * 8u; n = i + 1; }
+                        }
+                        granule_wait2<2>(rsA, off, n, epoch, val, p.timeout, dead, nap);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (i < n) { T0 += __uint_as_float(val[i][0]); T1 += __uint_as_float(val[i][1]); }
+                    }
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) { T0 += __shfl_xor(T0, o); T1 += __shfl_xor(T1, o); }
+                    if (act && q == 0) granule_store2(rsB, (unsigned)c * 8u, epoch, mu / (T0 + aM), mu / (T1 + aM));  // nu_j = mu
+                }
+            } else {
                 const int q = tq & 15, cg = tq >> 4;
                 const u64* base = bufA + (int64_t)w * G * cs;  // my consumer region: [producer][cs]
                 for (int j0 = 0; j0 < cs; j0 += 32) {
@@ -837,6 +934,16 @@ __global__ __launch_bounds__(512, KT <= 4 ? 4 : 2) void sinkhorn_resident(SkResP
             }
             if (dbg) dbg[4] = __builtin_amdgcn_s_memrealtime();
             // ---- stage B consume: all of b into LDS
+            if constexpr (pair) {
+                for (int c0 = 0; c0 < W; c0 += 1024) {  // wave-uniform trip count
+                    const int ca = c0 + 2 * tq;
+                    unsigned off[1] = {ca < N ? (unsigned)ca * 8u : 0u};
+                    unsigned val[1][2];
+                    granule_wait2<1>(rsB, off, ca < N ? 1 : 0, epoch, val, p.timeout, dead, nap);
+                    if (ca < W) *reinterpret_cast<f32x2*>(vbuf + ca) = f32x2{ca < N ? __uint_as_float(val[0][0]) : 0.f,
+                                                                            ca + 1 < N ? __uint_as_float(val[0][1]) : 0.f};
+                }
+            } else
             for (int c0 = 0; c0 < W; c0 += 1024) {  // wave-uniform trip count
                 const int ca = c0 + tq, cb = c0 + 512 + tq;
                 int off[2] = {ca < N ? ca : 0, cb < N ? cb : 0};
@@ -1066,11 +1173,21 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
     const size_t res_lds = sizeof(float) * (size_t)(9 * KT_of(ldS) * 256 + 4 + 32);
     if (resident) {
         const bool full = N == ldS && N == KT_of(ldS) * 256;
+        // granule pairs (16-byte exchange stores / loads): a thread must own an even number of columns and a consumer's column
+        // slice must be even
+        const int G0 = (M + skr_rows(ldS) - 1) / skr_rows(ldS);
+        const bool pairs = KT_of(ldS) >= 4 && ((N + G0 - 1) / G0) % 2 == 0 && dbg_knob("E2EMV_SKR_PAIR", 1) != 0;
         switch (KT_of(ldS)) {
             case 1: kfn = full ? (const void*)sinkhorn_resident<1, true> : (const void*)sinkhorn_resident<1, false>; break;
             case 2: kfn = full ? (const void*)sinkhorn_resident<2, true> : (const void*)sinkhorn_resident<2, false>; break;
-            case 4: kfn = full ? (const void*)sinkhorn_resident<4, true> : (const void*)sinkhorn_resident<4, false>; break;
-            default: kfn = full ? (const void*)sinkhorn_resident<8, true> : (const void*)sinkhorn_resident<8, false>; break;
+            case 4:
+                if (pairs) kfn = full ? (const void*)sinkhorn_resident<4, true, true> : (const void*)sinkhorn_resident<4, false, true>;
+                else kfn = full ? (const void*)sinkhorn_resident<4, true> : (const void*)sinkhorn_resident<4, false>;
+                break;
+            default:
+                if (pairs) kfn = full ? (const void*)sinkhorn_resident<8, true, true> : (const void*)sinkhorn_resident<8, false, true>;
+                else kfn = full ? (const void*)sinkhorn_resident<8, true> : (const void*)sinkhorn_resident<8, false>;
+                break;
         }
         static std::map<std::pair<int, const void*>, int> occupancy;  // (device, kernel) -> resident workgroups per CU
         static std::mutex occupancy_mu;
