@@ -36,7 +36,11 @@ def run(B, N, iters, flags, path):
     t = rows[:, 2:].reshape(-1, int(rows[:, 1].max()) + 1, 7)  # [it][g][7]
     t = t[2:14]  # steady-state iterations
     d = np.diff(t, axis=2) * 10.0  # ns
-    names = ["rows+cols", "sync1", "fold+pubA", "stageA+pubB", "vN", "stageB poll", "sync2"]
+    # stamps (thread 0 of every workgroup): [0] iteration start, [1] after the row half-iteration and the wave's column partials,
+    # [2] after the barrier, the fold of the 8 waves and the stage-A publish, [3] after the stage-A wait / reduce and the
+    # stage-B publish, [4] after wave 0's dustbin-statistic poll, [5] after the stage-B poll, [6] after the closing barrier.
+    # (Until round 3 the labels below were shifted by one interval against the stamps.)
+    names = ["rows+cols", "barrier+fold+pubA", "stageA wait+reduce+pubB", "dustbin poll (wave 0)", "stageB poll", "closing barrier"]
     per = d.mean(axis=(0, 1))
     it_time = (t[1:, :, 0] - t[:-1, :, 0]).mean() * 10.0
     print(f"B={B} N={N} flags={flags}: {dt * 1e3:.3f} ms/call incl. final+match ({dt / iters * 1e6:.2f} us/iter); "
