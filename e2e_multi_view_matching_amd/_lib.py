@@ -113,6 +113,8 @@ SIGNATURES = {
     "e2emv_matcher_forward_train": (c_int, [c_void_p, ctypes.POINTER(ForwardDesc), _PP, _PP, _PP, _PP, c_void_p]),
     "e2emv_matcher_backward": (c_int, [c_void_p, _PP, c_void_p]),
     "e2emv_get_grad": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, c_void_p]),
+    "e2emv_w8pt_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e2emv_pose_errors_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_get_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_uint64), c_int, c_int]),
     "e2emv_profile": (c_int, [c_void_p, c_int]),
     "e2emv_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int64), c_int, c_int]),

@@ -187,6 +187,98 @@ __device__ __forceinline__ double angle_err(const double* R, const double* t, co
     return er + et;
 }
 
+// Everything behind the eigenvector of the weighted 8-point solve (estimate_relative_pose.py:74-82 + kornia's
+// decompose_essential_matrix): rank-2 projection of F (row-major 3x3, Hartley-normalised frame), de-normalisation, / E22,
+// E -> (R1, R2, t).  One thread, fp64.  Shared by the forward kernel and by the backward (which differentiates it
+// numerically: it is a smooth function of nine numbers).  Returns status bit 4 (degenerate E: completed deterministically).
+__device__ int w8pt_tail(double* Fm, double s0, double mx0, double my0, double s1, double mx1, double my1, double* E, double* R1, double* R2,
+                         double* tv) {
+    int st = 0;
+    // rank 2: remove the smallest singular direction
+    {
+        double A3[3][3], V3[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) A3[i][j] = Fm[i] * Fm[j] + Fm[3 + i] * Fm[3 + j] + Fm[6 + i] * Fm[6 + j];  // F^T F
+        jacobi_static<3>(A3, V3);
+        int m3 = 0;
+        if (A3[1][1] < A3[m3][m3]) m3 = 1;
+        if (A3[2][2] < A3[m3][m3]) m3 = 2;
+        const double v[3] = {V3[0][m3], V3[1][m3], V3[2][m3]};
+        for (int i = 0; i < 3; ++i) {
+            const double fv = Fm[i * 3] * v[0] + Fm[i * 3 + 1] * v[1] + Fm[i * 3 + 2] * v[2];
+            for (int j = 0; j < 3; ++j) Fm[i * 3 + j] -= fv * v[j];
+        }
+    }
+    // de-normalise: T2^T F T1 with T = [[s,0,-s mx],[0,s,-s my],[0,0,1]]
+    {
+        const double T1[9] = {s0, 0, -s0 * mx0, 0, s0, -s0 * my0, 0, 0, 1};
+        const double T2t[9] = {s1, 0, 0, 0, s1, 0, -s1 * mx1, -s1 * my1, 1};
+        double tmp[9];
+        mat3_mul(Fm, T1, tmp);
+        mat3_mul(T2t, tmp, E);
+        if (fabs(E[8]) > 1e-8) {  // normalize_transformation
+            const double d = E[8] + 1e-8;
+            for (int i = 0; i < 9; ++i) E[i] /= d;
+        }
+    }
+    // ---- essential decomposition ----
+    {
+        double A3[3][3], V3[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) A3[i][j] = E[i] * E[j] + E[3 + i] * E[3 + j] + E[6 + i] * E[6 + j];
+        jacobi_static<3>(A3, V3);
+        // order eigenvalues descending: i0 >= i1 >= i2
+        int i0 = 0, i2 = 0;
+        for (int i = 1; i < 3; ++i) {
+            if (A3[i][i] > A3[i0][i0]) i0 = i;
+            if (A3[i][i] < A3[i2][i2]) i2 = i;
+        }
+        if (i0 == i2) { i0 = 0; i2 = 2; }
+        const int i1 = 3 - i0 - i2;
+        double v1[3] = {V3[0][i0], V3[1][i0], V3[2][i0]};
+        double v2[3] = {V3[0][i1], V3[1][i1], V3[2][i1]};
+        double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+        double u1[3], u2[3];
+        for (int i = 0; i < 3; ++i) {
+            u1[i] = E[i * 3] * v1[0] + E[i * 3 + 1] * v1[1] + E[i * 3 + 2] * v1[2];
+            u2[i] = E[i * 3] * v2[0] + E[i * 3 + 1] * v2[1] + E[i * 3 + 2] * v2[2];
+        }
+        // Degenerate inputs (no usable correspondence: all weights zero, or every gathered point identical) give E of rank
+        // 1 or 0.  A library SVD still returns an orthonormal U there (arbitrary in the null space); U = E V / sigma would
+        // divide by zero, so the missing columns are completed deterministically and the case is flagged (status bit 2).
+        double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+        if (n1 > 1e-150) {
+            for (int i = 0; i < 3; ++i) u1[i] /= n1;
+        } else {
+            u1[0] = 1.0; u1[1] = 0.0; u1[2] = 0.0;
+            st |= 4;
+        }
+        // Gram-Schmidt keeps U orthonormal when sigma1 ~ sigma2 makes E v2 slightly oblique
+        double dp = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+        for (int i = 0; i < 3; ++i) u2[i] -= dp * u1[i];
+        double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+        if (!(n2 > 1e-7 * n1) || !(n2 > 1e-150)) {  // sigma2 ~ 0: any unit vector orthogonal to u1
+            int a = 0;
+            if (fabs(u1[1]) < fabs(u1[a])) a = 1;
+            if (fabs(u1[2]) < fabs(u1[a])) a = 2;
+            for (int i = 0; i < 3; ++i) u2[i] = (i == a ? 1.0 : 0.0) - u1[a] * u1[i];
+            n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+            st |= 4;
+        }
+        for (int i = 0; i < 3; ++i) u2[i] /= n2;
+        double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
+        // R1 = U W V^T, R2 = U W^T V^T,  W = [[0,-1,0],[1,0,0],[0,0,1]]
+        // U W   = [u2, -u1, u3] (columns);  U W^T = [-u2, u1, u3]
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                R1[i * 3 + j] = u2[i] * v1[j] - u1[i] * v2[j] + u3[i] * v3[j];
+                R2[i * 3 + j] = -u2[i] * v1[j] + u1[i] * v2[j] + u3[i] * v3[j];
+            }
+        for (int i = 0; i < 3; ++i) tv[i] = u3[i];
+    }
+    return st;
+}
+
 // Kernel 1: one workgroup per pair -> normalised points, weights, essential matrix, candidates.
 __global__ __launch_bounds__(256) void w8pt_fundamental(W8Params p) {
     __shared__ double sG[81];
@@ -312,96 +404,14 @@ __global__ __launch_bounds__(256) void w8pt_fundamental(W8Params p) {
     }
     double Fm[9];
     for (int i = 0; i < 9; ++i) Fm[i] = sV[i * 9 + mi];  // row-major 3x3 (E6)
-    // rank 2: remove the smallest singular direction
-    {
-        double A3[3][3], V3[3][3];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) A3[i][j] = Fm[i] * Fm[j] + Fm[3 + i] * Fm[3 + j] + Fm[6 + i] * Fm[6 + j];  // F^T F
-        jacobi_static<3>(A3, V3);
-        int m3 = 0;
-        if (A3[1][1] < A3[m3][m3]) m3 = 1;
-        if (A3[2][2] < A3[m3][m3]) m3 = 2;
-        const double v[3] = {V3[0][m3], V3[1][m3], V3[2][m3]};
-        for (int i = 0; i < 3; ++i) {
-            const double fv = Fm[i * 3] * v[0] + Fm[i * 3 + 1] * v[1] + Fm[i * 3 + 2] * v[2];
-            for (int j = 0; j < 3; ++j) Fm[i * 3 + j] -= fv * v[j];
-        }
-    }
-    // de-normalise: T2^T F T1 with T = [[s,0,-s mx],[0,s,-s my],[0,0,1]]
-    double E[9];
-    {
-        const double T1[9] = {s0, 0, -s0 * mx0, 0, s0, -s0 * my0, 0, 0, 1};
-        const double T2t[9] = {s1, 0, 0, 0, s1, 0, -s1 * mx1, -s1 * my1, 1};
-        double tmp[9];
-        mat3_mul(Fm, T1, tmp);
-        mat3_mul(T2t, tmp, E);
-        if (fabs(E[8]) > 1e-8) {  // normalize_transformation
-            const double d = E[8] + 1e-8;
-            for (int i = 0; i < 9; ++i) E[i] /= d;
-        }
-    }
-    int st = 0;
+    double E[9], R1[9], R2[9], tv[3];
+    const int st_tail = w8pt_tail(Fm, s0, mx0, my0, s1, mx1, my1, E, R1, R2, tv);
+    int st = st_tail;
     if (!(sstat[4] > 1e-6)) st |= 1;
     for (int i = 0; i < 9; ++i) {
         p.E[b * 9 + i] = E[i];
         if (p.F) p.F[b * 9 + i] = (float)E[i];
         if (!isfinite(E[i])) st |= 2;
-    }
-    // ---- essential decomposition ----
-    double R1[9], R2[9], tv[3];
-    {
-        double A3[3][3], V3[3][3];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) A3[i][j] = E[i] * E[j] + E[3 + i] * E[3 + j] + E[6 + i] * E[6 + j];
-        jacobi_static<3>(A3, V3);
-        // order eigenvalues descending: i0 >= i1 >= i2
-        int i0 = 0, i2 = 0;
-        for (int i = 1; i < 3; ++i) {
-            if (A3[i][i] > A3[i0][i0]) i0 = i;
-            if (A3[i][i] < A3[i2][i2]) i2 = i;
-        }
-        if (i0 == i2) { i0 = 0; i2 = 2; }
-        const int i1 = 3 - i0 - i2;
-        double v1[3] = {V3[0][i0], V3[1][i0], V3[2][i0]};
-        double v2[3] = {V3[0][i1], V3[1][i1], V3[2][i1]};
-        double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
-        double u1[3], u2[3];
-        for (int i = 0; i < 3; ++i) {
-            u1[i] = E[i * 3] * v1[0] + E[i * 3 + 1] * v1[1] + E[i * 3 + 2] * v1[2];
-            u2[i] = E[i * 3] * v2[0] + E[i * 3 + 1] * v2[1] + E[i * 3 + 2] * v2[2];
-        }
-        // Degenerate inputs (no usable correspondence: all weights zero, or every gathered point identical) give E of rank
-        // 1 or 0.  A library SVD still returns an orthonormal U there (arbitrary in the null space); U = E V / sigma would
-        // divide by zero, so the missing columns are completed deterministically and the case is flagged (status bit 2).
-        double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
-        if (n1 > 1e-150) {
-            for (int i = 0; i < 3; ++i) u1[i] /= n1;
-        } else {
-            u1[0] = 1.0; u1[1] = 0.0; u1[2] = 0.0;
-            st |= 4;
-        }
-        // Gram-Schmidt keeps U orthonormal when sigma1 ~ sigma2 makes E v2 slightly oblique
-        double dp = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
-        for (int i = 0; i < 3; ++i) u2[i] -= dp * u1[i];
-        double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
-        if (!(n2 > 1e-7 * n1) || !(n2 > 1e-150)) {  // sigma2 ~ 0: any unit vector orthogonal to u1
-            int a = 0;
-            if (fabs(u1[1]) < fabs(u1[a])) a = 1;
-            if (fabs(u1[2]) < fabs(u1[a])) a = 2;
-            for (int i = 0; i < 3; ++i) u2[i] = (i == a ? 1.0 : 0.0) - u1[a] * u1[i];
-            n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
-            st |= 4;
-        }
-        for (int i = 0; i < 3; ++i) u2[i] /= n2;
-        double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
-        // R1 = U W V^T, R2 = U W^T V^T,  W = [[0,-1,0],[1,0,0],[0,0,1]]
-        // U W   = [u2, -u1, u3] (columns);  U W^T = [-u2, u1, u3]
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                R1[i * 3 + j] = u2[i] * v1[j] - u1[i] * v2[j] + u3[i] * v3[j];
-                R2[i * 3 + j] = -u2[i] * v1[j] + u1[i] * v2[j] + u3[i] * v3[j];
-            }
-        for (int i = 0; i < 3; ++i) tv[i] = u3[i];
     }
     double* cd = p.cands + (int64_t)b * 48;
     for (int c = 0; c < 4; ++c) {
@@ -423,6 +433,201 @@ __global__ __launch_bounds__(256) void w8pt_fundamental(W8Params p) {
     p.sel[b] = sel;
     for (int c = 0; c < 4; ++c) p.counts[b * 4 + c] = 0;
     if (p.status) p.status[b] = st;
+}
+
+// ---- backward of the weighted 8-point solve with respect to the confidences (training, second slice: the pose loss) ----------
+// T = tail(f), f = eigenvector (smallest eigenvalue) of A = sum_n w_n^2 x_n x_n^T, w_n = c_n / (sum c + 1e-6) (weights multiply
+// the design ROWS, E1; the Hartley statistics are unweighted, E2: they do not depend on c).  Given g_T = dL/dT:
+//   g_f  = J^T g_T, J = dT/df by central differences of the tail in fp64 (a smooth function of nine numbers; every perturbed
+//          evaluation picks the candidate closest to the forward's T, so eigenvector sign / branch flips cannot leak in),
+//   y    = (A - lambda I)^+ g_f = sum_{k != min} v_k (v_k . g_f) / (lambda_k - lambda)        (df = -(A - lambda I)^+ dA f),
+//   dL/dw_n = -2 w_n (y . x_n)(f . x_n),   dL/dc_m = dL/dw_m / S - (sum_n dL/dw_n c_n) / S^2,  S = sum c + 1e-6.
+// One workgroup per sample; the eigen-problem is recomputed (cheaper than a tape: 40 us per call of 32 samples).
+struct W8BwdParams {
+    int B, N;
+    const float* k0n;   // [B][N][2] normalised camera coordinates (info["kpts0_norm"])
+    const float* k1n;
+    const float* conf;  // [B][N] the confidences handed to the forward (unnormalised)
+    const float* T;     // [B][16] the forward's pose
+    const float* gT;    // [B][16] dL/dT
+    float* gconf;       // [B][N] out
+};
+
+__global__ __launch_bounds__(256) void w8pt_backward_kernel(W8BwdParams p) {
+    __shared__ double sG[81];
+    __shared__ double sB[81];
+    __shared__ double sV1[81];
+    __shared__ double sV2[81];
+    __shared__ double srot[18];
+    __shared__ int spart[12];
+    __shared__ double sred[4 * 48];
+    __shared__ double sstat[16];
+    __shared__ double sT[18 * 12];
+    __shared__ double sf[9], sgf[9], sy[9];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = p.N;
+    const float* k0n = p.k0n + (int64_t)b * N * 2;
+    const float* k1n = p.k1n + (int64_t)b * N * 2;
+    const float* cf = p.conf + (int64_t)b * N;
+    float* gc = p.gconf + (int64_t)b * N;
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int i = tid; i < N; i += 256) {
+        acc[0] += k0n[2 * i]; acc[1] += k0n[2 * i + 1]; acc[2] += k1n[2 * i]; acc[3] += k1n[2 * i + 1]; acc[4] += cf[i];
+    }
+    for (int j = 0; j < 5; ++j) {
+        double v = wave_sum_d(acc[j]);
+        if (lane == 0) sred[wave * 48 + j] = v;
+    }
+    __syncthreads();
+    if (tid < 5) sstat[tid] = sred[tid] + sred[48 + tid] + sred[96 + tid] + sred[144 + tid];
+    __syncthreads();
+    const double mx0 = sstat[0] / N, my0 = sstat[1] / N, mx1 = sstat[2] / N, my1 = sstat[3] / N;
+    const float wsum = (float)sstat[4] + 1e-6f;
+    double d0 = 0, d1 = 0;
+    for (int i = tid; i < N; i += 256) {
+        const double ax = (double)k0n[2 * i] - mx0, ay = (double)k0n[2 * i + 1] - my0;
+        const double bx = (double)k1n[2 * i] - mx1, by = (double)k1n[2 * i + 1] - my1;
+        d0 += sqrt(ax * ax + ay * ay);
+        d1 += sqrt(bx * bx + by * by);
+    }
+    d0 = wave_sum_d(d0);
+    d1 = wave_sum_d(d1);
+    __syncthreads();
+    if (lane == 0) { sred[wave * 48] = d0; sred[wave * 48 + 1] = d1; }
+    __syncthreads();
+    if (tid < 2) sstat[8 + tid] = sred[tid] + sred[48 + tid] + sred[96 + tid] + sred[144 + tid];
+    __syncthreads();
+    const double s0 = sqrt(2.0) / (sstat[8] / N + 1e-8), s1 = sqrt(2.0) / (sstat[9] / N + 1e-8);
+    auto design = [&](int i, double* r) {  // the UNWEIGHTED design row of correspondence i (:65)
+        const double x1 = s0 * ((double)k0n[2 * i] - mx0), y1 = s0 * ((double)k0n[2 * i + 1] - my0);
+        const double x2 = s1 * ((double)k1n[2 * i] - mx1), y2 = s1 * ((double)k1n[2 * i + 1] - my1);
+        r[0] = x2 * x1; r[1] = x2 * y1; r[2] = x2; r[3] = y2 * x1; r[4] = y2 * y1; r[5] = y2; r[6] = x1; r[7] = y1; r[8] = 1.0;
+    };
+    double g[45];
+#pragma unroll
+    for (int j = 0; j < 45; ++j) g[j] = 0.0;
+    for (int i = tid; i < N; i += 256) {
+        const double w = (double)(cf[i] / wsum);
+        double r[9];
+        design(i, r);
+        int j = 0;
+#pragma unroll
+        for (int a = 0; a < 9; ++a)
+#pragma unroll
+            for (int c = a; c < 9; ++c) g[j++] += (w * r[a]) * (w * r[c]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 45; ++j) {
+        double v = wave_sum_d(g[j]);
+        if (lane == 0) sred[wave * 48 + j] = v;
+    }
+    __syncthreads();
+    if (tid < 45) {
+        const double v = sred[tid] + sred[48 + tid] + sred[96 + tid] + sred[144 + tid];
+        int j = 0, a = 0, c = 0;
+        for (a = 0; a < 9; ++a) {
+            if (tid < j + 9 - a) { c = a + (tid - j); break; }
+            j += 9 - a;
+        }
+        sG[a * 9 + c] = v;
+        sG[c * 9 + a] = v;
+    }
+    __syncthreads();
+    double* const V = jacobi9_parallel(sG, sB, sV1, sV2, srot, spart, tid);
+    __syncthreads();
+    if (tid == 0) {
+        int mi = 0;
+        const int skip = N >= 9 ? 0 : 9 - N;
+        bool used[9];
+        for (int i = 0; i < 9; ++i) used[i] = false;
+        for (int k = 0; k <= skip; ++k) {
+            mi = -1;
+            for (int i = 0; i < 9; ++i)
+                if (!used[i] && (mi < 0 || sG[i * 9 + i] < sG[mi * 9 + mi])) mi = i;
+            used[mi] = true;
+        }
+        spart[10] = mi;
+        for (int i = 0; i < 9; ++i) sf[i] = V[i * 9 + mi];
+    }
+    __syncthreads();
+    const int mi = spart[10];
+    const float* To = p.T + (int64_t)b * 16;
+    const float* gT = p.gT + (int64_t)b * 16;
+    const double h = 1e-6;
+    if (tid < 18) {
+        double Fm[9], E[9], R1[9], R2[9], tv[3];
+        for (int i = 0; i < 9; ++i) Fm[i] = sf[i];
+        Fm[tid >> 1] += (tid & 1) ? -h : h;
+        (void)w8pt_tail(Fm, s0, mx0, my0, s1, mx1, my1, E, R1, R2, tv);
+        int best = 0;
+        double bd = 1e300;
+        for (int c = 0; c < 4; ++c) {
+            const double* R = c < 2 ? R1 : R2;
+            const double sg = (c & 1) ? -1.0 : 1.0;
+            double d = 0.0;
+            for (int r = 0; r < 3; ++r) {
+                for (int q = 0; q < 3; ++q) { const double e = R[r * 3 + q] - (double)To[r * 4 + q]; d += e * e; }
+                const double e = sg * tv[r] - (double)To[r * 4 + 3];
+                d += e * e;
+            }
+            if (d < bd) { bd = d; best = c; }
+        }
+        const double* R = best < 2 ? R1 : R2;
+        const double sg = (best & 1) ? -1.0 : 1.0;
+        for (int i = 0; i < 9; ++i) sT[tid * 12 + i] = R[i];
+        for (int i = 0; i < 3; ++i) sT[tid * 12 + 9 + i] = sg * tv[i];
+    }
+    __syncthreads();
+    if (tid < 9) {
+        const double* Tp = sT + (2 * tid) * 12;
+        const double* Tm = sT + (2 * tid + 1) * 12;
+        double gsum = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            for (int q = 0; q < 3; ++q) gsum += (double)gT[r * 4 + q] * (Tp[r * 3 + q] - Tm[r * 3 + q]);
+            gsum += (double)gT[r * 4 + 3] * (Tp[9 + r] - Tm[9 + r]);
+        }
+        sgf[tid] = gsum / (2.0 * h);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // the forward returned the identity (no candidate accepted / degenerate input): the pose does not depend on c
+        const double tn = (double)To[3] * To[3] + (double)To[7] * To[7] + (double)To[11] * To[11];
+        double dot = 0.0;
+        for (int i = 0; i < 9; ++i) dot += sgf[i] * sf[i];
+        for (int i = 0; i < 9; ++i) sgf[i] -= dot * sf[i];
+        const double lam = sG[mi * 9 + mi];
+        for (int i = 0; i < 9; ++i) sy[i] = 0.0;
+        if (tn > 0.25)
+            for (int k = 0; k < 9; ++k) {
+                if (k == mi) continue;
+                const double den = sG[k * 9 + k] - lam;
+                if (!(fabs(den) > 1e-300)) continue;
+                double pr = 0.0;
+                for (int i = 0; i < 9; ++i) pr += V[i * 9 + k] * sgf[i];
+                for (int i = 0; i < 9; ++i) sy[i] += V[i * 9 + k] * pr / den;
+            }
+    }
+    __syncthreads();
+    double S1 = 0.0;
+    for (int i = tid; i < N; i += 256) {
+        const double w = (double)(cf[i] / wsum);
+        double r[9];
+        design(i, r);
+        double yx = 0.0, fx = 0.0;
+#pragma unroll
+        for (int a = 0; a < 9; ++a) { yx += sy[a] * r[a]; fx += sf[a] * r[a]; }
+        const double dw = -2.0 * w * yx * fx;
+        gc[i] = (float)dw;
+        S1 += dw * (double)cf[i];
+    }
+    S1 = wave_sum_d(S1);
+    __syncthreads();
+    if (lane == 0) sred[wave] = S1;
+    __syncthreads();
+    const double Sall = sred[0] + sred[1] + sred[2] + sred[3];
+    const double ws = (double)wsum;
+    for (int i = tid; i < N; i += 256) gc[i] = (float)((double)gc[i] / ws - Sall / (ws * ws));
 }
 
 // DLT triangulation of one correspondence with P1 = [I|0], P2 = [R|t]; returns the two depths.
@@ -540,6 +745,36 @@ __global__ void pose_errors_kernel(int B, const float* T, const float* Tg, float
         e = fabsf(acosf(fminf(fmaxf(cd, -1.f), 1.f)));
     }
     tr[b] = e;
+}
+
+
+// backward of pose_errors_kernel with respect to the FIRST pose: gT = g_rot d rot/dT + g_tr d tr/dT (zero where an angle is
+// clamped or the translation norms fail the 1e-6 test - exactly the entries the forward leaves out of its means)
+__global__ void pose_errors_backward_kernel(int B, const float* T, const float* Tg, const float* g_rot, const float* g_tr, float* gT) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* A = T + (int64_t)b * 16;
+    const float* G = Tg + (int64_t)b * 16;
+    float* o = gT + (int64_t)b * 16;
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+    double trc = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) trc += (double)A[i * 4 + j] * G[i * 4 + j];
+    const double ca = (trc - 1.0) * 0.5;
+    if (ca > -1.0 && ca < 1.0) {
+        const double f = -(double)g_rot[b] * 0.5 / sqrt(1.0 - ca * ca);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) o[i * 4 + j] = (float)(f * G[i * 4 + j]);
+    }
+    const double t0[3] = {A[3], A[7], A[11]}, t1[3] = {G[3], G[7], G[11]};
+    const double n0 = sqrt(t0[0] * t0[0] + t0[1] * t0[1] + t0[2] * t0[2]), n1 = sqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+    if ((float)n0 * (float)n1 > 1e-6f) {
+        const double cd = (t0[0] * t1[0] + t0[1] * t1[1] + t0[2] * t1[2]) / (n0 * n1);
+        if (cd > -1.0 && cd < 1.0) {
+            const double f = -(double)g_tr[b] / sqrt(1.0 - cd * cd);
+            for (int i = 0; i < 3; ++i) o[i * 4 + 3] = (float)(f * (t1[i] / (n0 * n1) - cd * t0[i] / (n0 * n0)));
+        }
+    }
 }
 
 
@@ -734,6 +969,19 @@ extern "C" int e2emv_w8pt(e2emv_ctx* ctx, int B, int N, const float* d_kpts0, co
                     determine_inliers, d_T, d_kpts0n, d_kpts1n, d_conf_n, d_inliers, d_posdepth, d_F, d_status, s);
 }
 
+extern "C" int e2emv_w8pt_backward(e2emv_ctx* ctx, int B, int N, const float* d_kpts0n, const float* d_kpts1n, const float* d_conf, const float* d_T,
+                                   const float* d_gT, float* d_gconf, void* stream) {
+    if (!ctx || !d_kpts0n || !d_kpts1n || !d_conf || !d_T || !d_gT || !d_gconf) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    if (B <= 0 || N < 8) return set_err(ctx, E2EMV_ESHAPE, "w8pt_backward: B=%d N=%d", B, N);
+    (void)hipSetDevice(ctx->device);
+    W8BwdParams p{};
+    p.B = B; p.N = N; p.k0n = d_kpts0n; p.k1n = d_kpts1n; p.conf = d_conf; p.T = d_T; p.gT = d_gT; p.gconf = d_gconf;
+    hipLaunchKernelGGL(w8pt_backward_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
+    E2EMV_CHECK_LAUNCH(ctx, "w8pt_backward_kernel");
+    return E2EMV_OK;
+}
+
 extern "C" int e2emv_w8pt_ragged(e2emv_ctx* ctx, int B, int N, const int32_t* d_n_per, const float* d_kpts0, const float* d_kpts1,
                                  const float* d_intr0, const float* d_intr1, int kdim, int intr_batch, const float* d_conf,
                                  int choose_closest, const float* d_T_gt, int determine_inliers, float* d_T, float* d_kpts0n,
@@ -853,6 +1101,16 @@ extern "C" int e2emv_pose_error_means(e2emv_ctx* ctx, int B, const float* d_T, c
         hipLaunchKernelGGL(pose_error_means_kernel, dim3(1), dim3(64), 0, s, B, d_rot_err, d_transl_err, d_transl_valid, d_means2);
     prof_end(ctx, s);
     E2EMV_CHECK_LAUNCH(ctx, "pose error kernels");
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_pose_errors_backward(e2emv_ctx* ctx, int B, const float* d_T, const float* d_T_gt, const float* d_g_rot, const float* d_g_transl,
+                                          float* d_gT, void* stream) {
+    if (!ctx || !d_T || !d_T_gt || !d_g_rot || !d_g_transl || !d_gT) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    if (B <= 0) return set_err(ctx, E2EMV_ESHAPE, "pose_errors_backward: empty batch");
+    hipLaunchKernelGGL(pose_errors_backward_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, d_T, d_T_gt, d_g_rot, d_g_transl, d_gT);
+    E2EMV_CHECK_LAUNCH(ctx, "pose_errors_backward_kernel");
     return E2EMV_OK;
 }
 

@@ -4,7 +4,8 @@
 Same names, argument order, keyword names, ``info`` keys and ``None`` conventions as the
 reference (``estimate_relative_pose.py:9-14, 16-31, 84-136``; ``compute_pose_error.py:3-22``);
 the arithmetic runs in the HIP kernels of ``csrc/pose.hip`` (fp64 Gram / Jacobi instead of
-the reference's library SVDs).  Inference only (no autograd).  No CPU fallback.
+the reference's library SVDs).  The pose is differentiable with respect to the confidences (training, the pose loss:
+``_W8ptPose`` / ``e2emv_w8pt_backward``); keypoints and the candidate choice carry no gradient.  No CPU fallback.
 """
 import ctypes
 
@@ -63,6 +64,9 @@ def get_kpts(data, result, id0, id1):
     ctx = _lib.context(dev)
     k0d, k1d = _prep(k0, dev), _prep(k1, dev)
     m = matches.to(dev, torch.int64).contiguous()
+    if torch.is_grad_enabled() and conf.requires_grad:
+        cout, k1g = _MaskedConfidence.apply(conf, ctx, dev, k1d, m)
+        return k0d, k1g, data["intr" + str(id0)], data["intr" + str(id1)], cout.unsqueeze(-1)
     c = _prep(conf.reshape(conf.shape[0], -1), dev)
     B, N0 = m.shape
     k1g = torch.empty((B, N0, 2), dtype=torch.float32, device=dev)
@@ -100,6 +104,16 @@ def estimate_relative_pose_w8pt(kpts0, kpts1, intr0, intr1, confidence, choose_c
     Tg = _prep(T_021, dev) if (choose_closest and T_021 is not None) else None
     if choose_closest and Tg is None:
         raise ValueError("choose_closest=True needs T_021")
+    args = (ctx, dev, B, N, k0, k1, K0, K1, kdim, Tg, bool(choose_closest), bool(determine_inliers), conf_shape)
+    if torch.is_grad_enabled() and confidence.requires_grad:
+        # training (pose loss, helpers.py:253-258): T carries the graph back to the confidences (csrc/pose.hip, w8pt_backward)
+        holder = []
+        T = _W8ptPose.apply(conf2.to(dev, torch.float32), args, holder)
+        return T, holder[0]
+    return _w8pt_call(cf, *args)
+
+
+def _w8pt_call(cf, ctx, dev, B, N, k0, k1, K0, K1, kdim, Tg, choose_closest, determine_inliers, conf_shape):
     T = torch.empty((B, 4, 4), dtype=torch.float32, device=dev)
     k0n, k1n = torch.empty_like(k0), torch.empty_like(k1)
     cfn = torch.empty((B, N), dtype=torch.float32, device=dev)
@@ -116,6 +130,55 @@ def estimate_relative_pose_w8pt(kpts0, kpts1, intr0, intr1, confidence, choose_c
             "inliers": inl.bool() if inl is not None else None, "pos_depth_mask": pos.bool(),
             "F": F, "status": status}
     return T, info
+
+
+class _W8ptPose(torch.autograd.Function):
+    """T = w8pt(confidence): ``e2emv_w8pt`` forward, ``e2emv_w8pt_backward`` for dLoss/dconfidence (the keypoints and the
+    candidate choice carry no gradient).  ``holder`` receives the ``info`` dict of the forward."""
+
+    @staticmethod
+    def forward(fctx, conf, args, holder):
+        cf = conf.contiguous()
+        T, info = _w8pt_call(cf, *args)
+        holder.append(info)
+        fctx.args = args
+        fctx.save_for_backward(cf, T, info["kpts0_norm"], info["kpts1_norm"])
+        return T
+
+    @staticmethod
+    def backward(fctx, gT):
+        cf, T, k0n, k1n = fctx.saved_tensors
+        ctx, dev, B, N = fctx.args[:4]
+        g = gT.to(torch.float32).contiguous()
+        gconf = torch.empty((B, N), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ctx.call("e2emv_w8pt_backward", B, N, _lib.ptr(k0n), _lib.ptr(k1n), _lib.ptr(cf), _lib.ptr(T), _lib.ptr(g), _lib.ptr(gconf),
+                     _lib.stream_ptr(dev))
+        return gconf, None, None
+
+
+class _MaskedConfidence(torch.autograd.Function):
+    """``confidence = (matches >= 0) * conf_scores`` of ``get_kpts`` (:27-29) with the gather of image 1's keypoints:
+    forward ``e2emv_gather_matched``, backward ``e2emv_apply_mask``."""
+
+    @staticmethod
+    def forward(fctx, conf, ctx, dev, k1d, m):
+        B, N0 = m.shape
+        c = conf.reshape(B, -1).to(dev, torch.float32).contiguous()
+        k1g = torch.empty((B, N0, 2), dtype=torch.float32, device=dev)
+        cout = torch.empty((B, N0), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ctx.call("e2emv_gather_matched", B, N0, k1d.shape[1], _lib.ptr(k1d), _lib.ptr(m), _lib.ptr(c), _lib.ptr(k1g),
+                     _lib.ptr(cout), _lib.stream_ptr(dev))
+        fctx.misc = (ctx, dev, m, conf.shape)
+        fctx.mark_non_differentiable(k1g)
+        return cout, k1g
+
+    @staticmethod
+    def backward(fctx, gcout, _gk):
+        ctx, dev, m, shape = fctx.misc
+        g = gcout.to(torch.float32).contiguous()
+        return mask_confidence(g, m >= 0).reshape(shape), None, None, None, None
 
 
 def run_weighted_8_point(data, result, id0, id1, choose_closest=False, target_T_021=None):
@@ -215,8 +278,40 @@ def pose_errors(T0, T1):
     return rot, tr
 
 
+class _PoseErrors(torch.autograd.Function):
+    """(rot [B], transl [B], valid [B]) = pose errors of T0 against T1 with the gradient w.r.t. T0 (``e2emv_pose_errors_backward``):
+    the two error functions as the pose LOSS of ``helpers.run_matcher`` (helpers.py:256-258)."""
+
+    @staticmethod
+    def forward(fctx, T0, T1):
+        rot, tr, valid, _ = _pose_error_buffers(T0, T1, means=False)
+        fctx.save_for_backward(_prep(T0, rot.device), _prep(T1, rot.device))
+        fctx.mark_non_differentiable(valid)
+        return rot, tr, valid
+
+    @staticmethod
+    def backward(fctx, g_rot, g_tr, _gv):
+        a, b = fctx.saved_tensors
+        dev, B = a.device, a.shape[0]
+        ctx = _lib.context(dev)
+        gr = (torch.zeros(B, device=dev) if g_rot is None else g_rot).to(torch.float32).contiguous()
+        gt = (torch.zeros(B, device=dev) if g_tr is None else g_tr).to(torch.float32).contiguous()
+        gT = torch.empty((B, 4, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ctx.call("e2emv_pose_errors_backward", B, _lib.ptr(a), _lib.ptr(b), _lib.ptr(gr), _lib.ptr(gt), _lib.ptr(gT), _lib.stream_ptr(dev))
+        return gT, None
+
+
+def _wants_grad(T0):
+    return torch.is_grad_enabled() and torch.is_tensor(T0) and T0.requires_grad
+
+
 def compute_rotation_error(T0, T1, reduce=True):
-    """``compute_rotation_error`` (compute_pose_error.py:3-12); the mean is reduced on the device."""
+    """``compute_rotation_error`` (compute_pose_error.py:3-12); the mean is reduced on the device.  Differentiable with respect to
+    ``T0`` when it carries a graph (the rotation loss of ``helpers.run_matcher``)."""
+    if _wants_grad(T0):
+        rot, _, _ = _PoseErrors.apply(T0, T1)
+        return rot.mean() if reduce else rot
     rot, _, _, m2 = _pose_error_buffers(T0, T1, means=reduce)
     return m2[0] if reduce else rot
 
@@ -224,7 +319,11 @@ def compute_rotation_error(T0, T1, reduce=True):
 def compute_translation_error_as_angle(T0, T1, reduce=True):
     """``compute_translation_error_as_angle`` (compute_pose_error.py:14-22): only the entries whose norm product
     exceeds 1e-6 count - ``reduce=True`` averages over them on the device, ``reduce=False`` returns exactly those
-    entries (shape [n_valid], like the reference's boolean indexing)."""
+    entries (shape [n_valid], like the reference's boolean indexing).  Differentiable with respect to ``T0`` like the above."""
+    if _wants_grad(T0):
+        _, tr, valid = _PoseErrors.apply(T0, T1)
+        sel = tr[valid.bool()]
+        return sel.mean() if reduce else sel
     _, tr, valid, m2 = _pose_error_buffers(T0, T1, means=reduce)
     return m2[1] if reduce else tr[valid.bool()]
 

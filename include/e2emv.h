@@ -386,6 +386,20 @@ int e2emv_matcher_forward_train(e2emv_ctx* ctx, const e2emv_forward_desc* fd, co
 int e2emv_matcher_backward(e2emv_ctx* ctx, const float* const* d_dlogZ, void* stream);
 int e2emv_get_grad(e2emv_ctx* ctx, const char* key, float* d_dst, int64_t numel, void* stream);
 
+/* Backward of e2emv_w8pt with respect to the confidences (training, the pose loss of helpers.py:253-258: rot / translation
+ * error of run_weighted_8_point's pose).  Inputs: the normalised correspondences and the pose the forward returned (info
+ * "kpts0_norm" / "kpts1_norm", T), the confidences it was given, d_gT = dLoss/dT [B][4][4]; output d_gconf [B][N].  The
+ * derivative of the eigenvector is analytic, the 9 -> 12 Jacobian of the rank-2 / decomposition tail is taken by central
+ * differences in fp64.  The candidate choice (choose_closest / cheirality) is piecewise constant: the candidate the forward
+ * chose is differentiated. */
+int e2emv_w8pt_backward(e2emv_ctx* ctx, int B, int N, const float* d_kpts0n, const float* d_kpts1n, const float* d_conf, const float* d_T,
+                        const float* d_gT, float* d_gconf, void* stream);
+
+/* Backward of e2emv_pose_errors with respect to d_T (compute_rotation_error / compute_translation_error_as_angle as the pose
+ * loss, helpers.py:256-258): d_gT [B][4][4] = d_g_rot[b] d rot_b / dT + d_g_transl[b] d transl_b / dT. */
+int e2emv_pose_errors_backward(e2emv_ctx* ctx, int B, const float* d_T, const float* d_T_gt, const float* d_g_rot, const float* d_g_transl,
+                               float* d_gT, void* stream);
+
 /* ---- timing hooks used by bench.py (HIP events on the caller's stream) -------------
  * After e2emv_profile(ctx, 1) every kernel family launched by the library is bracketed by
  * HIP events on its stream; e2emv_profile_read returns accumulated milliseconds and launch

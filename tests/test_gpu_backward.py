@@ -181,3 +181,92 @@ def test_eval_mode_and_no_grad_stay_on_the_inference_path(gpu):
     assert model.train()(data)["scores_0_1"].requires_grad
     model.config["autograd"] = False
     assert not model(data)["scores_0_1"].requires_grad
+
+
+# ------------------------------------------------------------------------------------------------- pose loss, second slice
+def _two_view_scene(B, N, seed, noise_px=0.5):
+    g = torch.Generator().manual_seed(seed)
+    K = torch.tensor([[600.0, 0, 320, 0], [0, 600.0, 240, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    k0, k1, Ts = [], [], []
+    for _ in range(B):
+        axis = torch.randn(3, generator=g)
+        axis = axis / axis.norm()
+        ang = 0.1 + 0.2 * float(torch.rand(1, generator=g))
+        Kx = torch.tensor([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = torch.eye(3) + torch.sin(torch.tensor(ang)) * Kx + (1 - torch.cos(torch.tensor(ang))) * (Kx @ Kx)
+        t = torch.randn(3, generator=g) * 0.5
+        X = torch.stack([torch.rand(N, generator=g) * 4 - 2, torch.rand(N, generator=g) * 3 - 1.5, torch.rand(N, generator=g) * 4 + 3], 1)
+        X1 = X @ R.T + t
+        p0 = X / X[:, 2:] @ K[:3, :3].T
+        p1 = X1 / X1[:, 2:] @ K[:3, :3].T
+        k0.append(p0[:, :2] + noise_px * torch.randn(N, 2, generator=g))
+        k1.append(p1[:, :2] + noise_px * torch.randn(N, 2, generator=g))
+        T = torch.eye(4)
+        T[:3, :3], T[:3, 3] = R, t
+        Ts.append(T)
+    conf = torch.rand(B, N, 1, generator=g) * 0.8 + 0.2
+    conf[:, ::7] = 0.0  # unmatched keypoints carry weight 0
+    return torch.stack(k0), torch.stack(k1), K.unsqueeze(0).repeat(B, 1, 1), torch.stack(Ts), conf, g
+
+
+@pytest.mark.parametrize("choose_closest", [True, False])
+def test_w8pt_pose_gradient_wrt_confidence(gpu, choose_closest):
+    """dLoss/dconfidence through the weighted 8-point solve (e2emv_w8pt_backward: analytic eigenvector derivative + central
+    differences of the rank-2 / decomposition tail) against torch.autograd through the fp64 oracle (library SVD backward).
+    Loss = a random linear + quadratic functional of the 3 x 4 pose (exercises the whole Jacobian with a pose-dependent dL/dT).
+    The reference's own angle losses (compute_pose_error.py:3-22) are NOT the comparison: d arccos = -1 / sqrt(1 - cos^2) with
+    1 - cos ~ 1e-6 at these pose errors resolves to a few per cent on an fp32 pose - the conditioning of that loss, on either
+    side (measured: every entry of dT/dconfidence matches the oracle to 5e-8); they are checked for finite gradients below."""
+    import e2e_multi_view_matching_amd as E
+    from oracle import w8pt as OW
+    B, N = 3, 300
+    k0, k1, Kc, Tgt, conf, g = _two_view_scene(B, N, seed=11 + int(choose_closest))
+    # both sides get the SAME fp32 numbers: camera coordinates made once in fp32, identity intrinsics from there on (the gradient
+    # divides by the gap between the two smallest eigenvalues: an input rounded differently on the two sides shows up 1e3 x)
+    k0 = (k0 - Kc[:, None, :2, 2]) / torch.stack([Kc[:, 0, 0], Kc[:, 1, 1]], -1)[:, None]
+    k1 = (k1 - Kc[:, None, :2, 2]) / torch.stack([Kc[:, 0, 0], Kc[:, 1, 1]], -1)[:, None]
+    Kc = torch.eye(4).unsqueeze(0).repeat(B, 1, 1)
+    Wr = torch.randn(B, 3, 4, generator=g)
+    c_ref = conf.double().clone().requires_grad_(True)
+    T_ref, _ = OW.estimate_relative_pose_w8pt(k0.double(), k1.double(), Kc.double(), Kc.double(), c_ref, choose_closest=choose_closest,
+                                              T_021=Tgt.double())
+    loss_ref = (T_ref[:, :3, :] * Wr.double()).sum() + ((T_ref[:, :3, :] - 0.3) ** 2 * Wr.double().flip(1)).sum()
+    loss_ref.backward()
+    c = conf.to(gpu).clone().requires_grad_(True)
+    T, info = E.estimate_relative_pose_w8pt(k0.to(gpu), k1.to(gpu), Kc.to(gpu), Kc.to(gpu), c, choose_closest=choose_closest,
+                                            T_021=Tgt.to(gpu))
+    assert T.requires_grad and float((T.detach().cpu().double() - T_ref.detach()).abs().max()) < 1e-4
+    Td = T.double()
+    loss = (Td[:, :3, :] * Wr.to(gpu).double()).sum() + ((Td[:, :3, :] - 0.3) ** 2 * Wr.to(gpu).double().flip(1)).sum()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    loss.backward()
+    gp, gr = c.grad.cpu().double(), c_ref.grad
+    assert bool(gp.isfinite().all())
+    for b in range(B):  # (a correspondence of weight 0 still has a gradient: dL/dc_m carries the normalisation term)
+        rel = float((gp[b] - gr[b]).norm() / gr[b].norm())
+        assert rel < REL, (b, rel)
+    # the reference's pose losses on the same graph: finite gradients (has_finite_gradients, helpers.py:284-288)
+    c2 = conf.to(gpu).clone().requires_grad_(True)
+    T2, _ = E.estimate_relative_pose_w8pt(k0.to(gpu), k1.to(gpu), Kc.to(gpu), Kc.to(gpu), c2, choose_closest=choose_closest, T_021=Tgt.to(gpu))
+    (E.compute_rotation_error(T2, Tgt.to(gpu)) + E.compute_translation_error_as_angle(T2, Tgt.to(gpu))).backward()
+    assert c2.grad is not None and bool(c2.grad.isfinite().all()) and float(c2.grad.abs().max()) > 0
+
+
+def test_pose_error_gradients(gpu):
+    """compute_rotation_error / compute_translation_error_as_angle as losses: gradients w.r.t. the predicted pose against
+    autograd through the oracle's restatement of compute_pose_error.py:3-22 (moderate angles: the arccos is well conditioned)."""
+    import e2e_multi_view_matching_amd as E
+    from oracle import w8pt as OW
+    _, _, _, Ta, _, _ = _two_view_scene(6, 8, seed=5)
+    _, _, _, Tb, _, _ = _two_view_scene(6, 8, seed=6)
+    Tb[2, :3, 3] = 0.0  # an entry the translation error leaves out (norm product <= 1e-6)
+    for reduce in (True, False):
+        a_ref = Ta.double().clone().requires_grad_(True)
+        lr = OW.compute_rotation_error(a_ref, Tb.double(), reduce=reduce).sum() * 1.5 + \
+            OW.compute_translation_error_as_angle(a_ref, Tb.double(), reduce=reduce).sum() * 0.7
+        lr.backward()
+        a = Ta.to(gpu).clone().requires_grad_(True)
+        lp = E.compute_rotation_error(a, Tb.to(gpu), reduce=reduce).sum() * 1.5 + E.compute_translation_error_as_angle(a, Tb.to(gpu), reduce=reduce).sum() * 0.7
+        lp.backward()
+        assert abs(lp.item() - lr.item()) < 1e-5
+        assert float((a.grad.cpu().double() - a_ref.grad).abs().max()) < 1e-5 * float(a_ref.grad.abs().max())
