@@ -111,7 +111,8 @@ SIGNATURES = {
     "e2emv_attention_p2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "e2emv_train_commit": (c_int, [c_void_p, ctypes.POINTER(ModelDesc)]),
     "e2emv_matcher_forward_train": (c_int, [c_void_p, ctypes.POINTER(ForwardDesc), _PP, _PP, _PP, _PP, c_void_p]),
-    "e2emv_matcher_backward": (c_int, [c_void_p, _PP, c_void_p]),
+    "e2emv_conf_forward_train": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "e2emv_matcher_backward": (c_int, [c_void_p, _PP, _PP, c_void_p]),
     "e2emv_get_grad": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, c_void_p]),
     "e2emv_w8pt_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_pose_errors_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -44,6 +44,8 @@ struct TrainState {
     std::vector<int> kdims;      // [3, c0, ..., D]
     std::vector<TrainLayer> layers;
     size_t wf = 0, bf = 0, alpha = 0;
+    size_t wc0 = 0, bc0 = 0, wc1 = 0, bc1 = 0;  // conf_mlp.0 (+ BN conf_mlp.1) [D][2D], conf_mlp.3 [1][D]
+    bool conf_mlp = false;
     float bin_score = 1.f;
     // upstream parameters (for the unfolding) and their gradients (same offsets)
     float* d_raw = nullptr;
@@ -64,6 +66,8 @@ struct TrainState {
     float* t_mdesc = nullptr;
     float* t_S = nullptr;                 // [P*B][N][ldS]
     float* t_uv = nullptr;                // [P*B][iters + 1][2][N + 1]: u_t, v_t (t = 0: zeros)
+    std::vector<float*> t_cfeat, t_chid;  // conf head, per pair: [B][N][2D] input, [B][N][D] hidden (post ReLU)
+    std::vector<const int64_t*> t_cmatch; // matches the conf head of a pair was run with (caller's buffer, must stay alive until backward)
 };
 
 static TrainState* ts_of(e2emv_ctx* ctx) { return static_cast<TrainState*>(ctx->train); }
@@ -232,6 +236,15 @@ extern "C" int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     if ((rc = conv_bn(ctx, t, raw, "final_proj", "", D, D, w, b))) return rc;
     t->wf = pk.add(w);
     t->bf = pk.add(b);
+    t->conf_mlp = m->conf_mlp != 0;
+    if (t->conf_mlp) {
+        if ((rc = conv_bn(ctx, t, raw, "conf_mlp.0", "conf_mlp.1", D, 2 * D, w, b))) return rc;
+        t->wc0 = pk.add(w);
+        t->bc0 = pk.add(b);
+        if ((rc = conv_bn(ctx, t, raw, "conf_mlp.3", "", 1, D, w, b))) return rc;
+        t->wc1 = pk.add(w);
+        t->bc1 = pk.add(b);
+    }
     const HostTensor* bs = findt(ctx, "bin_score");
     if (!bs || bs->data.size() != 1) return set_err(ctx, E2EMV_ESTATE, "train_commit: missing scalar 'bin_score'");
     t->bin_score = bs->data[0];
@@ -279,6 +292,7 @@ extern "C" int e2emv_matcher_forward_train(e2emv_ctx* ctx, const e2emv_forward_d
     for (int i = 1; i < nk; ++i) need += al256((size_t)Mtot * t->kdims[i] * 4);
     need += (size_t)(L + 1) * al256((size_t)Mtot * D * 4) + (size_t)L * (al256((size_t)Mtot * 3 * D * 4) + 2 * al256((size_t)Mtot * D * 4) + al256((size_t)Mtot * 2 * D * 4));
     need += al256((size_t)Mtot * D * 4) + al256((size_t)P * B * N * ldS * 4) + al256((size_t)P * B * (iters + 1) * 2 * (N + 1) * 4);
+    if (t->conf_mlp) need += (size_t)P * (al256((size_t)B * N * 2 * D * 4) + al256((size_t)B * N * D * 4));
     if (need > t->tape_bytes) {
         E2EMV_HIP(ctx, hipDeviceSynchronize());
         if (t->d_tape) E2EMV_HIP(ctx, hipFree(t->d_tape));
@@ -308,6 +322,12 @@ extern "C" int e2emv_matcher_forward_train(e2emv_ctx* ctx, const e2emv_forward_d
     t->t_mdesc = take((size_t)Mtot * D * 4);
     t->t_S = take((size_t)P * B * N * ldS * 4);
     t->t_uv = take((size_t)P * B * (iters + 1) * 2 * (N + 1) * 4);
+    t->t_cfeat.assign(P, nullptr); t->t_chid.assign(P, nullptr); t->t_cmatch.assign(P, nullptr);
+    if (t->conf_mlp)
+        for (int q = 0; q < P; ++q) {
+            t->t_cfeat[q] = take((size_t)B * N * 2 * D * 4);
+            t->t_chid[q] = take((size_t)B * N * D * 4);
+        }
     t->B = B; t->T = T; t->N = N; t->n_rows = n_rows; t->iters = iters; t->P = P; t->ldS = ldS; t->Mtot = Mtot;
     t->have_tape = false;
 
@@ -398,6 +418,39 @@ extern "C" int e2emv_matcher_forward_train(e2emv_ctx* ctx, const e2emv_forward_d
     return E2EMV_OK;
 }
 
+// confidence head of pair `pair` (order (0,1), (0,2), (1,2), ...) on the mdesc of the tape: conf[b][n] = sigmoid(conf_mlp([mdesc_i[n] |
+// mdesc_j[match n]])) for matched n, 0 otherwise.  d_matches0 must stay alive until e2emv_matcher_backward (it is read again).
+extern "C" int e2emv_conf_forward_train(e2emv_ctx* ctx, int pair, const int64_t* d_matches0, float* d_conf, void* stream) {
+    if (!ctx || !d_matches0 || !d_conf) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    TrainState* t = ts_of(ctx);
+    if (!t || !t->have_tape) return set_err(ctx, E2EMV_ESTATE, "conf_forward_train: no tape - e2emv_matcher_forward_train first");
+    if (!t->conf_mlp) return set_err(ctx, E2EMV_ESTATE, "conf_forward_train: the committed model has no conf_mlp");
+    if (pair < 0 || pair >= t->P) return set_err(ctx, E2EMV_EINVAL, "conf_forward_train: pair %d of %d", pair, t->P);
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int B = t->B, T = t->T, N = t->N, n_rows = t->n_rows, D = t->model.desc_dim;
+    int pi = 0, pj = 1, q = 0;
+    for (int j = 0; j < T; ++j)
+        for (int i = 0; i < j; ++i, ++q)
+            if (q == pair) { pi = i; pj = j; }
+    const int64_t tuple_stride = (int64_t)T * n_rows * D;
+    float* feat = t->t_cfeat[pair];
+    float* hid = t->t_chid[pair];
+    hipLaunchKernelGGL(conf_feat_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, N, D, (const float*)t->t_mdesc + (int64_t)pi * n_rows * D,
+                       (const float*)t->t_mdesc + (int64_t)pj * n_rows * D, tuple_stride, d_matches0, feat);
+    E2EMV_CHECK_LAUNCH(ctx, "conf_feat_kernel");
+    GemmArgs g;
+    g.M = B * N; g.N = D; g.K = 2 * D; g.K1 = 2 * D; g.A = feat; g.lda = 2 * D; g.W = t->d_w + t->wc0; g.ldw = 2 * D; g.bias = t->d_w + t->bc0;
+    g.relu = true; g.C = hid; g.ldc = D;
+    if (int rc = launch_gemm_nt(ctx, g, s)) return rc;
+    hipLaunchKernelGGL(conf_fwd_kernel, dim3((unsigned)(((int64_t)B * N + 3) / 4)), dim3(256), 0, s, (int64_t)B * N, D, (const float*)hid,
+                       (const float*)t->d_w + t->wc1, (const float*)t->d_w + t->bc1, d_matches0, d_conf);
+    E2EMV_CHECK_LAUNCH(ctx, "conf_fwd_kernel");
+    t->t_cmatch[pair] = d_matches0;
+    return E2EMV_OK;
+}
+
 // attention backward of one layer: d att [Mtot][D] -> dqkv [Mtot][3D] (zeroed here); P / dP: scratch [B*H][N][ldP] each
 static int attention_backward(e2emv_ctx* ctx, TrainState* t, int l, const float* datt, float* dqkv, float* Pb, float* dPb, hipStream_t s) {
     const int B = t->B, T = t->T, N = t->N, n_rows = t->n_rows, D = t->model.desc_dim, H = t->model.num_heads;
@@ -450,7 +503,7 @@ static int attention_backward(e2emv_ctx* ctx, TrainState* t, int l, const float*
     return E2EMV_OK;
 }
 
-extern "C" int e2emv_matcher_backward(e2emv_ctx* ctx, const float* const* d_dlogZ, void* stream) {
+extern "C" int e2emv_matcher_backward(e2emv_ctx* ctx, const float* const* d_dlogZ, const float* const* d_dconf, void* stream) {
     if (!ctx || !d_dlogZ) return E2EMV_EINVAL;
     E2EMV_ENTER(ctx, stream);
     TrainState* t = ts_of(ctx);
@@ -529,6 +582,31 @@ extern "C" int e2emv_matcher_backward(e2emv_ctx* ctx, const float* const* d_dlog
             g.C = dmd + (int64_t)j * n_rows * D; g.ldc = D; g.cz0 = tuple_stride; g.alpha = sc; g.mode = 1;
             if ((rc = launch_gg(ctx, g, s))) return rc;
         }
+    // ---- confidence heads (pose loss): d conf -> conf_mlp gradients and two more contributions to d mdesc ----
+    if (d_dconf && t->conf_mlp) {
+        int q = 0;
+        for (int j = 0; j < T; ++j)
+            for (int i = 0; i < j; ++i, ++q) {
+                if (!d_dconf[q]) continue;
+                if (!t->t_cmatch[q]) return set_err(ctx, E2EMV_ESTATE, "matcher_backward: d conf for pair %d without e2emv_conf_forward_train", q);
+                const int64_t rows = (int64_t)B * N;
+                float* dz = du;       // [B*N]      (B (N + 1) floats available)
+                float* dhc = dcat;    // [B*N][D]
+                float* dfeat = dh;    // [B*N][2D]
+                hipLaunchKernelGGL(conf_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, rows, D, (const float*)t->t_chid[q],
+                                   W + t->wc1, W + t->bc1, t->t_cmatch[q], d_dconf[q], dz, dhc);
+                E2EMV_CHECK_LAUNCH(ctx, "conf_bwd_kernel");
+                if ((rc = wgrad(ctx, dz, 1, 1, t->t_chid[q], D, D, rows, gw + t->wc1, D, s))) return rc;
+                if ((rc = colsum(ctx, dz, rows, 1, 1, gw + t->bc1, s))) return rc;
+                if ((rc = wgrad(ctx, dhc, D, D, t->t_cfeat[q], 2 * D, 2 * D, rows, gw + t->wc0, 2 * D, s))) return rc;
+                if ((rc = colsum(ctx, dhc, rows, D, D, gw + t->bc0, s))) return rc;
+                if ((rc = dgrad(ctx, dhc, D, D, W + t->wc0, 2 * D, 2 * D, rows, dfeat, 2 * D, false, s))) return rc;
+                hipLaunchKernelGGL(conf_scatter_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, N, D, (const float*)dfeat, t->t_cmatch[q],
+                                   dmd + (int64_t)i * n_rows * D, dmd + (int64_t)j * n_rows * D, tuple_stride);
+                E2EMV_CHECK_LAUNCH(ctx, "conf_scatter_kernel");
+            }
+        E2EMV_HIP(ctx, hipMemsetAsync(du, 0, (size_t)B * (N + 1) * sizeof(float), s));
+    }
     // ---- final_proj ----
     if ((rc = wgrad(ctx, dmd, D, D, t->t_x[L], D, D, Mtot, gw + t->wf, D, s))) return rc;
     if ((rc = colsum(ctx, dmd, Mtot, D, D, gw + t->bf, s))) return rc;
@@ -608,6 +686,10 @@ extern "C" int e2emv_matcher_backward(e2emv_ctx* ctx, const float* const* d_dlog
         unfold(base + ".mlp.3", "", gw + Lw.w1, gw + Lw.b1, 2 * D, 0, D, 2 * D, nullptr, 0, nullptr);
     }
     unfold("final_proj", "", gw + t->wf, gw + t->bf, D, 0, D, D, nullptr, 0, nullptr);
+    if (t->conf_mlp) {
+        unfold("conf_mlp.0", "conf_mlp.1", gw + t->wc0, gw + t->bc0, 2 * D, 0, D, 2 * D, nullptr, 0, nullptr);
+        unfold("conf_mlp.3", "", gw + t->wc1, gw + t->bc1, D, 0, 1, D, nullptr, 0, nullptr);
+    }
     E2EMV_HIP(ctx, hipMemcpyAsync(gref("bin_score"), gw + t->alpha, sizeof(float), hipMemcpyDeviceToDevice, s));
     E2EMV_CHECK_LAUNCH(ctx, "unfold kernels");
     return E2EMV_OK;

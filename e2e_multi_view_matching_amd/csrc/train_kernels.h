@@ -268,6 +268,62 @@ __global__ __launch_bounds__(256) void skb_alpha_kernel(int M, int N, const floa
     if (threadIdx.x == 0) atomicAdd(dalpha, red[0] + red[1] + red[2] + red[3]);
 }
 
+// ---- confidence head (conf_mlp) of the training path --------------------------------------------------------------------
+// feat[b][n][:] = [mdesc_i[b][n][:] | mdesc_j[b][max(match, 0)][:]]   (dense [B][N][2D]; mdesc rows n_rows apart per image)
+__global__ __launch_bounds__(256) void conf_feat_kernel(int N, int D, const float* mdesc_i, const float* mdesc_j, int64_t tuple_stride,
+                                                        const int64_t* matches, float* feat) {
+    const int b = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    int64_t j = matches[(int64_t)b * N + row];
+    if (j < 0) j = 0;
+    const float* si = mdesc_i + b * tuple_stride + (int64_t)row * D;
+    const float* sj = mdesc_j + b * tuple_stride + j * D;
+    float* dst = feat + ((int64_t)b * N + row) * 2 * D;
+    for (int c = lane; c < D; c += 64) { dst[c] = si[c]; dst[D + c] = sj[c]; }
+}
+// conf[r] = match[r] >= 0 ? sigmoid(<h[r], w1> + b1) : 0   (wave per row)
+__global__ __launch_bounds__(256) void conf_fwd_kernel(int64_t rows, int D, const float* hid, const float* w1, const float* b1, const int64_t* matches,
+                                                       float* conf) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float* h = hid + r * D;
+    float acc = 0.f;
+    for (int c = lane; c < D; c += 64) acc += h[c] * w1[c];
+    acc = tr_wave_sum(acc);
+    if (lane == 0) conf[r] = matches[r] >= 0 ? 1.f / (1.f + __expf(-(acc + b1[0]))) : 0.f;
+}
+// conf = sigmoid(z), z = <h, w1> + b1:  dz[r] = valid ? g[r] sigma (1 - sigma) : 0;  dh[r][:] = dz[r] w1[:] (h > 0)   (wave per row)
+__global__ __launch_bounds__(256) void conf_bwd_kernel(int64_t rows, int D, const float* hid, const float* w1, const float* b1, const int64_t* matches,
+                                                       const float* gconf, float* dz, float* dh) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float* h = hid + r * D;
+    float acc = 0.f;
+    for (int c = lane; c < D; c += 64) acc += h[c] * w1[c];
+    acc = tr_wave_sum(acc);
+    const float sg = 1.f / (1.f + __expf(-(acc + b1[0])));
+    const float d = matches[r] >= 0 ? gconf[r] * sg * (1.f - sg) : 0.f;
+    if (lane == 0) dz[r] = d;
+    for (int c = lane; c < D; c += 64) dh[r * D + c] = h[c] > 0.f ? d * w1[c] : 0.f;
+}
+// dmdesc_i[b][n][:] += dfeat[b][n][:D];  dmdesc_j[b][match][:] += dfeat[b][n][D:]  (matched rows only; mutual matches are unique,
+// atomics keep it safe for any index list)
+__global__ __launch_bounds__(256) void conf_scatter_kernel(int N, int D, const float* dfeat, const int64_t* matches, float* dmd_i, float* dmd_j,
+                                                           int64_t tuple_stride) {
+    const int b = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const int64_t j = matches[(int64_t)b * N + row];
+    if (j < 0) return;
+    const float* src = dfeat + ((int64_t)b * N + row) * 2 * D;
+    float* di = dmd_i + b * tuple_stride + (int64_t)row * D;
+    float* dj = dmd_j + b * tuple_stride + j * D;
+    for (int c = lane; c < D; c += 64) { atomicAdd(di + c, src[c]); atomicAdd(dj + c, src[D + c]); }
+}
+
 // ---- folded gradients -> the gradients of the upstream parameters --------------------------------------------------------
 // A convolution W [rows][cols] (+ bias) that was committed as  Wf[r'][c'] = s_r W[r][c],  bf[r'] = (b[r] - mean[r]) s_r + beta[r]
 // with s = gamma / sqrt(var + eps) (eval-mode BatchNorm folded; s = 1 without one), r' = rmap[r], c' = cmap[c] (head-major

@@ -23,8 +23,10 @@ there) and runs the hand-written HIP path; without the library or an MI355X it r
 Training, first slice: in ``.train()`` mode with gradients enabled the ``scores_{i}_{j}`` carry an autograd
 graph (``_MatchScores``: the library's fp32 forward with a tape and its hand-written backward, csrc/train.hip), so the
 reference's stage-1 step ``match_loss(...).backward(); optimizer.step()`` (``train.py:406-425``) works unchanged.
-BatchNorm layers normalise with their running statistics there (they are not updated); ``conf_mlp`` and the pose loss
-through the weighted 8-point solve get no gradient yet.
+BatchNorm layers normalise with their running statistics there (they are not updated).  With ``full_output`` (the reference
+sets it for the pose loss, ``helpers.py:245``) the matches come from the same fp32 forward and, for a model with ``conf_mlp``,
+``conf_scores_{i}_{j}`` carry the graph too: the pose loss of stage 2 reaches ``conf_mlp`` and the GNN through
+``pose.run_weighted_8_point`` (its backward: ``e2emv_w8pt_backward``).
 """
 import ctypes
 
@@ -58,13 +60,16 @@ DEFAULT_CONFIG = {
 
 
 class _MatchScores(torch.autograd.Function):
-    """scores_{i}_{j} = f(parameters): e2emv_matcher_forward_train / e2emv_matcher_backward behind torch.autograd.
+    """(scores_{i}_{j} ..., conf_scores_{i}_{j} ...) = f(parameters): ``e2emv_matcher_forward_train`` (+ ``e2emv_conf_forward_train``
+    per pair when the model has a ``conf_mlp`` and ``full_output`` is on) and ``e2emv_matcher_backward`` behind torch.autograd.
 
     The context keeps the tape of its LAST training forward only: backward() of an older graph raises."""
 
     @staticmethod
-    def forward(fctx, module, ctx, fd, kpts, scores, descs, shapes, names, *params):
+    def forward(fctx, cfg, *params):
+        ctx, fd, kpts, scores, descs, shapes, names, full, thr, holder = cfg
         dev = params[0].device
+        P = len(shapes)
         logZ = [torch.empty(s, dtype=torch.float32, device=dev) for s in shapes]
         keep, args = [], []
         for lst in (kpts, scores, descs, logZ):
@@ -74,29 +79,49 @@ class _MatchScores(torch.autograd.Function):
         with torch.cuda.device(dev):
             ctx.call("e2emv_matcher_forward_train", ctypes.byref(fd), *args, _lib.stream_ptr(dev))
         ctx.train_generation += 1
-        fctx.lib_ctx, fctx.generation, fctx.names, fctx.dev = ctx, ctx.train_generation, names, dev
-        fctx.shapes = shapes
+        conf = []
+        use_conf = full and any(n.startswith("conf_mlp.") for n in names)
+        if full:
+            from . import ops
+            extra = {"m0": [], "m1": [], "s0": [], "s1": [], "conf": []}
+            for p in range(P):
+                m0, m1, s0, s1 = ops.extract_matches(logZ[p], thr)   # the mutual-match block on the scores of THIS forward
+                for k, v in zip(("m0", "m1", "s0", "s1"), (m0, m1, s0, s1)):
+                    extra[k].append(v)
+                if use_conf:
+                    c = torch.empty(m0.shape, dtype=torch.float32, device=dev)
+                    with torch.cuda.device(dev):
+                        ctx.call("e2emv_conf_forward_train", p, _lib.ptr(m0), _lib.ptr(c), _lib.stream_ptr(dev))
+                    conf.append(c)
+                else:  # no conf_mlp: the confidence is the match score of the valid matches (quirk E13) - not differentiated
+                    from .pose import mask_confidence
+                    extra["conf"].append(mask_confidence(s0, m0 >= 0))
+            holder.append(extra)
+            fctx.keep = extra  # (the library reads the matches again in the backward)
+        fctx.lib_ctx, fctx.generation, fctx.names, fctx.dev, fctx.P = ctx, ctx.train_generation, names, dev, P
+        fctx.n_conf = len(conf)
         fctx.param_shapes = [p.shape for p in params]
         fctx.set_materialize_grads(False)
-        return tuple(logZ)
+        return tuple(logZ) + tuple(conf)
 
     @staticmethod
     def backward(fctx, *grads):
-        ctx, dev = fctx.lib_ctx, fctx.dev
+        ctx, dev, P = fctx.lib_ctx, fctx.dev, fctx.P
         if ctx.train_generation != fctx.generation:
             raise RuntimeError("MultiViewMatcher: backward() of a forward that is not the last training forward on this device "
                                "(the library keeps one tape per context)")
         g = [None if x is None else x.to(torch.float32).contiguous() for x in grads]
-        p, arr = _lib.ptr_array(g)
-        out = [None] * 8
+        pz, arr_z = _lib.ptr_array(g[:P])
+        pc, arr_c = _lib.ptr_array(g[P:]) if fctx.n_conf else (None, None)
+        out = [None]
         with torch.cuda.device(dev):
-            ctx.call("e2emv_matcher_backward", p, _lib.stream_ptr(dev))
+            ctx.call("e2emv_matcher_backward", pz, pc, _lib.stream_ptr(dev))
             for n, (name, shape) in enumerate(zip(fctx.names, fctx.param_shapes)):
-                if not fctx.needs_input_grad[8 + n]:
+                if not fctx.needs_input_grad[1 + n]:
                     out.append(None)
                     continue
-                if name.startswith("conf_mlp."):
-                    out.append(torch.zeros(shape, dtype=torch.float32, device=dev))  # not on the match-loss path
+                if name.startswith("conf_mlp.") and not fctx.n_conf:
+                    out.append(torch.zeros(shape, dtype=torch.float32, device=dev))  # conf head not on this graph
                     continue
                 t = torch.empty(shape, dtype=torch.float32, device=dev)
                 ctx.call("e2emv_get_grad", name.encode(), ctypes.c_void_p(t.data_ptr()), t.numel(), _lib.stream_ptr(dev))
@@ -291,7 +316,6 @@ class MultiViewMatcher(nn.Module):
         fd.desc_dtype = _lib.DESC_F16 if descs[0].dtype == torch.float16 else _lib.DESC_F32
         fd.flags = (_lib.FLAG_FULL_OUTPUT if full else 0) | (_lib.FLAG_MULTI_FRAME if cfg["multi_frame_matching"] else 0)
         P = len(pairs)
-        graph_scores = None
         if self._differentiable():
             if len(set(Ns)) != 1:
                 raise NotImplementedError("training path: all images of a call must carry the same number of keypoints "
@@ -300,10 +324,20 @@ class MultiViewMatcher(nn.Module):
                 raise NotImplementedError("training path: tuples of more than two images need multi_frame_matching")
             self._push_train_weights(ctx)
             named = [(k, p) for k, p in self.named_parameters()]
-            graph_scores = _MatchScores.apply(self, ctx, fd, kpts, scores, descs, [(B, N + 1, N + 1)] * P,
-                                              [k for k, _ in named], *[p for _, p in named])
-            if not full:
-                return {f"scores_{i}_{j}": graph_scores[p] for p, (i, j) in enumerate(pairs)}
+            holder = []
+            cfgt = (ctx, fd, kpts, scores, descs, [(B, N + 1, N + 1)] * P, [k for k, _ in named], full, float(cfg["match_threshold"]), holder)
+            outs = _MatchScores.apply(cfgt, *[p for _, p in named])
+            out = {f"scores_{i}_{j}": outs[p] for p, (i, j) in enumerate(pairs)}
+            if full:  # matches / confidences from the scores of this very forward (the fp32 training arithmetic)
+                extra = holder[0]
+                for p, (i, j) in enumerate(pairs):
+                    out[f"matches{i}_{i}_{j}"] = extra["m0"][p]
+                    out[f"matches{j}_{i}_{j}"] = extra["m1"][p]
+                    out[f"matching_scores{i}_{i}_{j}"] = extra["s0"][p]
+                    out[f"matching_scores{j}_{i}_{j}"] = extra["s1"][p]
+                    c = outs[P + p] if len(outs) > P else extra["conf"][p]
+                    out[f"conf_scores_{i}_{j}"] = c.unsqueeze(-1)
+            return out
         logZ = [torch.empty((B, Ns[i] + 1, Ns[j] + 1), dtype=torch.float32, device=dev) for i, j in pairs]
         none = [None] * P
         if full:
@@ -327,7 +361,7 @@ class MultiViewMatcher(nn.Module):
                 # range of the arithmetic mode (the scores of that call are NaN / inf either way)
                 ctx.call("e2emv_sync", _lib.stream_ptr(dev))
         for p, (i, j) in enumerate(pairs):
-            out[f"scores_{i}_{j}"] = logZ[p] if graph_scores is None else graph_scores[p]
+            out[f"scores_{i}_{j}"] = logZ[p]
             if full:
                 out[f"matches{i}_{i}_{j}"] = m0[p]
                 out[f"matches{j}_{i}_{j}"] = m1[p]

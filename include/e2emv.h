@@ -368,22 +368,29 @@ int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset);
  * with the reference's own arithmetic (fp32).  Differentiated: keypoint encoder, every GNN layer (projections, attention,
  * merge, MLP), final_proj, the score matrix, bin_score and the unrolled log-domain Sinkhorn (SuperGlue's
  * log_optimal_transport, models/superglue.py:156-186 upstream).  BatchNorm layers use their running statistics (frozen) and
- * still hand back gradients for their affine parameters.  Forward-only in this slice: conf_mlp, the pose loss through the
- * weighted 8-point solve, batch-statistics BatchNorm, images with differing keypoint counts.
+ * still hand back gradients for their affine parameters.  The pose loss (helpers.py:253-258) reaches the network through the
+ * confidences: e2emv_w8pt_backward (below) -> e2emv_conf_forward_train / d_dconf here.  Forward-only: batch-statistics
+ * BatchNorm, images with differing keypoint counts, the confidences of a model WITHOUT conf_mlp (the match score).
  *
  * e2emv_train_commit        folds the weights handed over with e2emv_set_weight into the training arena (call again after
  *                           every optimiser step, after re-sending the changed tensors).
  * e2emv_matcher_forward_train   same inputs as e2emv_matcher_forward (fd->n_kpts keypoints in every image); outputs the
  *                           log assignment matrices d_logZ[pair] = [batch][n_kpts + 1][n_kpts + 1] fp32, pairs in the
  *                           order (0,1), (0,2), (1,2), ... and keeps the tape of this call in the context.
- * e2emv_matcher_backward    d_dlogZ[pair] = dLoss / dlogZ of the last forward_train (same layout; a null entry = zero):
+ * e2emv_conf_forward_train  (models with conf_mlp; the pose loss) confidence head of one pair on the tape's matched descriptors:
+ *                           d_conf [batch][n_kpts] = sigmoid(conf_mlp([mdesc_i[n] | mdesc_j[match n]])) for matched n, else 0;
+ *                           d_matches0 = that pair's matches (e.g. from e2emv_extract_matches on d_logZ), kept alive by the
+ *                           caller until the backward.
+ * e2emv_matcher_backward    d_dlogZ[pair] = dLoss / dlogZ of the last forward_train (same layout; a null entry = zero),
+ *                           d_dconf (may be null) [pair] = dLoss / dconf of e2emv_conf_forward_train (a null entry = zero):
  *                           leaves the gradient of every upstream parameter in the context.
  * e2emv_get_grad            copies the gradient of parameter `key` (the reference's state_dict name, an optional "module."
  *                           prefix is ignored) into d_dst (device, fp32, numel elements); stream-ordered.                 */
 int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* model);
 int e2emv_matcher_forward_train(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const float* const* d_kpts, const float* const* d_kscores,
                                 const void* const* d_desc, float* const* d_logZ, void* stream);
-int e2emv_matcher_backward(e2emv_ctx* ctx, const float* const* d_dlogZ, void* stream);
+int e2emv_conf_forward_train(e2emv_ctx* ctx, int pair, const int64_t* d_matches0, float* d_conf, void* stream);
+int e2emv_matcher_backward(e2emv_ctx* ctx, const float* const* d_dlogZ, const float* const* d_dconf, void* stream);
 int e2emv_get_grad(e2emv_ctx* ctx, const char* key, float* d_dst, int64_t numel, void* stream);
 
 /* Backward of e2emv_w8pt with respect to the confidences (training, the pose loss of helpers.py:253-258: rot / translation

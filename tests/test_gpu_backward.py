@@ -88,11 +88,11 @@ def _grads(cfg, data_kw, gpu, seed):
     return model, leaves, out, ref, pairs
 
 
-def _check(model, leaves):
+def _check(model, leaves, conf_too=False):
     assert _has_finite_gradients(model)
     worst = {}
     for k, p in model.named_parameters():
-        if k.startswith("conf_mlp."):
+        if k.startswith("conf_mlp.") and not conf_too:
             continue
         assert p.grad is not None, k
         g, gr = p.grad.cpu().double(), leaves[k].grad.double()
@@ -155,7 +155,7 @@ def test_optimizer_step_is_seen_by_the_next_forward(gpu):
         loss.backward()
         assert _has_finite_gradients(model)
         opt.step()
-        losses.append(float(loss))
+        losses.append(loss.item())
     assert losses[2] < losses[1] < losses[0], losses
 
 
@@ -270,3 +270,69 @@ def test_pose_error_gradients(gpu):
         lp.backward()
         assert abs(lp.item() - lr.item()) < 1e-5
         assert float((a.grad.cpu().double() - a_ref.grad).abs().max()) < 1e-5 * float(a_ref.grad.abs().max())
+
+
+def test_pose_loss_gradients_end_to_end(gpu):
+    """Stage-2 training step (helpers.run_matcher with opt.pose_loss, helpers.py:243-260): match loss on the scores + a pose loss
+    on run_weighted_8_point's pose, whose confidences come from conf_mlp on the matched descriptors.  Gradients of EVERY
+    parameter (conf_mlp included) against autograd through the oracle (matcher in fp32, weighted 8-point in fp64).
+    Weights: identity-like (real matches, a well-posed 8-point problem) plus a perturbation so that no gradient vanishes."""
+    from e2e_multi_view_matching_amd import MultiViewMatcher
+    import e2e_multi_view_matching_amd as E
+    from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
+    from oracle.matcher import matcher_forward
+    from oracle import w8pt as OW
+    torch.manual_seed(21)
+    cfg = {"GNN_layers": ["self", "cross"], "sinkhorn_iterations": 30, "conf_mlp": True, "match_threshold": 0.2, "full_output": True}
+    model = MultiViewMatcher(cfg)
+    _randomize_bn(model, 21)
+    identity_like_state(model)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(22)
+        for _, prm in model.named_parameters():
+            prm.add_(torch.randn(prm.shape, generator=g) * (0.01 if prm.dim() > 1 else 0.005))
+    B, N = 2, 256
+    data = make_tuples(batch=B, tuple_size=2, n_kpts=N, seed=9)
+    idx, w = _targets(B, N, 900)
+    Wr = torch.randn(B, 3, 4, generator=torch.Generator().manual_seed(23))
+    # the 8-point solve sees camera coordinates made ONCE in fp32 (identical numbers on both sides) and identity intrinsics
+    Kc = data["intr0"]
+    eye = torch.eye(4).unsqueeze(0).repeat(B, 1, 1)
+    pose_in = {"intr0": eye, "intr1": eye}
+    for m in range(2):
+        pose_in[f"keypoints{m}"] = (data[f"keypoints{m}"] - Kc[:, None, :2, 2]) / torch.stack([Kc[:, 0, 0], Kc[:, 1, 1]], -1)[:, None]
+    Tgt = data["T_0to1"]
+
+    def pose_term(T):
+        T = T.double()
+        W = Wr.to(T.device).double()
+        return (T[:, :3, :] * W).sum() + ((T[:, :3, :] - 0.3) ** 2 * W.flip(1)).sum()
+
+    # ---- oracle ----
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    leaves = {k: sd[k].requires_grad_(True) for k, _ in model.named_parameters()}
+    ocfg = dict(model.config)
+    ocfg.update(full_output=True, grad=True)
+    for k in ("mfma_precision", "autograd", "check_finite"):
+        ocfg.pop(k, None)
+    ref = matcher_forward(data, sd, ocfg)
+    res64 = {"matches0_0_1": ref["matches0_0_1"], "conf_scores_0_1": ref["conf_scores_0_1"].double()}
+    T_ref, _ = OW.run_weighted_8_point({k: (v.double() if torch.is_tensor(v) else v) for k, v in pose_in.items()}, res64, 0, 1,
+                                       choose_closest=True, target_T_021=Tgt.double())
+    loss_ref = _match_loss(ref["scores_0_1"], idx, w).double() + 5.0 * pose_term(T_ref)
+    loss_ref.backward()
+    # ---- product ----
+    model = model.to(gpu).train()
+    out = model({k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in data.items()})
+    assert torch.equal(out["matches0_0_1"].cpu(), ref["matches0_0_1"]) and int((ref["matches0_0_1"] >= 0).sum()) > 0.3 * B * N
+    assert out["conf_scores_0_1"].requires_grad and out["scores_0_1"].requires_grad
+    assert float((out["conf_scores_0_1"].detach().cpu() - ref["conf_scores_0_1"].detach()).abs().max()) < 1e-5
+    T, _ = E.run_weighted_8_point({k: v.to(gpu) for k, v in pose_in.items()}, out, 0, 1, choose_closest=True, target_T_021=Tgt.to(gpu))
+    assert float((T.detach().cpu().double() - T_ref.detach()).abs().max()) < 1e-4
+    loss = _match_loss(out["scores_0_1"], idx.to(gpu), w.to(gpu)).double() + 5.0 * pose_term(T)
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-3 * abs(loss_ref.item())
+    worst = _check(model, leaves, conf_too=True)
+    assert any(k.startswith("conf_mlp.") for k in worst)
+    # the pose term reached the network: without it the conf head gets exactly zero
+    assert all(float(p.grad.abs().max()) > 0 for k, p in model.named_parameters() if k.startswith("conf_mlp."))
