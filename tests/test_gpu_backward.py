@@ -336,3 +336,47 @@ def test_pose_loss_gradients_end_to_end(gpu):
     assert any(k.startswith("conf_mlp.") for k in worst)
     # the pose term reached the network: without it the conf head gets exactly zero
     assert all(float(p.grad.abs().max()) > 0 for k, p in model.named_parameters() if k.startswith("conf_mlp."))
+
+
+def test_stage2_step_the_way_run_matcher_drives_it(gpu):
+    """The reference's loop body (helpers.py:243-260, train.py:406-425) spelled out on this package's callables: a DataParallel-
+    wrapped matcher, `matcher.module.config["full_output"] = True`, match loss over the scores, pose = run_weighted_8_point(...,
+    choose_closest=True, target_T_021=inv(pose1) @ pose0 ...), rotation + translation-angle losses, backward, the
+    has_finite_gradients gate, two optimiser groups (conf_mlp apart, helpers.get_parameters), step - twice."""
+    import e2e_multi_view_matching_amd as E
+    from e2e_multi_view_matching_amd import MultiViewMatcher
+    from e2e_multi_view_matching_amd.synthetic import identity_like_state, make_tuples
+    torch.manual_seed(3)
+    model = MultiViewMatcher({"GNN_layers": ["self", "cross"], "sinkhorn_iterations": 20, "conf_mlp": True})
+    identity_like_state(model)
+    matcher = torch.nn.DataParallel(model.to(gpu), device_ids=[gpu.index or 0]).train()
+    conf_params = [p for k, p in matcher.named_parameters() if "conf_mlp" in k]
+    other = [p for k, p in matcher.named_parameters() if "conf_mlp" not in k]
+    opt = torch.optim.Adam([{"params": other, "lr": 1e-5}, {"params": conf_params, "lr": 1e-4}])
+    B, N = 2, 256
+    data = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in make_tuples(batch=B, tuple_size=2, n_kpts=N, seed=14).items()}
+    gt = data["gt_matches0_0_1"]
+    idx = torch.full((B, 2, N + 1), N, dtype=torch.int64, device=gpu)
+    idx[:, 0, :N] = torch.where(gt >= 0, gt, torch.full_like(gt, N))
+    for b in range(B):
+        has = gt[b] >= 0
+        idx[b, 1, gt[b][has]] = torch.arange(N, device=gpu)[has]
+    w = torch.ones((B, 2, N + 1), device=gpu)
+    w[:, :, N] = 0
+    before = [p.detach().clone() for p in conf_params]
+    for _ in range(2):
+        opt.zero_grad()
+        matcher.module.config["full_output"] = True
+        result = matcher(data)
+        match_loss = _match_loss(result["scores_0_1"], idx, w)
+        target = data["T_0to1"]
+        pred, _ = E.run_weighted_8_point(data, result, 0, 1, choose_closest=True, target_T_021=target)
+        rot_loss = E.compute_rotation_error(pred, target)
+        transl_loss = E.compute_translation_error_as_angle(pred, target)
+        train_loss = match_loss + 100.0 * (rot_loss + transl_loss)
+        assert bool(torch.isfinite(train_loss))
+        train_loss.backward()
+        assert _has_finite_gradients(matcher)
+        assert all(p.grad is not None and float(p.grad.abs().max()) > 0 for p in conf_params)
+        opt.step()
+    assert all(not torch.equal(a, p.detach()) for a, p in zip(before, conf_params))
