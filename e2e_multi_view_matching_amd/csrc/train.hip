@@ -113,7 +113,7 @@ static int dgrad(e2emv_ctx* ctx, const float* dY, int64_t ldy, int n_out, const 
     return launch_gg(ctx, g, s);
 }
 static int colsum(e2emv_ctx* ctx, const float* X, int64_t rows, int N, int64_t ld, float* out, hipStream_t s) {
-    const int64_t per = 2048;
+    const int64_t per = 256;  // (rows per workgroup: the loop is a chain of dependent loads - keep it short, many workgroups)
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (unsigned)((rows + per - 1) / per)), dim3(256), 0, s, X, rows, N, ld, out, per);
     E2EMV_CHECK_LAUNCH(ctx, "colsum_kernel");
     return E2EMV_OK;
@@ -407,7 +407,7 @@ extern "C" int e2emv_matcher_forward_train(e2emv_ctx* ctx, const e2emv_forward_d
                 float* v_t = u_t + (N + 1);
                 const float* v_p = uv + (int64_t)(it - 1) * 2 * (N + 1) + (N + 1);
                 hipLaunchKernelGGL(skt_row_kernel, dim3((N + 1 + 3) / 4, B), dim3(256), 0, s, sk, v_p, u_t, uvs, uvs);
-                hipLaunchKernelGGL(skt_col_kernel, dim3((N + 1 + 255) / 256, B), dim3(256), 0, s, sk, (const float*)u_t, v_t, uvs, uvs);
+                hipLaunchKernelGGL(skt_col_kernel, dim3((N + 1 + 63) / 64, B), dim3(1024), 0, s, sk, (const float*)u_t, v_t, uvs, uvs);
             }
             if (!d_logZ[pidx]) return set_err(ctx, E2EMV_EINVAL, "matcher_forward_train: null logZ for pair %d", pidx);
             const float* u_T = uv + (int64_t)iters * 2 * (N + 1);
@@ -561,7 +561,7 @@ extern "C" int e2emv_matcher_backward(e2emv_ctx* ctx, const float* const* d_dlog
                 const float* v_t = u_t + (N + 1);
                 const float* v_p = uv + (int64_t)(it - 1) * 2 * (N + 1) + (N + 1);
                 hipLaunchKernelGGL(skb_vhalf_kernel, dim3((N + 1 + 3) / 4, B), dim3(256), 0, s, sk, u_t, v_t, (const float*)dv_cur, du, dC, uvs, uvs, (int64_t)(N + 1));
-                hipLaunchKernelGGL(skb_uhalf_kernel, dim3((N + 1 + 255) / 256, B), dim3(256), 0, s, sk, u_t, v_p, (const float*)du, dv_nxt, dC, uvs, uvs, (int64_t)(N + 1));
+                hipLaunchKernelGGL(skb_uhalf_kernel, dim3((N + 1 + 63) / 64, B), dim3(1024), 0, s, sk, u_t, v_p, (const float*)du, dv_nxt, dC, uvs, uvs, (int64_t)(N + 1));
                 E2EMV_HIP(ctx, hipMemsetAsync(du, 0, (size_t)B * (N + 1) * sizeof(float), s));
                 std::swap(dv_cur, dv_nxt);
             }

@@ -175,18 +175,34 @@ __global__ __launch_bounds__(256) void skt_row_kernel(SkT p, const float* v, flo
     s = tr_wave_sum(s);
     if (lane == 0) u[b * ustride + i] = (i < p.M ? p.norm : p.logN + p.norm) - (mx + __logf(s));
 }
-// v[j] = log_nu_j - LSE_i(C[i][j] + u[i]); one thread per column j in [0, N]
-__global__ __launch_bounds__(256) void skt_col_kernel(SkT p, const float* u, float* v, int64_t ustride, int64_t vstride) {
-    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (j > p.N) return;
+// v[j] = log_nu_j - LSE_i(C[i][j] + u[i]); a workgroup of 16 waves owns 64 columns: wave w walks the rows i = w, w + 16, ...
+// (65 dependent steps instead of M + 1 - a thread per column was latency-bound: 0.5 ms per launch), lane = column; the 16
+// partial (max, sum) pairs of a column are merged through LDS in a fixed order
+__global__ __launch_bounds__(1024) void skt_col_kernel(SkT p, const float* u, float* v, int64_t ustride, int64_t vstride) {
+    __shared__ float smx[16][64], ssm[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
+    const int j = blockIdx.x * 64 + lane;
     const float* Sb = p.S + (int64_t)b * p.M * p.ldS;
     const float* ub = u + b * ustride;
     float mx = -INFINITY, s = 0.f;
-    for (int i = 0; i <= p.M; ++i) {
-        const float x = skt_c(p, Sb, i, j) + ub[i];
-        if (x > mx) { s = s * __expf(mx - x) + 1.f; mx = x; } else { s += __expf(x - mx); }
+    if (j <= p.N)
+        for (int i = wv; i <= p.M; i += 16) {
+            const float x = skt_c(p, Sb, i, j) + ub[i];
+            if (x > mx) { s = s * __expf(mx - x) + 1.f; mx = x; } else { s += __expf(x - mx); }
+        }
+    smx[wv][lane] = mx;
+    ssm[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && j <= p.N) {
+        float M = smx[0][lane], S = ssm[0][lane];
+        for (int k = 1; k < 16; ++k) {
+            const float m2 = smx[k][lane], s2 = ssm[k][lane];
+            const float nm = fmaxf(M, m2);
+            S = (M == -INFINITY ? 0.f : S * __expf(M - nm)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - nm));
+            M = nm;
+        }
+        v[b * vstride + j] = (j < p.N ? p.norm : p.logM + p.norm) - (M + __logf(S));
     }
-    v[b * vstride + j] = (j < p.N ? p.norm : p.logM + p.norm) - (mx + __logf(s));
 }
 // Z[i][j] = C[i][j] + u[i] + v[j] - norm, dense [B][M+1][N+1]
 __global__ __launch_bounds__(256) void skt_out_kernel(SkT p, const float* u, const float* v, int64_t ustride, int64_t vstride, float* Z) {
@@ -236,24 +252,34 @@ __global__ __launch_bounds__(256) void skb_vhalf_kernel(SkT p, const float* u, c
     s = tr_wave_sum(s);
     if (lane == 0) du[b * dstride + i] -= s;
 }
-// u_t = log_mu - LSE_j(C + v_{t-1}):  P = exp(C + v_{t-1}[j] + u_t[i] - log_mu_i);  dC -= du[i] P;  dv_prev[j] = -sum_i du[i] P   (thread per column)
-__global__ __launch_bounds__(256) void skb_uhalf_kernel(SkT p, const float* u, const float* v_prev, const float* du, float* dv_prev, float* dC,
-                                                        int64_t ustride, int64_t vstride, int64_t dstride) {
-    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (j > p.N) return;
+// u_t = log_mu - LSE_j(C + v_{t-1}):  P = exp(C + v_{t-1}[j] + u_t[i] - log_mu_i);  dC -= du[i] P;  dv_prev[j] = -sum_i du[i] P
+// (16 waves x 64 columns like skt_col_kernel: wave w takes the rows i = w, w + 16, ...; column sums merged through LDS)
+__global__ __launch_bounds__(1024) void skb_uhalf_kernel(SkT p, const float* u, const float* v_prev, const float* du, float* dv_prev, float* dC,
+                                                         int64_t ustride, int64_t vstride, int64_t dstride) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
+    const int j = blockIdx.x * 64 + lane;
     const float* Sb = p.S + (int64_t)b * p.M * p.ldS;
     const float* ub = u + b * ustride;
     const float* dub = du + b * dstride;
-    float* d = dC + (int64_t)b * (p.M + 1) * (p.N + 1) + j;
-    const float vj = v_prev[b * vstride + j];
     float s = 0.f;
-    for (int i = 0; i <= p.M; ++i) {
-        const float g = dub[i];
-        const float P = __expf(skt_c(p, Sb, i, j) + vj + ub[i] - (i < p.M ? p.norm : p.logN + p.norm));
-        d[(int64_t)i * (p.N + 1)] -= g * P;
-        s += g * P;
+    if (j <= p.N) {
+        float* d = dC + (int64_t)b * (p.M + 1) * (p.N + 1) + j;
+        const float vj = v_prev[b * vstride + j];
+        for (int i = wv; i <= p.M; i += 16) {
+            const float g = dub[i];
+            const float P = __expf(skt_c(p, Sb, i, j) + vj + ub[i] - (i < p.M ? p.norm : p.logN + p.norm));
+            d[(int64_t)i * (p.N + 1)] -= g * P;
+            s += g * P;
+        }
     }
-    dv_prev[b * dstride + j] = -s;
+    part[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && j <= p.N) {
+        float t = part[0][lane];
+        for (int k = 1; k < 16; ++k) t += part[k][lane];
+        dv_prev[b * dstride + j] = -t;
+    }
 }
 // d alpha += sum over the dustbin row and column of dC (all problems); one workgroup per problem
 __global__ __launch_bounds__(256) void skb_alpha_kernel(int M, int N, const float* dC, float* dalpha) {
