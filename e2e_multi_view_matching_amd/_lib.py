@@ -42,7 +42,8 @@ class ForwardDesc(ctypes.Structure):
 class SuperPointDesc(ctypes.Structure):
     _fields_ = [("batch", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32), ("nms_radius", ctypes.c_int32),
                 ("max_keypoints", ctypes.c_int32), ("remove_borders", ctypes.c_int32), ("fill_random", ctypes.c_int32),
-                ("keypoint_threshold", ctypes.c_float), ("seed", ctypes.c_uint32)]
+                ("keypoint_threshold", ctypes.c_float), ("seed", ctypes.c_uint32), ("valid_height", ctypes.c_int32),
+                ("valid_width", ctypes.c_int32)]
 
 
 # every symbol include/e2emv.h declares: name -> (restype, argtypes)

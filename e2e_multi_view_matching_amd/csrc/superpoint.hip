@@ -400,6 +400,28 @@ int sp_conv3x3(e2emv_ctx* ctx, int layer, const float* in, float* out, int imgs,
     return rc;
 }
 
+// Images whose height / width is not a multiple of 8 (upstream: the convolutions see the whole image, every max-pool floors):
+// the encoder runs on the zero-padded multiple-of-8 grid and, after every convolution, the part of its output that lies outside
+// the VALID size of that level (H, H/2, H/4 floored like the pools) is set to zero - exactly the zero padding upstream's next
+// convolution would see there; behind the third pool the valid block is cropped out and everything after runs on it unpadded.
+typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void sp_zero_outside_kernel(float* buf, int Hp, int Wp, int C4, int hv, int wv, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / C4;
+        const int x = (int)(pix % Wp), y = (int)((pix / Wp) % Hp);
+        if (y >= hv || x >= wv) reinterpret_cast<sp_f32x4*>(buf)[i] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+__global__ __launch_bounds__(256) void sp_crop_kernel(const float* src, float* dst, int Hs, int Ws, int hv, int wv, int C4, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        const int64_t pix = i / C4;
+        const int x = (int)(pix % wv), y = (int)((pix / wv) % hv);
+        const int64_t b = pix / ((int64_t)wv * hv);
+        reinterpret_cast<sp_f32x4*>(dst)[i] = reinterpret_cast<const sp_f32x4*>(src)[((b * Hs + y) * Ws + x) * C4 + c];
+    }
+}
+
 int sp_conv1x1(e2emv_ctx* ctx, int layer, const float* in, float* out, int64_t rows, hipStream_t s) {
     GemmArgs g;
     g.M = (int)rows; g.N = kSpCout[layer]; g.K = kSpCin[layer];
@@ -421,17 +443,24 @@ extern "C" int e2emv_superpoint_forward(e2emv_ctx* ctx, const e2emv_superpoint_d
     E2EMV_ENTER(ctx, stream);
     if (!d || !d_images || !d_kpts || !d_scores || !d_desc || !d_count) return set_err(ctx, E2EMV_EINVAL, "superpoint_forward: NULL argument");
     if (!ctx->sp_committed) return set_err(ctx, E2EMV_ESTATE, "superpoint_forward: weights not committed (e2emv_superpoint_commit)");
-    const int B = d->batch, H = d->height, W = d->width, K = d->max_keypoints, r = d->nms_radius;
-    if (B < 1 || H < 16 || W < 16 || H % 8 || W % 8) return set_err(ctx, E2EMV_ESHAPE, "superpoint_forward: image %dx%d must be a multiple of 8 (>= 16)", H, W);
+    const int B = d->batch, K = d->max_keypoints, r = d->nms_radius;
+    const int Hp = d->height, Wp = d->width;  // the (padded) grid the images are stored on
+    if (B < 1 || Hp < 16 || Wp < 16 || Hp % 8 || Wp % 8) return set_err(ctx, E2EMV_ESHAPE, "superpoint_forward: image %dx%d must be a multiple of 8 (>= 16)", Hp, Wp);
+    const int Hv = d->valid_height > 0 ? d->valid_height : Hp, Wv = d->valid_width > 0 ? d->valid_width : Wp;  // the image itself
+    if (Hv > Hp || Wv > Wp || Hp - Hv >= 8 || Wp - Wv >= 8 || Hv < 16 || Wv < 16)
+        return set_err(ctx, E2EMV_ESHAPE, "superpoint_forward: valid size %dx%d must lie within 7 pixels below the padded %dx%d", Hv, Wv, Hp, Wp);
+    const bool padded = Hv != Hp || Wv != Wp;
+    const int H = Hv / 8 * 8, W = Wv / 8 * 8;  // size of the score map = what every stage behind the encoder works on
     if (K < 1 || K > kSelMaxK) return set_err(ctx, E2EMV_ESHAPE, "superpoint_forward: max_keypoints %d outside 1..%d", K, kSelMaxK);
     if (r < 0 || r > 16 || d->remove_borders < 0) return set_err(ctx, E2EMV_EINVAL, "superpoint_forward: nms_radius %d / remove_borders %d", r, d->remove_borders);
-    if ((int64_t)B * H * W >= (int64_t(1) << 31)) return set_err(ctx, E2EMV_ESHAPE, "superpoint_forward: batch too large for one call (B*H*W < 2^31)");
+    if ((int64_t)B * Hp * Wp >= (int64_t(1) << 31)) return set_err(ctx, E2EMV_ESHAPE, "superpoint_forward: batch too large for one call (B*H*W < 2^31)");
     hipStream_t s = (hipStream_t)stream;
+    const int64_t npix_p = (int64_t)B * Hp * Wp;
     const int64_t npix = (int64_t)B * H * W, cells = npix / 64;
     const int Hc = H / 8, Wc = W / 8;
     auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
     // workspace: two full-resolution 64-channel buffers (ping-pong for the whole encoder), heads, 5 score-sized maps, lists
-    const size_t big = al(sizeof(float) * npix * 64);
+    const size_t big = al(sizeof(float) * npix_p * 64);
     const size_t sz_x = al(sizeof(float) * cells * 128), sz_p = al(sizeof(float) * cells * 256), sz_65 = al(sizeof(float) * cells * 65);
     const size_t sz_map = al(sizeof(float) * npix);
     const size_t bytes = 2 * big + sz_x + 2 * sz_p + sz_65 + 7 * sz_map;
@@ -448,15 +477,33 @@ extern "C" int e2emv_superpoint_forward(e2emv_ctx* ctx, const e2emv_superpoint_d
 
     // ---- encoder ----
     prof_begin(ctx, PS_INGEST, s);
-    hipLaunchKernelGGL(sp_conv1a_kernel, dim3((unsigned)((npix + 15) / 16)), dim3(256), 0, s, d_images, ctx->sp_w[0], ctx->sp_b[0], A, H, W, npix);
+    hipLaunchKernelGGL(sp_conv1a_kernel, dim3((unsigned)((npix_p + 15) / 16)), dim3(256), 0, s, d_images, ctx->sp_w[0], ctx->sp_b[0], A, Hp, Wp, npix_p);
     E2EMV_CHECK_LAUNCH(ctx, "sp_conv1a_kernel");
     prof_end(ctx, s);
+    auto zero_outside = [&](float* buf, int lvl, int C) {  // zero what lies outside the valid size of encoder level `lvl` (1, 2, 4 = stride)
+        if (!padded) return;
+        const int hp = Hp / lvl, wp = Wp / lvl, hv = Hv / lvl, wv = Wv / lvl;
+        if (hv == hp && wv == wp) return;
+        const int64_t total = (int64_t)B * hp * wp * (C / 4);
+        hipLaunchKernelGGL(sp_zero_outside_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, s, buf, hp, wp, C / 4, hv, wv, total);
+    };
     // conv_b of blocks 1-3 write their 2x2 max-pooled output directly (fused epilogue)
-    if ((rc = sp_conv3x3(ctx, 1, A, Bf, B, H, W, s, true))) return rc;
-    if ((rc = sp_conv3x3(ctx, 2, Bf, A, B, H / 2, W / 2, s))) return rc;
-    if ((rc = sp_conv3x3(ctx, 3, A, Bf, B, H / 2, W / 2, s, true))) return rc;
-    if ((rc = sp_conv3x3(ctx, 4, Bf, A, B, H / 4, W / 4, s))) return rc;
-    if ((rc = sp_conv3x3(ctx, 5, A, Bf, B, H / 4, W / 4, s, true))) return rc;
+    zero_outside(A, 1, 64);
+    if ((rc = sp_conv3x3(ctx, 1, A, Bf, B, Hp, Wp, s, true))) return rc;
+    zero_outside(Bf, 2, 64);
+    if ((rc = sp_conv3x3(ctx, 2, Bf, A, B, Hp / 2, Wp / 2, s))) return rc;
+    zero_outside(A, 2, 64);
+    if ((rc = sp_conv3x3(ctx, 3, A, Bf, B, Hp / 2, Wp / 2, s, true))) return rc;
+    zero_outside(Bf, 4, 64);
+    if ((rc = sp_conv3x3(ctx, 4, Bf, A, B, Hp / 4, Wp / 4, s))) return rc;
+    zero_outside(A, 4, 128);
+    if ((rc = sp_conv3x3(ctx, 5, A, Bf, B, Hp / 4, Wp / 4, s, true))) return rc;
+    if (padded && (Hc != Hp / 8 || Wc != Wp / 8)) {  // the valid block of the third pool's output, unpadded from here on
+        const int64_t total = (int64_t)B * Hc * Wc * 32;
+        hipLaunchKernelGGL(sp_crop_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, s, (const float*)Bf, A, Hp / 8, Wp / 8, Hc, Wc, 32, total);
+        E2EMV_CHECK_LAUNCH(ctx, "sp_crop_kernel");
+        std::swap(A, Bf);
+    }
     if ((rc = sp_conv3x3(ctx, 6, Bf, A, B, Hc, Wc, s))) return rc;
     if ((rc = sp_conv3x3(ctx, 7, A, X, B, Hc, Wc, s))) return rc;
     // ---- detector head ----

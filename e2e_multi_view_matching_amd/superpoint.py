@@ -63,25 +63,25 @@ class SuperPoint(nn.Module):
             B, C, H, W = batch.shape
             if C != 1:
                 raise AssertionError("SuperPoint takes one-channel images, got {}".format(tuple(batch.shape)))
-            # the encoder pools three times: like upstream only the top-left (H//8*8) x (W//8*8) region yields keypoints.
-            # Upstream's convolutions still SEE the cut rows/columns before its pools floor them away; here they are
-            # cropped first (documented deviation, INTEGRATION.md: responses within ~16 px of a cropped edge can differ).
+            # the encoder pools three times: only the top-left (H//8*8) x (W//8*8) region yields keypoints, but upstream's
+            # convolutions SEE the rows / columns beyond it before the pools floor them away.  Same here: the image goes in
+            # zero-padded to the next multiple of 8 and the library masks every encoder level to its valid size.
+            Hv, Wv = H, W
             if H % 8 or W % 8:
-                H, W = H // 8 * 8, W // 8 * 8
-                if H == 0 or W == 0:
-                    raise AssertionError("SuperPoint needs images of at least 8x8 pixels")
-                batch = batch[:, :, :H, :W]
+                Hp, Wp = (H + 7) // 8 * 8, (W + 7) // 8 * 8
+                batch = torch.nn.functional.pad(batch, (0, Wp - W, 0, Hp - H))
+                H, W = Hp, Wp
             img = batch.to(torch.float32).contiguous()
             cfg = self.config
             K = cfg["max_keypoints"] if cfg["max_keypoints"] > 0 else MAX_KEYPOINTS_CAPACITY
-            d = _lib.SuperPointDesc(batch=B, height=H, width=W, nms_radius=int(cfg["nms_radius"]), max_keypoints=K,
+            d = _lib.SuperPointDesc(valid_height=Hv, valid_width=Wv, batch=B, height=H, width=W, nms_radius=int(cfg["nms_radius"]), max_keypoints=K,
                                     remove_borders=int(cfg["remove_borders"]), fill_random=1 if cfg["fill_with_random_keypoints"] else 0,
                                     keypoint_threshold=float(cfg["keypoint_threshold"]), seed=int(cfg.get("seed", 0)))
             kpts = torch.empty((B, K, 2), dtype=torch.float32, device=dev)
             scores = torch.empty((B, K), dtype=torch.float32, device=dev)
             desc = torch.empty((B, 256, K), dtype=torch.float32, device=dev)
             count = torch.empty((B,), dtype=torch.int32, device=dev)
-            smap = torch.empty((B, H, W), dtype=torch.float32, device=dev) if cfg.get("return_score_map") else None
+            smap = torch.empty((B, Hv // 8 * 8, Wv // 8 * 8), dtype=torch.float32, device=dev) if cfg.get("return_score_map") else None
             with torch.cuda.device(dev), ctx.py_lock:
                 self._upload(ctx)  # (again, now under the lock: another thread's model may have taken the context's weight set)
                 ctx.call("e2emv_superpoint_forward", ctypes.byref(d), _lib.ptr(img), _lib.ptr(kpts), _lib.ptr(scores), _lib.ptr(desc),

@@ -263,7 +263,7 @@ int e2emv_mv_triangulate(e2emv_ctx* ctx, int n, const double* P0, const double* 
  * convDb), then e2emv_superpoint_commit repacks them for NHWC implicit-GEMM convolutions.                          */
 typedef struct {
     int32_t batch;             /* images in this call (a merged tuple batch, helpers.py:73-81)                      */
-    int32_t height, width;     /* multiples of 8                                                                      */
+    int32_t height, width;     /* multiples of 8 (the storage grid; see valid_height / valid_width)                   */
     int32_t nms_radius;        /* config "nms_radius"                                                                 */
     int32_t max_keypoints;     /* K: capacity of the outputs, 1..4096 (config "max_keypoints"; -1 is mapped by the
                                   Python layer to the capacity)                                                       */
@@ -271,12 +271,15 @@ typedef struct {
     int32_t fill_random;       /* fork option "fill_with_random_keypoints": pad to K with pseudo-random pixels        */
     float keypoint_threshold;  /* config "keypoint_threshold"                                                         */
     uint32_t seed;             /* for fill_random                                                                     */
+    int32_t valid_height, valid_width; /* 0 = height / width.  Otherwise the size of the images themselves, stored zero-padded
+                                  on the (height, width) grid with height - valid_height < 8 (same for the width): the
+                                  convolutions see the whole image and every max-pool floors, like upstream            */
 } e2emv_superpoint_desc;
 int e2emv_superpoint_commit(e2emv_ctx* ctx);
 /* d_images [B,H,W] fp32 grey in [0,1].  Outputs: d_kpts [B,K,2] pixel (x, y), d_scores [B,K], d_desc [B,256,K]
  * (descriptor-major, what the matcher's descriptors{m} input wants), d_count [B] valid entries per image (the rest is
  * zero).  Order: row-major when an image has <= K candidates, else score-descending (ties: lower pixel index).
- * d_score_map (optional) [B,H,W] receives the NMS-ed score map.                                                        */
+ * d_score_map (optional) [B,H8,W8] (H8 = valid height rounded down to a multiple of 8) receives the NMS-ed score map.                                                        */
 int e2emv_superpoint_forward(e2emv_ctx* ctx, const e2emv_superpoint_desc* desc, const float* d_images, float* d_kpts,
                              float* d_scores, float* d_desc, int32_t* d_count, float* d_score_map, void* stream);
 

@@ -40,7 +40,10 @@ def test_matches_hf_golden(gpu):
             assert np.abs(de[:, :m].T - g[f"{tag}/descriptors"][b, :m]).max() < 1e-4
 
 
-@pytest.mark.parametrize("B,H,W,maxk,r,border", [(3, 120, 160, 256, 4, 4), (2, 64, 200, -1, 2, 8), (1, 480, 640, 1024, 4, 4)])
+# (the last three sizes are NOT multiples of 8 - MegaDepth-style resizes: upstream's convolutions see the whole image and its
+# pools floor; the library runs the encoder on the zero-padded grid with every level masked to its valid size)
+@pytest.mark.parametrize("B,H,W,maxk,r,border", [(3, 120, 160, 256, 4, 4), (2, 64, 200, -1, 2, 8), (1, 480, 640, 1024, 4, 4),
+                                                 (2, 123, 167, 256, 4, 4), (1, 486, 645, 1024, 4, 4), (2, 71, 97, -1, 3, 2)])
 def test_matches_oracle(gpu, B, H, W, maxk, r, border):
     img = _image(B, H, W, seed=H + W)
     sd = OS.seeded_state(0)
