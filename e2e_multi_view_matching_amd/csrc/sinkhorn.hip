@@ -568,7 +568,15 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 }
 
 // rows per workgroup: 8 waves x 4 rows up to 1024 columns, 8 x 2 rows up to 2048 (64 matrix values per lane either way)
-static inline int skr_rows(int64_t) { return 32; }
+// rows per workgroup: 8 waves x RW rows.  RW = 4 (64 matrix values per lane at 1024 columns, two workgroups per CU) or RW = 8 at
+// 1024 columns (128 values per lane, one workgroup per CU: the same number of resident problems, HALF as many workgroups in a
+// problem's exchange and half the granule traffic)
+static int g_skr_rw8 = -1;
+static inline int skr_rw(int64_t ldS) {
+    if (g_skr_rw8 < 0) g_skr_rw8 = dbg_knob("E2EMV_SKR_RW", 8) == 8 ? 1 : 0;
+    return (g_skr_rw8 && ldS > 512 && ldS <= 1024) ? 8 : 4;
+}
+static inline int skr_rows(int64_t ldS) { return 8 * skr_rw(ldS); }
 constexpr unsigned SKR_SPIN_LIMIT = 1u << 21;
 
 struct SkResParams {
@@ -684,10 +692,10 @@ __device__ __forceinline__ float exp_accurate(float x) {
     return __builtin_amdgcn_exp2f(y) * fmaf(r, 0.693147180559945f, 1.0f);
 }
 
-template <int KT, bool FULL, bool PAIR = false>
-__global__ __launch_bounds__(512, KT <= 4 ? 4 : 2) void sinkhorn_resident(SkResParams p) {
+template <int KT, bool FULL, bool PAIR = false, int RW = 4>
+__global__ __launch_bounds__(512, (KT <= 4 && RW == 4) ? 4 : 2) void sinkhorn_resident(SkResParams p) {
     constexpr int W = KT * 256;                       // padded column count held by a wave
-    constexpr int RW = 4;                             // rows per wave: 64 matrix values per lane (KT <= 4: two workgroups per
+    // RW rows per wave: 64 matrix values per lane at RW = 4 (KT <= 4: two workgroups per
                                                       // CU), 128 at KT = 8 (one per CU - half as many workgroups exchange)
     constexpr int ROWS = 8 * RW;                      // rows per workgroup
     constexpr int CPT = (W + 511) / 512;              // columns a thread folds / publishes
@@ -1181,7 +1189,10 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
             case 1: kfn = full ? (const void*)sinkhorn_resident<1, true> : (const void*)sinkhorn_resident<1, false>; break;
             case 2: kfn = full ? (const void*)sinkhorn_resident<2, true> : (const void*)sinkhorn_resident<2, false>; break;
             case 4:
-                if (pairs) kfn = full ? (const void*)sinkhorn_resident<4, true, true> : (const void*)sinkhorn_resident<4, false, true>;
+                if (skr_rw(ldS) == 8) {
+                    if (pairs) kfn = full ? (const void*)sinkhorn_resident<4, true, true, 8> : (const void*)sinkhorn_resident<4, false, true, 8>;
+                    else kfn = full ? (const void*)sinkhorn_resident<4, true, false, 8> : (const void*)sinkhorn_resident<4, false, false, 8>;
+                } else if (pairs) kfn = full ? (const void*)sinkhorn_resident<4, true, true> : (const void*)sinkhorn_resident<4, false, true>;
                 else kfn = full ? (const void*)sinkhorn_resident<4, true> : (const void*)sinkhorn_resident<4, false>;
                 break;
             default:
