@@ -579,18 +579,22 @@ def run(args):
             # profiles/README.md), not a byte rate; the arithmetic (one packed FMA per element per half-iteration) is the rest.
             ms_call = sk["ms"] / args.steps
             problems = B * P
-            resident = max(1, min(problems, (2 * 256) // max((N + 31) // 32, 1)))   # 2 workgroups / CU x 256 CUs, 32 rows each
+            rows_wg = 64 if 512 < N <= 1024 else 32                      # rows of a problem per workgroup (sinkhorn.hip: skr_rows)
+            wg_per_cu = 1 if (rows_wg == 64 or N > 1024) else 2
+            resident = max(1, min(problems, (wg_per_cu * 256) // max((N + rows_wg - 1) // rows_wg, 1)))
             rounds = -(-problems // resident)
-            hop_us = 2.75  # one problem alone on the chip: 5.5 us per iteration = 2 dependent exchanges (profiles/README.md)
+            hop_us = 0.8  # an idle one-to-one granule hand-off on this chip (MI355X_MICROARCH.md price list): the physical floor of a hop
             exch_ms = rounds * args.sinkhorn_iters * 2 * hop_us * 1e-3
             fma_ms = rounds * args.sinkhorn_iters * 2 * (resident * N * N / 2) / (256 * 64 * 2.0e9) * 1e3  # packed fp32 FMA: 2 elements / lane / clk
             physical = problems * 2 * N * N * 4 + problems * (N + 1) ** 2 * 4
             out["sinkhorn_bound"] = {"bound": "inter-workgroup exchange latency (resident kernel)", "ms_per_call": round(ms_call, 3),
                                      "iterations": args.sinkhorn_iters, "problems": problems, "resident_problems": resident, "rounds": rounds,
+                                     "us_per_iteration": round(ms_call * 1e3 / (rounds * max(args.sinkhorn_iters, 1)), 2),
                                      "exchange_floor_ms": round(exch_ms, 3), "arithmetic_floor_ms": round(fma_ms, 3),
                                      "frac": round((exch_ms + fma_ms) / ms_call, 4),
                                      "physical_hbm_gbs": round(physical / (ms_call * 1e-3) / 1e9, 1),
-                                     "note": "frac = (exchange floor + arithmetic floor) / measured; the SURVEY 8(d) byte model (2 sweeps of the "
+                                     "note": "frac = (2 idle granule hops of 0.8 us per iteration + packed-FMA time) / measured; one problem alone on "
+                                             "the chip runs 5.05 us per iteration (profiles/README.md); the SURVEY 8(d) byte model (2 sweeps of the "
                                              "couplings per iteration from HBM) does not describe a kernel that keeps them in registers"}
     for alt, alt_prof in alts:
         if alt_prof:
