@@ -25,7 +25,10 @@ def _stream_mode(on):
 @pytest.mark.parametrize("B,M,N,iters", [(2, 128, 128, 100), (1, 100, 77, 20), (2, 33, 250, 5), (3, 1024, 1024, 100),
                                          (1, 1, 1, 3), (2, 5, 1000, 10), (2, 1000, 5, 10), (1, 513, 511, 30), (40, 256, 256, 50),
                                          (70, 300, 260, 7), (2, 2048, 2048, 30), (1, 1500, 2000, 10), (6, 2048, 2048, 12),
-                                         (3, 1100, 1030, 25)])
+                                         (3, 1100, 1030, 25),
+                                         # 513 ... 1024 columns = the 64-row workgroups of round 3: ragged rows, odd column slices
+                                         # (no granule pairs), a partial last workgroup, many problems (several rounds)
+                                         (3, 700, 900, 20), (2, 1000, 777, 15), (2, 640, 1000, 10), (20, 1024, 1000, 6), (2, 65, 1024, 12)])
 def test_resident_vs_oracle_and_vs_the_streaming_chain(gpu, B, M, N, iters):
     import e2e_multi_view_matching_amd as E
     from oracle.sinkhorn import log_optimal_transport
