@@ -1,15 +1,16 @@
-// Training path, first slice (VERDICT r2 row g): the matcher forward with a tape and the backward of the match
-// loss, so that the reference's `run_matcher` -> `train_loss.backward()` (helpers.py:243-260, train.py:406-425, stage 1:
-// pose_loss = False) runs through this library.  Reference arithmetic: fp32 everywhere (the f32 kernels of the inference
-// path for the forward, train_kernels.h for the rest).
+// Training path (VERDICT r2 row g): the matcher forward with a tape and the backward of the match loss and of the
+// pose loss, so that the reference's `run_matcher` -> `train_loss.backward()` (helpers.py:243-260, train.py:406-425) runs
+// through this library in both training stages.  Reference arithmetic: fp32 everywhere (the f32 kernels of the inference path
+// for the forward, train_kernels.h for the rest).
 //
 // What is differentiated: keypoint encoder, the L x {q|k|v projection, attention, merge, MLP}, final_proj, the score
-// matrix, the dustbin score and the unrolled log-domain Sinkhorn (the reverse sweep walks the stored u_t, v_t of every
+// matrix, the dustbin score, the unrolled log-domain Sinkhorn (the reverse sweep walks the stored u_t, v_t of every
 // iteration - the same gradient torch.autograd computes through upstream's log_optimal_transport, not an implicit
-// differentiation).  BatchNorm layers normalise with their RUNNING statistics (frozen-statistics fine-tuning; the
+// differentiation) and the conf_mlp head (e2emv_conf_forward_train; the pose loss reaches it through pose.hip's
+// e2emv_w8pt_backward).  BatchNorm layers normalise with their RUNNING statistics (frozen-statistics fine-tuning; the
 // reference builds its DDP wrapper with broadcast_buffers=False "until BatchNorm stats are updated", train.py:351-356);
-// their affine parameters get gradients through the folded convolution.  Still forward-only: conf_mlp and the pose-loss
-// path (weighted 8-point), batch-statistics BatchNorm, ragged keypoint counts.
+// their affine parameters get gradients through the folded convolution.  Still forward-only: batch-statistics BatchNorm,
+// ragged keypoint counts, the confidences of a model without conf_mlp (the match score).
 //
 // The backward is a sequence of general fp32 MFMA GEMMs (dgrad: dY W, wgrad: dY^T X with the row contraction split over
 // workgroups) and row-wise kernels; the attention backward re-computes the probabilities from the saved q|k|v.

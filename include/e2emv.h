@@ -365,7 +365,7 @@ int e2emv_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, in
  * context runs the log-domain launch chain for every later call.  Host-synchronising. */
 int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset);
 
-/* ---- training, first slice: the matcher with a tape and the backward of the match loss ---------------------------------
+/* ---- training: the matcher with a tape, the backward of the match loss and (through the confidences) of the pose loss ------
  * Replaces, for stage-1 training (match loss only), what torch.autograd does under the reference's
  *   pred = run_matcher(...); train_loss.backward()        (/root/reference/helpers.py:243-260, train.py:406-425)
  * with the reference's own arithmetic (fp32).  Differentiated: keypoint encoder, every GNN layer (projections, attention,

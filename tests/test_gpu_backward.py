@@ -1,4 +1,4 @@
-"""Training path, first slice (-m gpu): parameter gradients of the match loss through MultiViewMatcher's HIP backward
+"""Training path (-m gpu): parameter gradients of the match loss and of the pose loss through MultiViewMatcher's HIP backward
 (csrc/train.hip behind torch.autograd) against torch.autograd over the CPU oracle (oracle.matcher with grad = True).
 
 Bar (VERDICT r2, row g): every parameter's gradient within 1e-3 relative (||g - g_ref|| / ||g_ref||), fp32 arithmetic,
