@@ -13,6 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def _env(**kw):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(kw)
@@ -80,7 +89,7 @@ def test_gpus_8_world_of_eight_ranks_over_gloo():
     """The driver's `bench.py --gpus 8` shape: eight ranks join one process group, every rank contributes its pairs and its
     clock, rank 0 prints one line with the whole-job aggregate (stub step - the launch, barriers and collectives are real)."""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "3"],
+                        "--master-port", str(_free_port()), BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "3"],
                        capture_output=True, text=True, timeout=900, env=_env(E2EMV_BENCH_STUB="1", OMP_NUM_THREADS="1"), cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -4,6 +4,7 @@ ranks share the GPU (E2EMV_BENCH_SHARE_GPU, metric collectives over gloo) - stil
 weights, workspace and streams, with the barrier / MAX-over-ranks / all-gather path around the real step."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -14,6 +15,14 @@ pytestmark = [pytest.mark.gpu]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def test_bench_two_ranks_real_kernels(gpu):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     extra = []
@@ -21,7 +30,7 @@ def test_bench_two_ranks_real_kernels(gpu):
         env["E2EMV_BENCH_SHARE_GPU"] = "1"
         extra = ["--backend", "gloo"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
            "--kpts", "512", "--cpu-pairs", "0", "--no-alt", "--no-latency"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
