@@ -503,7 +503,8 @@ def run(args):
         # the default arithmetic has no out-of-range fallback to take (tile exponents): `fallbacks` is 0 by
         # construction; rescaled_blocks = plane blocks outside the exponents' dead zone (0 for an ordinary network),
         # sinkhorn_reports = problems the exponential-domain Sinkhorn reported non-finite
-        out["range"] = {"fallbacks": st["sinkhorn_rescued"], "rescaled_blocks": st["rescaled_blocks"], "sinkhorn_reports": st["sinkhorn_bad"]}
+        out["range"] = {"fallbacks": st["sinkhorn_rescued"], "rescaled_blocks": st["rescaled_blocks"], "sinkhorn_reports": st["sinkhorn_bad"],
+                        "attention_slow_tiles": st.get("attention_slow_tiles", 0)}
     if bare is not None:
         out["ms_per_step_without_event_brackets"] = round(1000.0 * bare / args.steps, 3)
     if alts:
@@ -517,11 +518,12 @@ def run(args):
     def roofline_of(prof_, mode_):
         fl = algorithmic_flops(B, T, N, D, args.layers, True)
         fam = max(("gemm", "attention"), key=lambda k: prof_[k]["ms"])
-        gen3 = mode_ == "f16x2" and getattr(wl, "ctx", None) is not None and wl.ctx.f16x2_kernels == 3
+        gen = wl.ctx.f16x2_kernels if mode_ == "f16x2" and getattr(wl, "ctx", None) is not None else 0
+        gen3 = gen >= 3
         kname = {"f32": {"gemm": "gemm_nt_kernel", "attention": "attention_kernel"},
                  "bf16x3": {"gemm": "gemm_x3_kernel", "attention": "attention3f_kernel"},
                  "f16x2": {"gemm": "gemm_p2_kernel" if gen3 else "gemm_h2_kernel",
-                           "attention": "attention_p2_kernel" if gen3 else "attention_h2f_kernel"}}[mode_][fam]
+                           "attention": ("attention_p2w_kernel" if gen == 4 and N > 256 else "attention_p2_kernel") if gen3 else "attention_h2f_kernel"}}[mode_][fam]
         # f32 mode: exact fp32 MFMA.  bf16x3 mode: every algorithmic flop is 6 bf16-MFMA flops, so the ceiling for
         # ALGORITHMIC flops is the dense bf16 peak / 6.
         # f16x2 mode: 3 fp16-MFMA flops per algorithmic flop.

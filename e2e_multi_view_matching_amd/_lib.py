@@ -19,7 +19,7 @@ DESC_F32, DESC_F16 = 0, 1
 OK, EINVAL, ENOMEM, EHIP, ESHAPE, ESTATE = 0, -1, -2, -3, -4, -5
 PRECISION_F32, PRECISION_BF16X3, PRECISION_F16X2 = 0, 1, 2
 PRECISION_NAMES = {"f32": PRECISION_F32, "bf16x3": PRECISION_BF16X3, "f16x2": PRECISION_F16X2,
-                   "f16x2-r2": PRECISION_F16X2}  # "-r2": the same arithmetic on the round-2 kernels (fp32 activations)
+                   "f16x2-r2": PRECISION_F16X2, "f16x2-r3": PRECISION_F16X2}  # "-r2": the same arithmetic on the round-2 kernels (fp32 activations)
 
 c_void_p, c_int, c_float, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_char_p
 c_int64, c_size_t = ctypes.c_int64, ctypes.c_size_t
@@ -185,7 +185,7 @@ class Context:
         self.train_owner = None       # (module, fingerprint) whose weights e2emv_train_commit folded last
         self.train_generation = 0     # bumped by every forward_train: the context keeps the tape of the LAST one only
         self.default_precision = self.precision()  # E2EMV_PRECISION at creation time (else f32)
-        self.f16x2_kernels = 2 if os.environ.get("E2EMV_F16X2_KERNELS") == "r2" else 3
+        self.f16x2_kernels = {"r2": 2, "r3": 3}.get(os.environ.get("E2EMV_F16X2_KERNELS"), 4)
         self.default_f16x2_kernels = self.f16x2_kernels
         self.forced_precision = None               # set_precision(): explicit process-wide override for models with
         #                                            config["mfma_precision"] = None
@@ -203,19 +203,21 @@ class Context:
         self.forced_precision = precision
         self.call("e2emv_set_precision", self.default_precision if precision is None else precision)
 
-    def set_f16x2_kernels(self, generation=3):
-        """f16x2 implementation: 3 = plane activations (gemm_p2 / attention_p2, the default), 2 = the round-2 kernels
-        (fp32 activations split inside the consuming kernel)."""
+    def set_f16x2_kernels(self, generation=4):
+        """f16x2 implementation: 4 = plane activations (gemm_p2 / attention_p2w above 256 keys, the default), 3 = the same
+        with the round-3 attention (attention_p2), 2 = the round-2 kernels (fp32 activations split inside the consuming
+        kernel)."""
         self.call("e2emv_set_f16x2_kernels", int(generation))
         self.f16x2_kernels = int(generation)
 
     def stats(self, reset=False):
         """{'rescaled_blocks': plane blocks that needed a non-zero tile exponent, 'sinkhorn_bad': Sinkhorn problems with
         non-finite scores, 'sinkhorn_rescued': problems re-solved in the log domain behind the resident kernel (correct
-        outputs)} since the last reset (host-synchronising)."""
-        v = (ctypes.c_uint64 * 3)()
-        self.call("e2emv_get_stats", v, 3, 1 if reset else 0)
-        return {"rescaled_blocks": int(v[0]), "sinkhorn_bad": int(v[1]), "sinkhorn_rescued": int(v[2])}
+        outputs), 'attention_slow_tiles': (wave, stream, key tile) softmaxes attention_p2w redid on its slow path - a row
+        maximum outgrew the running one by more than ~2^9, or a ragged last tile} since the last reset (host-synchronising)."""
+        v = (ctypes.c_uint64 * 4)()
+        self.call("e2emv_get_stats", v, 4, 1 if reset else 0)
+        return {"rescaled_blocks": int(v[0]), "sinkhorn_bad": int(v[1]), "sinkhorn_rescued": int(v[2]), "attention_slow_tiles": int(v[3])}
 
     def set_split_min_rows(self, min_rows=-1):
         """Calls with fewer keypoint rows than this run the fp32-MFMA kernels even in a split-operand mode

@@ -13,7 +13,7 @@
 // every ds_read_b128 of a fragment conflict-free.  The output is written as scaled planes, the operand format of MLP0.
 #include <algorithm>
 
-#include "p2.h"
+#include "attention_p2.h"
 
 namespace e2emv {
 
@@ -24,18 +24,6 @@ constexpr int AP_TILEB = 64 * 256;       // one operand tile: 64 rows x 256 B
 constexpr int AP_BUFB = 2 * AP_TILEB;    // K | V^T
 constexpr float AP_SINV = 1.f / P2_QS, AP_PLOG = 10.f, AP_LAZY = 5.f;
 
-struct AttnP2Params {
-    const uint16_t* qk;   // [n_img*n_rows][2D] plain planes, q | k
-    const uint16_t* vt;   // [n_img][H][64][n_rows] plain planes
-    uint16_t* out;        // [n_img*n_rows][D] scaled planes
-    unsigned qk_bytes, vt_bytes;
-    const int* EQK;       // tile exponents (p2.h) of q | k [rows/64][8] and of V^T [rows/64][4] (by key rows); null = all zero
-    const int* EVt;
-    int* EO;              // exponents of the output [rows/64][4]; null = not wanted
-    int B, T, n_rows, D, H, cross;
-    int nv[E2EMV_MAX_TUPLE];
-    int nq, groups, gper;
-};
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_p2_kernel(AttnP2Params p) {
@@ -327,7 +315,10 @@ int launch_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, const int* nv,
     p.gper = (p.groups + 7) / 8;
     static int nw_knob = -1;
     if (nw_knob < 0) nw_knob = dbg_knob("E2EMV_AP2_NW", 0);
-    if (nw_knob == 4 || nw_knob == 8) ctx->attn_p2_nw = nw_knob;
+    if (nw_knob == 4 || nw_knob == 8 || nw_knob == 1) ctx->attn_p2_nw = nw_knob;
+    // above 256 keys: one wave per SIMD with the overlap of matrix and vector work written into the wave's instruction
+    // stream (attention_p2w.hip, attn_p2_nw == 1 forces it); below, and for A/B runs (4 / 8), the two-waves-per-SIMD kernel here
+    if (ctx->attn_p2_nw == 1 || (ctx->attn_p2_nw == 0 && ctx->attn_wide && n_valid > 256)) return launch_attention_p2w(ctx, p, n_valid, s);
     const int nw = ctx->attn_p2_nw == 4 || ctx->attn_p2_nw == 8 ? ctx->attn_p2_nw : (n_valid > 256 ? 8 : 4);  // measured: 222 / 224 us at 1024 keys, 202 / 209 at 2048
     const size_t lds = 2 * AP_BUFB;
     const void* fn = nw == 8 ? reinterpret_cast<const void*>(attention_p2_kernel<8>) : reinterpret_cast<const void*>(attention_p2_kernel<4>);

@@ -96,7 +96,9 @@ struct e2emv_ctx {
     int precision = 0;  // E2EMV_PRECISION_F32 | _BF16X3 | _F16X2 (dense GNN contractions)
     int64_t split_min_rows = -1;  // split-operand kernels from this many keypoint rows per call (-1: half a 128-row tile per CU)
     bool h2_legacy = false;  // f16x2 mode on the round-2 kernels (fp32 activations split inside gemm_h2 / attention_h2f): the A/B arm of the plane path
-    int attn_p2_nw = 0;      // attention_p2 workgroup size: 0 = by key count, 4 | 8 waves (micro-benchmarks)
+    bool attn_wide = true;   // f16x2 kernel generation 4 (default): attention_p2w above 256 keys; false = generation 3 (attention_p2 everywhere)
+    int attn_abl = 0;        // measurement build: ablation of attention_p2w's main loop
+    int attn_p2_nw = 0;      // attention on planes: 0 = by key count, 4 | 8 = attention_p2 with that many waves, 1 = attention_p2w (micro-benchmarks)
     bool b3_planes = false;  // bf16x3 mode: q|k|v handed to the attention as planes from the GEMM epilogue (E2EMV_B3_PLANES=1)
     // keypoint encoder: layer 0 (3->c0) used by the ingest kernel, the rest through the GEMM
     float* kenc_w0 = nullptr;  // [c0][3] folded
@@ -202,7 +204,8 @@ constexpr int dbg_knob(const char*, int dflt) { return dflt; }
 constexpr const char* dbg_env(const char*) { return nullptr; }
 #endif
 void train_free(e2emv_ctx* ctx);  // train.hip
-// ctx->d_flags (device words: [0] Sinkhorn give-up flag, [1] its sticky count, [2] plane blocks that needed a tile exponent)
+// ctx->d_flags (device words: [0] Sinkhorn give-up flag, [1] its sticky count, [2] plane blocks that needed a tile exponent,
+// [5] (wave, tile) softmaxes attention_p2w redid on its slow path)
 int ensure_flags(e2emv_ctx* ctx);
 // hipFuncAttributeMaxDynamicSharedMemorySize for kernels that use more than the default dynamic LDS: once per
 // (device, kernel), thread-safe (ctx.hip)

@@ -164,7 +164,10 @@ int e2emv_create(e2emv_ctx** out, int device) {
     ctx->num_cus = p.multiProcessorCount;
     if (dbg_knob("E2EMV_NO_FUSE_MERGE", 0) == 1) ctx->fuse_merge = false;
     if (dbg_knob("E2EMV_B3_PLANES", 0) == 1) ctx->b3_planes = true;
-    if (const char* e = getenv("E2EMV_F16X2_KERNELS")) ctx->h2_legacy = strcmp(e, "r2") == 0;  // round-2 f16x2 kernels (A/B measurements)
+    if (const char* e = getenv("E2EMV_F16X2_KERNELS")) {  // earlier kernel generations of the f16x2 mode (A/B measurements)
+        ctx->h2_legacy = strcmp(e, "r2") == 0;
+        ctx->attn_wide = strcmp(e, "r3") != 0;
+    }
     // default arithmetic of the dense GNN contractions: the split-operand fp16 x 2 path (22-bit operands, fp32 accumulate;
     // every parity test runs in all three modes at the same bar); E2EMV_PRECISION=bf16x3 selects the 24-bit bf16 x 3
     // split, =f32 the exact fp32-MFMA kernels
@@ -599,12 +602,12 @@ int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset) {
     E2EMV_LOCK(ctx);
     (void)hipSetDevice(ctx->device);
     E2EMV_HIP(ctx, hipDeviceSynchronize());
-    unsigned f[4] = {0, 0, 0, 0};
+    unsigned f[6] = {0, 0, 0, 0, 0, 0};
     if (ctx->d_flags) E2EMV_HIP(ctx, hipMemcpy(f, ctx->d_flags, sizeof(f), hipMemcpyDeviceToHost));
     ctx->stat_sinkhorn_bad += f[1];
     ctx->stat_sinkhorn_rescued += f[3];
-    const uint64_t v[3] = {(uint64_t)f[2], ctx->stat_sinkhorn_bad, ctx->stat_sinkhorn_rescued};
-    for (int i = 0; i < n; ++i) stats[i] = i < 3 ? v[i] : 0;
+    const uint64_t v[4] = {(uint64_t)f[2], ctx->stat_sinkhorn_bad, ctx->stat_sinkhorn_rescued, (uint64_t)f[5]};
+    for (int i = 0; i < n; ++i) stats[i] = i < 4 ? v[i] : 0;
     if (ctx->d_flags && (f[1] || f[3])) {  // the device counts moved into the host-side totals
         E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 1, 0, sizeof(unsigned)));
         E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 3, 0, sizeof(unsigned)));
@@ -615,6 +618,7 @@ int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset) {
         ctx->stat_sinkhorn_rescued = 0;
         ctx->sinkhorn_stream = false;  // (a reset also returns the Sinkhorn to the resident kernel)
         if (ctx->d_flags) E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 2, 0, sizeof(unsigned)));
+        if (ctx->d_flags) E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 5, 0, sizeof(unsigned)));
     }
     return E2EMV_OK;
 }
@@ -622,8 +626,9 @@ int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset) {
 int e2emv_set_f16x2_kernels(e2emv_ctx* ctx, int generation) {
     if (!ctx) return E2EMV_EINVAL;
     E2EMV_LOCK(ctx);
-    if (generation != 2 && generation != 3) return set_err(ctx, E2EMV_EINVAL, "f16x2 kernel generation %d (2 or 3)", generation);
+    if (generation < 2 || generation > 4) return set_err(ctx, E2EMV_EINVAL, "f16x2 kernel generation %d (2, 3 or 4)", generation);
     ctx->h2_legacy = generation == 2;
+    ctx->attn_wide = generation == 4;
     return E2EMV_OK;
 }
 

@@ -383,6 +383,9 @@ extern "C" int e2emv_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, int 
     const int save_nw = ctx->attn_p2_nw;
     if (flags & 2) ctx->attn_p2_nw = 4;
     if (flags & 4) ctx->attn_p2_nw = 8;
+    if (flags & 8) ctx->attn_p2_nw = 1;  // attention_p2w.hip
+    ctx->attn_abl = (flags >> 4) & 15;   // (bits 4..7: its ablations, measurement build only; 15 stands for 29)
+    if (ctx->attn_abl == 15) ctx->attn_abl = 29;
     const int reps = (flags >> 8) > 0 ? (flags >> 8) : 1;
     for (int i = 0; i < reps && !rc; ++i) {
         prof_begin(ctx, PS_ATTN, s);

@@ -270,7 +270,7 @@ class MultiViewMatcher(nn.Module):
             want = _lib.PRECISION_NAMES[mode]
         if ctx.precision() != want:
             ctx.call("e2emv_set_precision", want)
-        gen = 2 if mode == "f16x2-r2" else ctx.default_f16x2_kernels
+        gen = {"f16x2-r2": 2, "f16x2-r3": 3}.get(mode, ctx.default_f16x2_kernels)
         if ctx.f16x2_kernels != gen:
             ctx.set_f16x2_kernels(gen)
         kpts, scores, descs = [], [], []

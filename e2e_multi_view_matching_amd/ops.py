@@ -134,15 +134,15 @@ def qkv_p2(X, W, bias, n_rows, H=4):
     return out
 
 
-def attention_p2(qkv, B, T, n_valid, H, cross, waves=0, reps=1):
+def attention_p2(qkv, B, T, n_valid, H, cross, waves=0, reps=1, abl=0):
     """attention_p2.hip on an fp32 q|k|v matrix (split into the plane operands by a helper kernel); same contract as
-    `attention`.  waves: 0 = by key count, 4 / 8 = workgroup size."""
+    `attention`.  waves: 0 = by key count, 4 / 8 = attention_p2 with that workgroup size, 1 = attention_p2w (one wave per SIMD)."""
     ctx = _ctx(qkv)
     q = qkv.contiguous().float()
     n_img, n_rows, D3 = q.shape
     D = D3 // 3
     out = torch.empty((n_img, n_rows, D), dtype=torch.float32, device=q.device)
-    flags = (1 if cross else 0) | {0: 0, 4: 2, 8: 4}[waves] | (int(reps) << 8 if reps > 1 else 0)
+    flags = (1 if cross else 0) | {0: 0, 4: 2, 8: 4, 1: 8}[waves] | (int(reps) << 8 if reps > 1 else 0) | ((int(abl) & 15) << 4)
     with torch.cuda.device(q.device):
         ctx.call("e2emv_attention_p2", B, T, n_rows, n_valid, D, H, _lib.ptr(q), flags, _lib.ptr(out), _lib.stream_ptr(q.device))
     return out

@@ -334,9 +334,11 @@ int e2emv_attention_bf16x3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid
 /* ---- f16x2 on plane activations (the default implementation of E2EMV_PRECISION_F16X2) ---------------------------
  * Activations live in HBM as the two fp16 planes of the f16x2 arithmetic (4 bytes per element like fp32, 32-column
  * blocks of {hi, lo}); every producer splits its output once in its epilogue, consumers move the planes from global
- * memory straight into LDS.  generation 3 = these kernels (gemm_p2.hip, attention_p2.hip; needs descriptor_dim 256 /
- * 4 heads, other widths use generation 2), 2 = the round-2 kernels that keep fp32 activations and split them inside
- * the consuming GEMM / attention (kept as the A/B arm and for other widths).  Also E2EMV_F16X2_KERNELS=r2 at e2emv_create. */
+ * memory straight into LDS.  generation 4 (default) = these kernels (gemm_p2.hip; attention_p2w.hip - one wave per SIMD,
+ * matrix and softmax work interleaved inside the wave - above 256 keys, attention_p2.hip below; needs descriptor_dim 256 /
+ * 4 heads, other widths use generation 2), 3 = the same with the round-3 attention (attention_p2.hip everywhere), 2 = the
+ * round-2 kernels that keep fp32 activations and split them inside the consuming GEMM / attention (kept as A/B arms and
+ * for other widths).  Also E2EMV_F16X2_KERNELS=r2 | r3 at e2emv_create. */
 int e2emv_set_f16x2_kernels(e2emv_ctx* ctx, int generation);
 /* building blocks on fp32 buffers (conversion to / from planes done by helper kernels; for tests and micro-benchmarks):
  * C = act([A | A2] W^T + bias) (+ R); A [M,K1], A2 [M,K-K1] or NULL, W [N,K], R [M,N] or NULL.  flags: bit0 relu, bit1 the
@@ -349,7 +351,7 @@ int e2emv_gemm_p2(e2emv_ctx* ctx, int M, int Nout, int K, int K1, const float* d
  * matrix: d_X [n_img*n_rows, D], d_W [3D, D] head-major, d_qkv [n_img*n_rows, 3D]. */
 int e2emv_qkv_p2(e2emv_ctx* ctx, int n_img, int n_rows, int D, int H, const float* d_X, const float* d_W, const float* d_bias,
                  float* d_qkv, void* stream);
-/* same contract as e2emv_attention on the plane kernel; flags: bit0 cross, bit1 / bit2 force 4 / 8 waves per workgroup,
+/* same contract as e2emv_attention on the plane kernel; flags: bit0 cross, bit1 / bit2 force attention_p2 with 4 / 8 waves per workgroup, bit3 forces attention_p2w (one wave per SIMD),
  * bits 8.. = timed repetitions. */
 int e2emv_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv, int flags,
                        float* d_out, void* stream);
@@ -362,7 +364,8 @@ int e2emv_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, in
  * Sinkhorn problems the exponential-domain resident kernel could not finish (a scaling left fp32's range, or an
  * inter-workgroup wait gave up under contention) and the rescue pass behind it re-solved in the log domain inside the same
  * call: their outputs are correct, nothing is raised; once the host has seen such an event (here or in e2emv_sync) the
- * context runs the log-domain launch chain for every later call.  Host-synchronising. */
+ * context runs the log-domain launch chain for every later call; stats[3] = (wave, stream, 64-key tile) softmaxes that
+ * attention_p2w redid on its slow path (a performance counter: results are the same).  Host-synchronising. */
 int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset);
 
 /* ---- training: the matcher with a tape, the backward of the match loss and (through the confidences) of the pose loss ------

@@ -57,7 +57,7 @@ def _compare(out, ref, pairs):
         assert c.shape == cr.shape and float((c - cr).abs().max()) < TOL
 
 
-PRECISIONS = ["f32", "bf16x3", "f16x2", "f16x2-r2"]  # "-r2": the f16x2 arithmetic on the round-2 kernels
+PRECISIONS = ["f32", "bf16x3", "f16x2", "f16x2-r3", "f16x2-r2"]  # "-r2": the f16x2 arithmetic on the round-2 kernels
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

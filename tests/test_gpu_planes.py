@@ -104,8 +104,8 @@ def _attention_ref(qkv, B, T, n_valid, H, cross):
 
 
 @pytest.mark.parametrize("B,T,n_rows,n_valid,cross", [(2, 2, 128, 128, 0), (2, 2, 256, 200, 1), (1, 3, 256, 131, 1),
-                                                       (1, 2, 128, 5, 0), (1, 2, 512, 300, 0)])
-@pytest.mark.parametrize("waves", [4, 8])
+                                                       (1, 2, 128, 5, 0), (1, 2, 512, 300, 0), (1, 2, 512, 512, 1), (1, 4, 640, 577, 1)])
+@pytest.mark.parametrize("waves", [4, 8, 1])  # 1 = attention_p2w.hip (one wave per SIMD, 256 queries per workgroup)
 def test_attention_p2(gpu, B, T, n_rows, n_valid, cross, waves):
     import e2e_multi_view_matching_amd as E
     g = torch.Generator().manual_seed(n_valid)
@@ -118,18 +118,23 @@ def test_attention_p2(gpu, B, T, n_rows, n_valid, cross, waves):
     assert err < 2e-5 and err < 3 * err32 + 1e-6, (err, err32)
 
 
-def test_attention_p2_spiked_key_forces_rescale(gpu):
+@pytest.mark.parametrize("waves", [0, 1])
+def test_attention_p2_spiked_key_forces_rescale(gpu, waves):
+    """waves = 1 (attention_p2w): the spike sits in the FOURTH key tile of one query of each stream's block - the fast path's
+    sum check must send exactly those tiles through the slow path (true maximum, O and l rescaled)."""
     import e2e_multi_view_matching_amd as E
     g = torch.Generator().manual_seed(3)
     qkv = torch.randn(2, 256, 768, generator=g)
     qkv[0, 200, 256:512] = qkv[0, 17, 0:256] * 6.0  # key 200 aligned with query 17, all heads
+    qkv[1, 77, 256:512] = qkv[1, 40, 0:256] * 9.0   # key 77 (second tile) aligned with query 40 (second stream of its wave)
     ref = _attention_ref(qkv, 1, 2, 256, 4, 0)
-    out = E.attention_p2(qkv.to(gpu), 1, 2, 256, 4, 0).cpu()
+    out = E.attention_p2(qkv.to(gpu), 1, 2, 256, 4, 0, waves=waves).cpu()
     assert float((out.double() - ref).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("waves", [0, 1])
 @pytest.mark.parametrize("qs,ks,vs", [(1.0, 1.0, 1.0), (0.05, 0.05, 0.01), (6.0, 6.0, 300.0), (30.0, 0.2, 1e-3)])
-def test_attention_p2_over_operand_magnitudes(gpu, qs, ks, vs):
+def test_attention_p2_over_operand_magnitudes(gpu, qs, ks, vs, waves):
     import e2e_multi_view_matching_amd as E
     B, T, n_rows, n_valid, cross = 1, 2, 256, 256, 1
     g = torch.Generator().manual_seed(7)
@@ -138,14 +143,14 @@ def test_attention_p2_over_operand_magnitudes(gpu, qs, ks, vs):
     qkv[..., 256:512] *= ks
     qkv[..., 512:] *= vs
     ref = _attention_ref(qkv, B, T, n_valid, 4, cross)
-    out = E.attention_p2(qkv.to(gpu), B, T, n_valid, 4, cross).cpu()
+    out = E.attention_p2(qkv.to(gpu), B, T, n_valid, 4, cross, waves=waves).cpu()
     out32 = E.attention(qkv.to(gpu), B, T, n_valid, 4, cross).cpu()
     err = float((out.double() - ref).abs().max()) / vs
     err32 = float((out32.double() - ref).abs().max()) / vs
     assert err < 3 * err32 + 2e-6, (err, err32)
 
 
-@pytest.mark.parametrize("kernel", ["p2", "f16x2"])
+@pytest.mark.parametrize("kernel", ["p2", "p2w", "f16x2"])
 def test_attention_constant_v_exposes_operand_hazards(gpu, kernel):
     """V == 1 makes every output element exactly sum(p) / sum(p) = 1, whatever the keys: the two 32-dim halves of a head
     go through separate MFMA chains fed from the SAME softmax-numerator registers, so any difference between them is an
@@ -158,8 +163,8 @@ def test_attention_constant_v_exposes_operand_hazards(gpu, kernel):
         n_rows = 128 if n_valid <= 128 else 256
         qkv = torch.randn(2, n_rows, 768, generator=g) * 1.5
         qkv[..., 512:] = 1.0
-        if kernel == "p2":
-            out = E.attention_p2(qkv.to(gpu), 1, 2, n_valid, 4, 0).cpu()
+        if kernel in ("p2", "p2w"):
+            out = E.attention_p2(qkv.to(gpu), 1, 2, n_valid, 4, 0, waves=1 if kernel == "p2w" else 0).cpu()
         else:
             out = E.attention_bf16x3(qkv.to(gpu), 1, 2, n_valid, 4, 0, kernel="f16x2").cpu()
         err = (out[:, :n_valid] - 1.0).abs().view(2, n_valid, 4, 64)
@@ -203,8 +208,9 @@ def test_gemm_p2_tile_exponents_carry_fp32_range(gpu, choices):
         assert e < bar, (choices, relu, planes_out, e)
 
 
+@pytest.mark.parametrize("waves", [0, 1])
 @pytest.mark.parametrize("qs,ks,vs", [(1.0, 1.0, 1.0), (300.0, 1.0, 1e6), (1e-3, 2e3, 1e-7), (1e4, 1e-4, 3e9), (50.0, 50.0, 7e4)])
-def test_attention_p2_tile_exponents_carry_fp32_range(gpu, qs, ks, vs):
+def test_attention_p2_tile_exponents_carry_fp32_range(gpu, qs, ks, vs, waves):
     """q, k, v magnitudes beyond the old limits of the mode (|q| < 5.6e3, |v| < 4e3): exponents in the logit scale and in
     the O accumulator; peaked and flat softmaxes."""
     import e2e_multi_view_matching_amd as E
@@ -216,7 +222,7 @@ def test_attention_p2_tile_exponents_carry_fp32_range(gpu, qs, ks, vs):
     qkv[..., 512:] *= vs
     qkv[0, 64:128, 512:] *= 1e-3  # one key block of one image three decades below the others: the O accumulator is rescaled
     ref = _attention_ref(qkv, B, T, n_valid, 4, cross)
-    out = E.attention_p2(qkv.to(gpu), B, T, n_valid, 4, cross).cpu()
+    out = E.attention_p2(qkv.to(gpu), B, T, n_valid, 4, cross, waves=waves).cpu()
     out32 = E.attention(qkv.to(gpu), B, T, n_valid, 4, cross).cpu()
     assert torch.isfinite(out[:, :n_valid]).all()
     err = float((out[:, :n_valid].double() - ref[:, :n_valid]).abs().max()) / vs

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One parameterised GPU-box script (run through gpurun): tools/gpu.sh <stage> [...]; output under gpurun_out/r3/.
+# One parameterised GPU-box script (run through gpurun): tools/gpu.sh <stage> [...]; output under gpurun_out/r4/.
 #   planes   per-kernel parity of the plane kernels + matcher parity + micro-benchmarks + bench A/B (plane vs round-2 kernels)
 #   tests    the whole -m gpu suite
 #   bench    bench.py lines (c2 default, c4, c5)
@@ -7,7 +7,7 @@
 #   kt       rocprofv3 kernel trace of one config / mode
 #   prof     rocprofv3 kernel trace + the three PMC passes of config c2
 cd "$GRAFT_REPO_ROOT" || exit 1
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r3
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r4
 mkdir -p $OUT
 export TMPDIR=/tmp
 stage=${1:-tests}
@@ -32,6 +32,45 @@ planes)
   timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_p2.json 2> $OUT/bench_p2.err
   E2EMV_F16X2_KERNELS=r2 timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_r2k.json 2> $OUT/bench_r2k.err
   show $OUT/bench_p2.json $OUT/bench_r2k.json
+  ;;
+aw)
+  # attention_p2w: parity of the attention kernels on planes, micro-benchmark against attention_p2, one bench line per kernel
+  timeout 900 python -m pytest tests/test_gpu_planes.py -x -q -k attention 2>&1 | tail -15 | tee $OUT/aw_tests.log
+  timeout 600 python tools/microbench.py --what ap2 2>&1 | tee $OUT/microbench_ap2.log
+  timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_aw.json 2> $OUT/bench_aw.err
+  E2EMV_F16X2_KERNELS=r3 timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_ap8.json 2> $OUT/bench_ap8.err
+  show $OUT/bench_aw.json $OUT/bench_ap8.json
+  ;;
+awabl)
+  # attention_p2w ablations (measurement build) + a PMC pass over attention_p2w and attention_p2
+  timeout 600 python tools/aw_ablate.py 2>&1 | grep -v amdgpu.ids | tee $OUT/aw_ablate.log
+  (cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d /tmp/aw_pmc -- python $GRAFT_REPO_ROOT/tools/aw_ablate.py --pmc > $OUT/aw_pmc.log 2>&1)
+  f=$(find /tmp/aw_pmc -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && python - "$f" <<'PY' | tee $OUT/aw_pmc_summary.txt
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for r in rows:
+    k = r['Kernel_Name'][:60]
+    if 'attention_p2' not in k: continue
+    acc[k][r['Counter_Name']] += float(r['Counter_Value']); 
+for k, d in acc.items():
+    print(k); [print('   ', c, f'{v:.4g}') for c, v in sorted(d.items())]
+PY
+  (cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/aw_pmc2 -- python $GRAFT_REPO_ROOT/tools/aw_ablate.py --pmc >> $OUT/aw_pmc.log 2>&1)
+  f=$(find /tmp/aw_pmc2 -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && python - "$f" <<'PY' | tee -a $OUT/aw_pmc_summary.txt
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in rows:
+    k = r['Kernel_Name'][:60]
+    if 'attention_p2' not in k: continue
+    acc[k][r['Counter_Name']] += float(r['Counter_Value'])
+for k, d in acc.items():
+    print(k); [print('   ', c, f'{v:.4g}') for c, v in sorted(d.items())]
+PY
+  tail -5 $OUT/aw_pmc.log
   ;;
 stamps)
   timeout 900 python tools/p2_stamps.py 2>&1 | tee $OUT/p2_stamps.log
@@ -61,16 +100,16 @@ kt)
   args="--config $cfg --precision $mode --steps 2 --warmup 1 --cpu-pairs 0 --no-alt --no-latency --no-profile"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_${cfg}_${mode} -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_${cfg}_${mode}.log 2>&1)
   db=$(find /tmp/kt_${cfg}_${mode} -name '*.db' | head -1)
-  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r3_kernel_stats_${cfg}_${mode}.md 2>&1
-  head -40 $OUT/r3_kernel_stats_${cfg}_${mode}.md
+  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r4_kernel_stats_${cfg}_${mode}.md 2>&1
+  head -40 $OUT/r4_kernel_stats_${cfg}_${mode}.md
   ;;
 prof)
   cfg=${2:-c2}; mode=${3:-f16x2}
   args="--config $cfg --precision $mode --steps 2 --warmup 1 --cpu-pairs 0 --no-alt --no-latency --no-profile"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_${cfg}_${mode} -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_${cfg}_${mode}.log 2>&1)
   db=$(find /tmp/kt_${cfg}_${mode} -name '*.db' | head -1)
-  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r3_kernel_stats_${cfg}_${mode}.md 2>&1
-  head -30 $OUT/r3_kernel_stats_${cfg}_${mode}.md
+  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r4_kernel_stats_${cfg}_${mode}.md 2>&1
+  head -30 $OUT/r4_kernel_stats_${cfg}_${mode}.md
   i=0
   for ctr in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
     (cd /tmp && timeout 400 rocprofv3 --pmc $ctr -d /tmp/pmc_${cfg}_${mode}_$i -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/pmc_${cfg}_${mode}_$i.log 2>&1)
@@ -79,8 +118,8 @@ prof)
   d0=$(find /tmp/pmc_${cfg}_${mode}_0 -name '*.db' | head -1); d1=$(find /tmp/pmc_${cfg}_${mode}_1 -name '*.db' | head -1); d2=$(find /tmp/pmc_${cfg}_${mode}_2 -name '*.db' | head -1)
   cp profiles/pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null
   pairs=32; kpts=1024; [ "$cfg" = c4 ] && pairs=80; [ "$cfg" = c5 ] && { pairs=80; kpts=2048; }
-  python profiles/summarize_pmc.py "$d0" "$d1" "$d2" $OUT/r3_pmc_${cfg}_${mode}.md $OUT/pmc_traffic.json $cfg $mode $pairs $kpts > /dev/null 2> $OUT/pmc_${cfg}_${mode}_summ.err
-  head -12 $OUT/r3_pmc_${cfg}_${mode}.md
+  python profiles/summarize_pmc.py "$d0" "$d1" "$d2" $OUT/r4_pmc_${cfg}_${mode}.md $OUT/pmc_traffic.json $cfg $mode $pairs $kpts > /dev/null 2> $OUT/pmc_${cfg}_${mode}_summ.err
+  head -12 $OUT/r4_pmc_${cfg}_${mode}.md
   ;;
 *) echo "unknown stage $stage"; exit 2;;
 esac

@@ -116,6 +116,32 @@ def main():
                     ms = family(lambda n: E.attention_p2(qkv, B, 2, N, 4, cross, waves=waves, reps=n), "attention", 5)
                     line += f" p2/{waves}w {ms * 1e3:7.1f} us {fl / ms / 1e9:6.1f} TF |"
                 print(line)
+    if "ap2" in args.what:
+        print("== attention on planes: attention_p2 (8 waves, 2 per SIMD) vs attention_p2w (4 waves, 1 per SIMD) -> us, TFLOP/s fp32-equivalent; max |diff|")
+        from e2e_multi_view_matching_amd import _lib
+        ctx = _lib.context(dev)
+
+        def fam(fn, n=10):
+            for _ in range(2):
+                fn(1)
+            ctx.call("e2emv_profile", 1)
+            _lib.profile_read(ctx, reset=True)
+            fn(n)
+            pr = _lib.profile_read(ctx, reset=True)["attention"]
+            ctx.call("e2emv_profile", 0)
+            return pr["ms"] / max(pr["launches"], 1)
+        for (B, T, N, nv) in [(32, 2, 1024, 1024), (8, 5, 1024, 1024), (8, 5, 2048, 2048), (32, 2, 1024, 1000), (32, 2, 512, 512)]:
+            qkv = torch.randn(B * T, N, 768, device=dev) * 1.5
+            for cross in (0, 1):
+                fl = B * T * 4.0 * nv * nv * (T - 1 if cross else 1) * 256
+                line = f"  B={B:3d} T={T} N={N:5d} valid={nv:5d} cross={cross} |"
+                outs = {}
+                for waves in (8, 1):
+                    ms = fam(lambda n: E.attention_p2(qkv, B, T, nv, 4, cross, waves=waves, reps=n))
+                    outs[waves] = E.attention_p2(qkv, B, T, nv, 4, cross, waves=waves)
+                    line += f" {'p2w' if waves == 1 else 'p2/8'} {ms * 1e3:7.1f} us {fl / ms / 1e9:6.1f} TF |"
+                d = float((outs[8][:, :nv] - outs[1][:, :nv]).abs().max())
+                print(line + f" max|diff| {d:.2e}")
     if "attn" in args.what:
         print("== attention (B pairs, N) -> us, TFLOP/s")
         for (B, N) in [(32, 1024), (8, 1024), (32, 512), (8, 2048)]:
