@@ -72,6 +72,9 @@ def parse_args(argv=None):
                     "pipeline = SuperPoint on tuple_size*batch 480x640 images -> matcher -> w8pt per step")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra measurement in the other arithmetic mode")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement (eval_pairs.py's loop shape)")
+    ap.add_argument("--baseline-1gpu", type=float, default=None, help="the `value` of the --gpus 1 run of the same config on "
+                    "this node: rank 0 then adds scaling_check = {efficiency = value / (n_gpus x it)} to its line (the driver "
+                    "computes its own from the per-N lines; this is for a manual 1/2/4/8 sweep)")
     ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; the CPU test uses gloo)")
     args = ap.parse_args(argv)
     preset = CONFIGS[args.config]
@@ -138,6 +141,25 @@ def algorithmic_flops(B, T, N, D, layers, conf_mlp):
 
 
 # ----------------------------------------------------------------------------------------- workloads
+def pin_cpus(local_rank, local_world):
+    """Per-rank CPU affinity: the host cores this process may use are cut into `local_world` contiguous slices (a contiguous
+    slice of the id space stays inside one socket / NUMA node on the two-socket hosts these boxes are) and the rank keeps slice
+    LOCAL_RANK - launch threads of 8 ranks then do not migrate across sockets.  E2EMV_BENCH_NO_PIN=1 turns it off; a host
+    without sched_setaffinity is left alone.  Returns the cpu set (for the log)."""
+    if local_world <= 1 or os.environ.get("E2EMV_BENCH_NO_PIN") or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // local_world
+        if per < 1:
+            return None
+        mine = set(cpus[local_rank * per:(local_rank + 1) * per])
+        os.sched_setaffinity(0, mine)
+        return mine
+    except OSError:
+        return None
+
+
 class HipWorkload:
     """The product path on this rank's GPU."""
 
@@ -146,9 +168,18 @@ class HipWorkload:
         assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
         # E2EMV_BENCH_SHARE_GPU=1 (tests only, never a reported number): ranks beyond the box's GPUs share them round-robin,
         # each with its own process and library context, so the N > 1 branch runs the real kernels on a 1-GPU box
+        n_dev = torch.cuda.device_count()
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
         if os.environ.get("E2EMV_BENCH_SHARE_GPU"):
-            local_rank %= torch.cuda.device_count()
+            local_rank %= n_dev
+        else:
+            # one process per GPU, rank -> device by LOCAL_RANK among the devices this process can see (whatever
+            # HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES left visible): fail here, with the numbers, not inside RCCL
+            assert n_dev >= local_world and local_rank < n_dev, (
+                f"bench.py: rank with LOCAL_RANK={local_rank} of {local_world} local ranks sees {n_dev} GPU(s) "
+                f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r}): one GPU per local rank is needed")
         torch.cuda.set_device(local_rank)
+        pin_cpus(local_rank, local_world)
         self.torch = torch
         self.dev = self.coll_dev = torch.device("cuda", local_rank)
         self.args = args
@@ -196,6 +227,7 @@ class HipWorkload:
                     Tr, vb = E.run_bundle_adjust_2_view(info["kpts0_norm"], info["kpts1_norm"], c, Tp, n_iterations=10)
                     Tp[vb] = Tr
                 errs.append(E.pose_errors(Tp, d[f"T_{i}to{j}"]))
+        self.last_poses = poses
         return res, errs
 
     def sync(self):
@@ -209,6 +241,7 @@ class HipWorkload:
         from e2e_multi_view_matching_amd.metrics import pair_errors_deg
         _, errs = self.step(self.model_id)
         self.id_errs = errs
+        self.id_T = [self.last_poses[p][0].detach().cpu() for p in self.pairs]  # the poses themselves (AUC parity sample)
         return np.concatenate([pair_errors_deg(r.cpu().numpy(), t.cpu().numpy()) for r, t in errs])
 
 
@@ -220,6 +253,7 @@ class StubWorkload:
     def __init__(self, args, rank, local_rank):
         self.args, self.rank, self.dev, self.coll_dev = args, rank, None, None
         self.pairs = [(i, j) for j in range(args.tuple_size) for i in range(j)]
+        self.cpus = pin_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
 
     def setup(self, rank):
         self.default_precision = 0
@@ -505,6 +539,10 @@ def run(args):
         # sinkhorn_reports = problems the exponential-domain Sinkhorn reported non-finite
         out["range"] = {"fallbacks": st["sinkhorn_rescued"], "rescaled_blocks": st["rescaled_blocks"], "sinkhorn_reports": st["sinkhorn_bad"],
                         "attention_slow_tiles": st.get("attention_slow_tiles", 0)}
+    if args.baseline_1gpu:
+        out["scaling_check"] = {"baseline_1gpu_value": args.baseline_1gpu, "ideal_value": round(world * args.baseline_1gpu, 2),
+                                "efficiency": round(value / (world * args.baseline_1gpu), 4),
+                                "note": "weak scaling: tuples are sharded, no data-path collective; the metric all-gather is outside the timed steps"}
     if bare is not None:
         out["ms_per_step_without_event_brackets"] = round(1000.0 * bare / args.steps, 3)
     if alts:
@@ -536,25 +574,45 @@ def run(args):
         achieved, ms, n = family(fam)
         # HBM bytes per launch of that kernel from the rocprofv3 --pmc passes of this same command (FETCH_SIZE x 2 per
         # MI355X_MICROARCH.md, calibrated on a kernel with a known byte count) - profiles/summarize_pmc.py
-        traffic = None
+        # ... and only while csrc/ still hashes to what those passes ran on (otherwise null: a stale counter is not a measurement)
+        traffic, traffic_src = None, "no PMC pass on record for this workload / mode (tools/gpu.sh prof)"
         try:
+            from e2e_multi_view_matching_amd.build import _stamp
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 pj = json.load(fh)
-            k = pj["workloads"][args.config][mode_]["kernels"][kname]
-            traffic = int(k["read_bytes"] + k["write_bytes"])
+            w_ = pj["workloads"][args.config][mode_]
+            k = w_["kernels"][kname]
+            if w_.get("csrc_stamp") and w_["csrc_stamp"] == _stamp():
+                traffic = int(k["read_bytes"] + k["write_bytes"])
+                traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command (tools/gpu.sh prof) on these very sources "
+                               f"(csrc stamp {w_['csrc_stamp'][:12]}), not measured in this run")
+            else:
+                traffic_src = ("profiles/pmc_traffic.json holds counters of OTHER sources (csrc stamp "
+                               f"{str(w_.get('csrc_stamp'))[:12]} != {_stamp()[:12]}): not reported; re-run tools/gpu.sh prof")
         except Exception:
-            traffic = None
+            pass
         # compulsory HBM bytes of the family per step (activations are 4 bytes per element in every mode: fp32, or a pair of
         # fp16 planes; the weights stay in L2): the floor the operand / result stream sets next to the matrix-core ceiling
         Mt, L = B * T * N, len(args.layers)
         hbm = {"gemm": L * Mt * D * 4 * (1 + 3 + 2 + 2 + 2 + 1 + 1), "attention": L * Mt * D * 4 * (3 + 1)}[fam]
         floor_ms = hbm / (PEAK_HBM_GBS * 1e9) * 1e3
-        main = {"bound": "mfma", "kernel": kname, "mode": mode_,
-                "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic,
-                "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command (tools/gpu.sh prof), not measured in this run",
-                "limiter": ("the matrix-core ceiling is the stated peak; what the kernel actually waits for is its operand / result stream "
-                            "(LDS fill from L2 and the synchronized epilogue store burst, DESIGN.md 4d) - see hbm_floor"),
+        # Which roof binds: the layer GEMMs of the split-operand modes sit BELOW the ridge (f16x2: 84 flop per compulsory byte
+        # against 833 TFLOP/s / 6.3 TB/s = 132) - their bound is HBM, and the matrix-core fraction rides along as `mfma`;
+        # attention (and the fp32-MFMA GEMMs, 16x slower matrix pipe) are matrix-core bound.
+        hbm_bound = fam == "gemm" and mode_ != "f32"
+        gbs = hbm / (ms / args.steps * 1e-3) / 1e9
+        common = {"kernel": kname, "mode": mode_, "traffic": traffic, "traffic_source": traffic_src}
+        if hbm_bound:
+            main = dict(common, bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                        frac_of_achievable=round(gbs / 6290.0, 4),
+                        mfma={"achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4)})
+        else:
+            main = dict(common, bound="mfma", achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(achieved / peak, 4))
+        main.update({
+                "limiter": ("compulsory HBM bytes of the family (activations in and out once, weights from L2) / HIP-event time against the 8 TB/s "
+                            "spec peak (6.29 TB/s measured copy rate: frac_of_achievable); a launch is 1 - 3 output tiles per workgroup, so the "
+                            "operand stream and the epilogue store burst alternate instead of overlapping (DESIGN.md 4d)") if hbm_bound else
+                           ("the matrix-core ceiling is the stated peak; see DESIGN.md 4d / 4f for what the kernel spends beside it"),
                 "hbm_floor": {"bytes_per_step": int(hbm), "bytes_per_launch": int(hbm // max(n // args.steps, 1)),
                               "ms_per_step_at_peak_hbm": round(floor_ms, 3), "peak_gbs": PEAK_HBM_GBS,
                               "frac_of_family_time": round(floor_ms / (ms / args.steps), 4),
@@ -563,7 +621,7 @@ def run(args):
                          ("exact fp32 MFMA (v_mfma_f32_32x32x2_f32)" if mode_ == "f32" else
                           f"peak = dense 16-bit MFMA 2500 TFLOP/s / {products} MFMA products per algorithmic flop (split operands)")) +
                         "; traffic = HBM bytes per launch (read + write) from the PMC passes under profiles/",
-                "avg_launch_ms": round(ms / max(n, 1), 4), "launches_per_step": n // args.steps}
+                "avg_launch_ms": round(ms / max(n, 1), 4), "launches_per_step": n // args.steps})
         fam2 = "attention" if fam == "gemm" else "gemm"
         a2, _, _ = family(fam2)
         second = {"kernel": fam2, "achieved": round(a2, 2), "unit": "TFLOP/s", "frac": round(a2 / peak, 4)}
@@ -615,17 +673,39 @@ def run(args):
         sd_id = {k: v.detach().cpu() for k, v in wl.model_id.state_dict().items()}
         with torch.no_grad():
             ref = matcher_forward(small, sd_id, {**wl.cfg, "full_output": True})
-            eo = []
-            for (i, j) in wl.pairs:
+            eo, eo64, eh64, dT = [], [], [], 0.0
+
+            def angles64(Tp, Tg):
+                """compute_pose_error.py:3-22 as a function of the pose alone, in fp64: the reference's fp32 arccos resolves a
+                sub-degree angle to a few per cent (d arccos = -1 / sqrt(1 - cos^2)) on EITHER implementation, so the fp32 angle legs
+                differ by more than the poses do; the parity statement is about the poses."""
+                Tp, Tg = Tp.double().numpy(), Tg.double().numpy()
+                R = np.einsum("bji,bjk->bik", Tp[:, :3, :3], Tg[:, :3, :3])
+                rot = np.abs(np.arccos(np.clip((np.trace(R, axis1=1, axis2=2) - 1.0) / 2.0, -1.0, 1.0)))
+                t0, t1 = Tp[:, :3, 3], Tg[:, :3, 3]
+                n = np.linalg.norm(t0, axis=1) * np.linalg.norm(t1, axis=1)
+                tr = np.where(n > 1e-6, np.abs(np.arccos(np.clip((t0 * t1).sum(1) / np.where(n > 1e-6, n, 1.0), -1.0, 1.0))), 0.0)
+                return pair_errors_deg(rot, tr)
+            for q, (i, j) in enumerate(wl.pairs):
                 Tr, _ = OW.run_weighted_8_point(small, ref, i, j)
                 r = OW.compute_rotation_error(Tr, small[f"T_{i}to{j}"], reduce=False)
                 t = OW.compute_translation_error_as_angle(Tr, small[f"T_{i}to{j}"], keep_shape=True)
                 eo.append(pair_errors_deg(r.numpy(), t.numpy()))
-        eo = np.concatenate(eo)
+                Th = wl.id_T[q][:nb]
+                eo64.append(angles64(Tr, small[f"T_{i}to{j}"]))
+                eh64.append(angles64(Th, small[f"T_{i}to{j}"]))
+                dT = max(dT, float((Th - Tr).abs().max()))
+        eo, eo64, eh64 = np.concatenate(eo), np.concatenate(eo64), np.concatenate(eh64)
         eh = np.concatenate([pair_errors_deg(r.cpu().numpy()[:nb], t.cpu().numpy()[:nb]) for r, t in wl.id_errs])
-        out["auc_parity_sample"] = {"pairs": int(nb * P), "hip": [round(100 * a, 3) for a in pose_auc(eh, [5, 10, 20])],
-                                    "oracle": [round(100 * a, 3) for a in pose_auc(eo, [5, 10, 20])],
-                                    "max_abs_err_deg_diff": float(np.max(np.abs(eh - eo)))}
+        out["auc_parity_sample"] = {"pairs": int(nb * P),
+                                    "hip": [round(100 * a, 2) for a in pose_auc(eh64, [5, 10, 20])],
+                                    "oracle": [round(100 * a, 2) for a in pose_auc(eo64, [5, 10, 20])],
+                                    "max_abs_dT": dT, "max_abs_err_deg_diff": float(np.max(np.abs(eh64 - eo64))),
+                                    "angle_arithmetic": "fp64 from the fp32 poses of either side (|dT| is the only difference; bar 1e-4)",
+                                    "fp32_angle_legs": {"hip": [round(100 * a, 3) for a in pose_auc(eh, [5, 10, 20])],
+                                                        "oracle": [round(100 * a, 3) for a in pose_auc(eo, [5, 10, 20])],
+                                                        "max_abs_err_deg_diff": float(np.max(np.abs(eh - eo))),
+                                                        "note": "the reference's own fp32 arccos on each side: ill-conditioned below a degree"}}
     if dist is not None:
         dist.destroy_process_group()
         # RCCL writes its version banner through C stdio: flush it now so that the JSON line below is the LAST line

@@ -5,7 +5,7 @@ Python surface (mirrors the reference's callables):
   normalize, compute_rotation_error, compute_translation_error_as_angle, pose_auc.
 Everything computes in libe2emv.so (hand-written HIP for gfx950) through ctypes.
 """
-from .matcher import MultiViewMatcher, SuperGlue  # noqa: F401
+from .matcher import MultiViewMatcher, SuperGlue, last_descriptors  # noqa: F401
 from .metrics import compute_pose_error, pose_auc  # noqa: F401
 from .ops import (attention, attention_bf16x3, attention_p2, extract_matches, gemm_bf16x3, gemm_nt, gemm_p2,  # noqa: F401
                   log_optimal_transport, qkv_p2)

@@ -58,6 +58,7 @@ SIGNATURES = {
     "e2emv_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "e2emv_d2h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "e2emv_sync": (c_int, [c_void_p, c_void_p]),
+    "e2emv_get_descriptors": (c_int, [c_void_p, c_void_p, c_int64, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p]),
     "e2emv_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, ctypes.POINTER(c_int64), c_int]),
     "e2emv_commit_weights": (c_int, [c_void_p, ctypes.POINTER(ModelDesc)]),
     "e2emv_matcher_forward": (c_int, [c_void_p, ctypes.POINTER(ForwardDesc), _PP, _PP, _PP, _PP, _PP, _PP, _PP, _PP, _PP,
@@ -177,6 +178,7 @@ class Context:
         # `sp_weights_owner` name the module instance + parameter fingerprint they currently hold, so that two models
         # alternating on one device (checkpoint comparison, EMA copy) re-push instead of running on each other's weights.
         self.weights_owner = None
+        self.sent_owner = None        # (module, fingerprint) whose tensors e2emv_set_weight handed over last
         self.sp_weights_owner = None
         # held across "push my weights -> select my arithmetic -> enqueue my forward": two threads running two models on
         # one device cannot interleave so that one runs on the other's committed weights (the C-side mutex serialises
@@ -186,7 +188,7 @@ class Context:
         self.train_generation = 0     # bumped by every forward_train: the context keeps the tape of the LAST one only
         self.default_precision = self.precision()  # E2EMV_PRECISION at creation time (else f32)
         self.f16x2_kernels = {"r2": 2, "r3": 3}.get(os.environ.get("E2EMV_F16X2_KERNELS"), 4)
-        self.default_f16x2_kernels = self.f16x2_kernels
+        self.default_f16x2_kernels = self._env_f16x2_kernels = self.f16x2_kernels
         self.forced_precision = None               # set_precision(): explicit process-wide override for models with
         #                                            config["mfma_precision"] = None
 
@@ -210,14 +212,21 @@ class Context:
         self.call("e2emv_set_f16x2_kernels", int(generation))
         self.f16x2_kernels = int(generation)
 
+    def select_f16x2_kernels(self, generation=None):
+        """The generation every model on this device runs from now on (forward() re-selects `default_f16x2_kernels` on each
+        call, so `set_f16x2_kernels` alone lasts one call).  None = back to what E2EMV_F16X2_KERNELS chose at creation."""
+        self.default_f16x2_kernels = self._env_f16x2_kernels if generation is None else int(generation)
+        self.set_f16x2_kernels(self.default_f16x2_kernels)
+
     def stats(self, reset=False):
         """{'rescaled_blocks': plane blocks that needed a non-zero tile exponent, 'sinkhorn_bad': Sinkhorn problems with
         non-finite scores, 'sinkhorn_rescued': problems re-solved in the log domain behind the resident kernel (correct
         outputs), 'attention_slow_tiles': (wave, stream, key tile) softmaxes attention_p2w redid on its slow path - a row
         maximum outgrew the running one by more than ~2^9, or a ragged last tile} since the last reset (host-synchronising)."""
-        v = (ctypes.c_uint64 * 4)()
-        self.call("e2emv_get_stats", v, 4, 1 if reset else 0)
-        return {"rescaled_blocks": int(v[0]), "sinkhorn_bad": int(v[1]), "sinkhorn_rescued": int(v[2]), "attention_slow_tiles": int(v[3])}
+        v = (ctypes.c_uint64 * 5)()
+        self.call("e2emv_get_stats", v, 5, 1 if reset else 0)
+        return {"rescaled_blocks": int(v[0]), "sinkhorn_bad": int(v[1]), "sinkhorn_rescued": int(v[2]), "attention_slow_tiles": int(v[3]),
+                "sinkhorn_timeouts": int(v[4])}  # (of the rescued: given up on a wait - contention -, not on range)
 
     def set_split_min_rows(self, min_rows=-1):
         """Calls with fewer keypoint rows than this run the fp32-MFMA kernels even in a split-operand mode

@@ -132,6 +132,9 @@ struct e2emv_ctx {
     unsigned* d_flags = nullptr;
     uint64_t stat_sinkhorn_bad = 0;      // Sinkhorn problems with non-finite scores so far (e2emv_get_stats)
     uint64_t stat_sinkhorn_rescued = 0;  // problems the log-domain rescue pass re-solved behind the resident kernel
+    int sk_range_strikes = 0;        // observed calls with range rescues (2 -> sinkhorn_stream)
+    int sk_stream_calls = 0;         // calls served by the chain since the demotion (16 -> the resident kernel is tried again)
+    uint64_t stat_sinkhorn_timeouts = 0;
     bool sinkhorn_stream = false;    // set by the first such report: later calls run the log-domain launch chain
     char* d_dummy = nullptr;  // 4 KB scratch line: target of masked-out stores of kernels that must issue a fixed number of stores (gemm_p2.hip)
     // workspace arena
@@ -143,6 +146,9 @@ struct e2emv_ctx {
     // drained first, because the arena contents of the earlier call may still be in use there.
     std::recursive_mutex mu;
     void* train = nullptr;  // e2emv::TrainState (train.hip)
+    // matched descriptors (final_proj output) of the last forward_joint call, in the workspace: [md_imgs][md_rows][md_dim] fp32
+    const float* last_mdesc = nullptr;
+    int md_imgs = 0, md_rows = 0, md_n = 0, md_dim = 0;
     hipStream_t last_stream = nullptr;
     bool have_last_stream = false;
     // profiling
@@ -205,6 +211,7 @@ constexpr const char* dbg_env(const char*) { return nullptr; }
 #endif
 void train_free(e2emv_ctx* ctx);  // train.hip
 // ctx->d_flags (device words: [0] Sinkhorn give-up flag, [1] its sticky count, [2] plane blocks that needed a tile exponent,
+// [3] Sinkhorn problems rescued after a range event, [6] after a timeout, [4] give-ups of the resident kernel's waits,
 // [5] (wave, tile) softmaxes attention_p2w redid on its slow path)
 int ensure_flags(e2emv_ctx* ctx);
 // hipFuncAttributeMaxDynamicSharedMemorySize for kernels that use more than the default dynamic LDS: once per

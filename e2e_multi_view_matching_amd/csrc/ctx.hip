@@ -232,6 +232,23 @@ int e2emv_d2h(e2emv_ctx* ctx, void* dst, const void* d_src, size_t bytes, void* 
     return E2EMV_OK;
 }
 
+// Rescue counts the host has just read from the device: `range` problems whose scalings left the exponential-domain kernel's
+// range (a property of the model: the second observation moves the context to the log-domain chain), `timeouts` problems given
+// up because an inter-workgroup wait ran out (contention, e.g. a co-tenant process: counted, never a reason to demote)
+static void note_rescues(e2emv_ctx* ctx, unsigned range, unsigned timeouts) {
+    const unsigned zero = 0;
+    if (range) {
+        (void)hipMemcpy(ctx->d_flags + 3, &zero, sizeof(zero), hipMemcpyHostToDevice);
+        ctx->stat_sinkhorn_rescued += range;
+        if (++ctx->sk_range_strikes >= 2) { ctx->sinkhorn_stream = true; ctx->sk_stream_calls = 0; }
+    }
+    if (timeouts) {
+        (void)hipMemcpy(ctx->d_flags + 6, &zero, sizeof(zero), hipMemcpyHostToDevice);
+        ctx->stat_sinkhorn_rescued += timeouts;
+        ctx->stat_sinkhorn_timeouts += timeouts;
+    }
+}
+
 int e2emv_sync(e2emv_ctx* ctx, void* stream) {
     if (!ctx) return E2EMV_EINVAL;
     E2EMV_ENTER(ctx, stream);
@@ -239,14 +256,9 @@ int e2emv_sync(e2emv_ctx* ctx, void* stream) {
     if (ctx->d_flags) {
         // [1]: Sinkhorn problems whose potentials are non-finite even after the log-domain rescue pass = non-finite scores
         // [3]: problems the rescue pass re-solved (finite outputs; a context that keeps needing it moves to the log-domain chain)
-        unsigned f[4] = {0, 0, 0, 0};
+        unsigned f[7] = {0, 0, 0, 0, 0, 0, 0};
         E2EMV_HIP(ctx, hipMemcpy(f, ctx->d_flags, sizeof(f), hipMemcpyDeviceToHost));
-        if (f[3]) {
-            unsigned zero = 0;
-            (void)hipMemcpy(ctx->d_flags + 3, &zero, sizeof(zero), hipMemcpyHostToDevice);
-            ctx->stat_sinkhorn_rescued += f[3];
-            ctx->sinkhorn_stream = true;
-        }
+        note_rescues(ctx, f[3], f[6]);
         if (f[1]) {
             unsigned zero = 0;
             (void)hipMemcpy(ctx->d_flags + 1, &zero, sizeof(zero), hipMemcpyHostToDevice);
@@ -602,20 +614,19 @@ int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset) {
     E2EMV_LOCK(ctx);
     (void)hipSetDevice(ctx->device);
     E2EMV_HIP(ctx, hipDeviceSynchronize());
-    unsigned f[6] = {0, 0, 0, 0, 0, 0};
+    unsigned f[7] = {0, 0, 0, 0, 0, 0, 0};
     if (ctx->d_flags) E2EMV_HIP(ctx, hipMemcpy(f, ctx->d_flags, sizeof(f), hipMemcpyDeviceToHost));
     ctx->stat_sinkhorn_bad += f[1];
-    ctx->stat_sinkhorn_rescued += f[3];
-    const uint64_t v[4] = {(uint64_t)f[2], ctx->stat_sinkhorn_bad, ctx->stat_sinkhorn_rescued, (uint64_t)f[5]};
-    for (int i = 0; i < n; ++i) stats[i] = i < 4 ? v[i] : 0;
-    if (ctx->d_flags && (f[1] || f[3])) {  // the device counts moved into the host-side totals
-        E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 1, 0, sizeof(unsigned)));
-        E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 3, 0, sizeof(unsigned)));
-        if (f[3]) ctx->sinkhorn_stream = true;  // this model keeps leaving the exponential-domain kernel's range: log-domain chain from now on
-    }
+    if (ctx->d_flags) note_rescues(ctx, f[3], f[6]);
+    const uint64_t v[5] = {(uint64_t)f[2], ctx->stat_sinkhorn_bad, ctx->stat_sinkhorn_rescued, (uint64_t)f[5], ctx->stat_sinkhorn_timeouts};
+    for (int i = 0; i < n; ++i) stats[i] = i < 5 ? v[i] : 0;
+    if (ctx->d_flags && f[1]) E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 1, 0, sizeof(unsigned)));  // moved into the host-side total
     if (reset) {
         ctx->stat_sinkhorn_bad = 0;
         ctx->stat_sinkhorn_rescued = 0;
+        ctx->stat_sinkhorn_timeouts = 0;
+        ctx->sk_range_strikes = 0;
+        ctx->sk_stream_calls = 0;
         ctx->sinkhorn_stream = false;  // (a reset also returns the Sinkhorn to the resident kernel)
         if (ctx->d_flags) E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 2, 0, sizeof(unsigned)));
         if (ctx->d_flags) E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 5, 0, sizeof(unsigned)));

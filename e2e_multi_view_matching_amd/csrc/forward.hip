@@ -171,7 +171,9 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
     const bool h2 = b3 && ctx->precision == E2EMV_PRECISION_F16X2;  // fp16 x 2 planes instead of bf16 x 3 (gemm_x3.hip)
     // f16x2 on PLANE activations (p2.h): every producer epilogue emits the two fp16 planes, consumers load them straight
     // into LDS (gemm_p2.hip, attention_p2.hip); h2_legacy keeps the round-2 kernels (fp32 activations, split in the consumer)
-    const bool p2 = h2 && !ctx->h2_legacy && D == 256 && H == 4 && !ctx->layers.empty();
+    // (their operands are addressed with 32-bit byte offsets: the widest plane matrices, q | k and the hidden layer, are
+    // Mtot x 2D x 4 bytes - beyond 2 GB, 2^20 rows at D = 256, the call runs on the round-2 kernels)
+    const bool p2 = h2 && !ctx->h2_legacy && D == 256 && H == 4 && !ctx->layers.empty() && Mtot * 8 * D < ((int64_t)1 << 31);
     // bf16x3 attention path: x as S3 planes (6D bytes/row) and V^T planes (6D bytes/row); the q|k planes
     // (S3, 2D wide = 12D bytes/row) live in the fp32 q|k|v buffer, which has exactly that size
     const size_t sz_x3 = b3 ? al((size_t)Mtot * 3 * D * 2) : 0;
@@ -385,6 +387,8 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         if (rc) return rc;
     }
 
+    ctx->last_mdesc = mdesc; ctx->md_imgs = B * T; ctx->md_rows = n_rows; ctx->md_n = N; ctx->md_dim = D;  // (e2emv_get_descriptors)
+
     // ---- all pairs: scores -> Sinkhorn -> matches; then the conf head per pair.  With equal keypoint counts all
     // P*B problems go through ONE Sinkhorn batch; a ragged tuple runs one batch per pair (M = N_i, N = N_j).
     const int64_t tuple_stride = (int64_t)T * n_rows * D;
@@ -535,5 +539,24 @@ extern "C" int e2emv_matcher_forward(e2emv_ctx* ctx, const e2emv_forward_desc* f
             int rc = forward_joint(ctx, &f2, kp, ks, de, lz, m0, m1, s0, s1, cf, s);
             if (rc) return rc;
         }
+    return E2EMV_OK;
+}
+
+// The matched descriptors (final_proj output, upstream's mdesc0 / mdesc1) of the last e2emv_matcher_forward call: what the
+// score matrix was built from.  An audit output - parity tests compare it with the oracle's descriptors, the quantity the GNN
+// arithmetic modes differ in (logZ is dominated by the fp32 Sinkhorn).
+extern "C" int e2emv_get_descriptors(e2emv_ctx* ctx, float* d_out, int64_t capacity, int* n_img, int* n_kpts, int* dim, void* stream) {
+    if (!ctx) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    if (!ctx->last_mdesc || ctx->last_mdesc < (const float*)ctx->d_ws) return set_err(ctx, E2EMV_ESTATE, "get_descriptors: no forward on this context yet");
+    if (n_img) *n_img = ctx->md_imgs;
+    if (n_kpts) *n_kpts = ctx->md_n;
+    if (dim) *dim = ctx->md_dim;
+    if (!d_out) return E2EMV_OK;  // (size query)
+    const int64_t need = (int64_t)ctx->md_imgs * ctx->md_n * ctx->md_dim;
+    if (capacity < need) return set_err(ctx, E2EMV_ESHAPE, "get_descriptors: buffer of %lld floats, %lld needed", (long long)capacity, (long long)need);
+    const size_t row = (size_t)ctx->md_dim * sizeof(float);
+    E2EMV_HIP(ctx, hipMemcpy2DAsync(d_out, (size_t)ctx->md_n * row, ctx->last_mdesc, (size_t)ctx->md_rows * row, (size_t)ctx->md_n * row,
+                                    (size_t)ctx->md_imgs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return E2EMV_OK;
 }

@@ -1054,7 +1054,21 @@ __global__ __launch_bounds__(1024) void sinkhorn_rescue(SkParams p, int iters, u
         bad = bad || !(fabsf(x) < INFINITY);
     }
     const int still = __syncthreads_or(bad ? 1 : 0);
-    if (tid == 0) atomicAdd(flags + (still ? 1 : 3), 1u);
+    // [1] non-finite even in the log domain (non-finite scores: an error); otherwise rescued - [6] when a wait of the resident
+    // kernel gave up in this launch (contention: says nothing about the model), [3] when not (a scaling left fp32's range)
+    if (tid == 0) atomicAdd(flags + (still ? 1 : (flags[0] ? 6 : 3)), 1u);
+}
+
+// streaming chain: the potentials of a problem with non-finite scores are non-finite - counted like the resident path's
+// (flags[1], reported by e2emv_sync / check_finite)
+__global__ __launch_bounds__(256) void sinkhorn_check_finite(SkParams p, unsigned* flags) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* ub = p.u + (int64_t)b * (p.M + 1);
+    const float* vb = p.v + (int64_t)b * p.ldV;
+    bool bad = false;
+    for (int i = tid; i <= p.M; i += 256) bad = bad || !(fabsf(ub[i]) < INFINITY);
+    for (int j = tid; j <= p.N; j += 256) bad = bad || !(fabsf(vb[j]) < INFINITY);
+    if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicAdd(flags + 1, 1u);
 }
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -1175,7 +1189,12 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
     }
     // once a call of this context reported scores outside the exponential-domain kernel's range (e2emv_sync / e2emv_get_stats),
     // the model at hand is served by the log-domain chain: slower, no range limit
-    if (ctx->sinkhorn_stream) resident = false;
+    // (demotion needs two observed range events; after 16 calls on the chain the resident kernel gets another try - a model whose
+    // scores really are out of its range is demoted again by the next event)
+    if (ctx->sinkhorn_stream) {
+        if (++ctx->sk_stream_calls > 16) { ctx->sinkhorn_stream = false; ctx->sk_stream_calls = 0; ctx->sk_range_strikes = 1; }
+        else resident = false;
+    }
     int wg_per_cu = 0;
     const void* kfn = nullptr;
     const size_t res_lds = sizeof(float) * (size_t)(9 * KT_of(ldS) * 256 + 4 + 32);
@@ -1273,6 +1292,7 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
             hipLaunchKernelGGL(sinkhorn_combine, dim3((unsigned)((p.ldV + 63) / 64), B), dim3(256), 0, s, p);
             std::swap(p.v, p.v_next);
         }
+        if (ensure_flags(ctx) == E2EMV_OK) hipLaunchKernelGGL(sinkhorn_check_finite, dim3(B), dim3(256), 0, s, p, ctx->d_flags);
     }
     sweep(true);  // logZ + fused arg-max from the final potentials (one more read of the scores)
     E2EMV_CHECK_LAUNCH(ctx, "sinkhorn kernels");

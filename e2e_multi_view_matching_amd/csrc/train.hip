@@ -175,20 +175,12 @@ int conv_bn(e2emv_ctx* ctx, TrainState* t, Pack& raw, const std::string& prefix,
 
 }  // namespace
 
-extern "C" int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* m) {
-    if (!ctx || !m) return E2EMV_EINVAL;
-    E2EMV_LOCK(ctx);
+// host part of e2emv_train_commit: folds BatchNorm / head order of the tensors handed over with e2emv_set_weight into the
+// packed training weights (pk) and keeps the raw parameters (raw) for the un-folding of the gradients
+static int train_build(e2emv_ctx* ctx, const e2emv_model_desc* m, TrainState* t, Pack& pk, Pack& raw) {
     const int D = m->desc_dim, H = m->num_heads;
-    if (D <= 0 || H <= 0 || D % H || D / H != 64) return set_err(ctx, E2EMV_ESHAPE, "train_commit: head dim must be 64 (D=%d H=%d)", D, H);
-    if (m->n_kenc < 1 || m->n_kenc > E2EMV_MAX_KENC || m->n_layers < 0 || m->n_layers > E2EMV_MAX_LAYERS) return set_err(ctx, E2EMV_ESHAPE, "train_commit: bad layer counts");
-    (void)hipSetDevice(ctx->device);
-    E2EMV_HIP(ctx, hipDeviceSynchronize());
-    train_free(ctx);
-    TrainState* t = new TrainState();
-    ctx->train = t;
     t->model = *m;
     const int d = D / H;
-    Pack pk, raw;
     std::vector<float> w, b;
     int rc;
     t->kdims = {3};
@@ -253,6 +245,38 @@ extern "C" int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     t->raw["bin_score"] = {raw.add(bs->data), 1};
     t->w_floats = pk.host.size();
     t->raw_floats = raw.host.size();
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* m) {
+    if (!ctx || !m) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
+    const int D = m->desc_dim, H = m->num_heads;
+    if (D <= 0 || H <= 0 || D % H || D / H != 64) return set_err(ctx, E2EMV_ESHAPE, "train_commit: head dim must be 64 (D=%d H=%d)", D, H);
+    if (m->n_kenc < 1 || m->n_kenc > E2EMV_MAX_KENC || m->n_layers < 0 || m->n_layers > E2EMV_MAX_LAYERS) return set_err(ctx, E2EMV_ESHAPE, "train_commit: bad layer counts");
+    (void)hipSetDevice(ctx->device);
+    TrainState* t = new TrainState();
+    Pack pk, raw;
+    if (int rc = train_build(ctx, m, t, pk, raw)) { delete t; return rc; }
+    // Every optimiser step comes through here (the parameters changed).  A context that already trains this model keeps
+    // its arenas and its tape: the new values are copied over the old ones - no free / malloc, one synchronisation (the
+    // previous step's kernels may still read the weights)
+    TrainState* old = ts_of(ctx);
+    E2EMV_HIP(ctx, hipDeviceSynchronize());
+    const bool reuse = old && old->w_floats == t->w_floats && old->raw_floats == t->raw_floats && memcmp(&old->model, m, sizeof(*m)) == 0 && old->d_w && old->d_maps;
+    if (reuse) {
+        t->d_w = old->d_w; t->d_gw = old->d_gw; t->d_raw = old->d_raw; t->d_graw = old->d_graw; t->d_maps = old->d_maps;
+        t->d_tape = old->d_tape; t->tape_bytes = old->tape_bytes;
+        delete old;  // (the host side only: the device buffers moved over)
+        ctx->train = t;
+        E2EMV_HIP(ctx, hipMemcpy(t->d_w, pk.host.data(), t->w_floats * sizeof(float), hipMemcpyHostToDevice));
+        E2EMV_HIP(ctx, hipMemcpy(t->d_raw, raw.host.data(), t->raw_floats * sizeof(float), hipMemcpyHostToDevice));
+        E2EMV_HIP(ctx, hipMemset(t->d_graw, 0, t->raw_floats * sizeof(float)));
+        return E2EMV_OK;
+    }
+    train_free(ctx);
+    ctx->train = t;
+    const int D = m->desc_dim, H = m->num_heads, d = D / H;
     E2EMV_HIP(ctx, hipMalloc((void**)&t->d_w, t->w_floats * sizeof(float)));
     E2EMV_HIP(ctx, hipMalloc((void**)&t->d_gw, t->w_floats * sizeof(float)));
     E2EMV_HIP(ctx, hipMalloc((void**)&t->d_raw, t->raw_floats * sizeof(float)));

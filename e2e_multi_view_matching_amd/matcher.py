@@ -50,6 +50,11 @@ DEFAULT_CONFIG = {
     # planes, 6 bf16-MFMA products) or "f16x2" (two fp16 planes, 3 fp16-MFMA products), all with fp32 accumulation and the
     # same parity bar.  None = the library default (environment variable E2EMV_PRECISION, else "f16x2").
     "mfma_precision": None,
+    # Training (.train() + gradients): BatchNorm layers normalise with their RUNNING statistics and do not update them
+    # (csrc/train.hip) - gradients for their affine parameters are returned.  Upstream's matcher.train() (train.py:131,348)
+    # would use batch statistics on a stock torch BatchNorm; the fork's own behaviour is not in the checkout.  The first
+    # differentiable forward of a model warns about this unless the key is set to True (= "I know").
+    "frozen_batchnorm": None,
     # True: forward() synchronises and raises if the device reported non-finite scores (off by default: the reference's
     # forward is asynchronous too, and the NaN / inf is in the outputs either way)
     "check_finite": False,
@@ -114,7 +119,12 @@ class _MatchScores(torch.autograd.Function):
         pz, arr_z = _lib.ptr_array(g[:P])
         pc, arr_c = _lib.ptr_array(g[P:]) if fctx.n_conf else (None, None)
         out = [None]
-        with torch.cuda.device(dev):
+        # one critical section from the generation check to the last e2emv_get_grad: another thread's training forward on this
+        # device would re-commit (gradient arena zeroed, tape dropped) in between and the remaining reads would be silently wrong
+        with ctx.py_lock, torch.cuda.device(dev):
+            if ctx.train_generation != fctx.generation:
+                raise RuntimeError("MultiViewMatcher: backward() of a forward that is not the last training forward on this device "
+                                   "(the library keeps one tape per context)")
             ctx.call("e2emv_matcher_backward", pz, pc, _lib.stream_ptr(dev))
             for n, (name, shape) in enumerate(zip(fctx.names, fctx.param_shapes)):
                 if not fctx.needs_input_grad[1 + n]:
@@ -126,6 +136,8 @@ class _MatchScores(torch.autograd.Function):
                 t = torch.empty(shape, dtype=torch.float32, device=dev)
                 ctx.call("e2emv_get_grad", name.encode(), ctypes.c_void_p(t.data_ptr()), t.numel(), _lib.stream_ptr(dev))
                 out.append(t)
+            if ctx.train_generation != fctx.generation:
+                raise RuntimeError("MultiViewMatcher: another training forward ran on this device during backward()")
         return tuple(out)
 
 
@@ -209,28 +221,41 @@ class MultiViewMatcher(nn.Module):
         md.conf_mlp = 1 if cfg["conf_mlp"] else 0
         return md
 
-    def _push_weights(self, ctx):
-        # the context holds one weight set: re-push whenever another module (or other parameter values) own it
-        owner = (self._token, self._fingerprint())
-        if ctx.weights_owner == owner:
+    def _send_weights(self, ctx, owner):
+        """e2emv_set_weight for every tensor (the library's host-side store), once per (module, parameter values)."""
+        if getattr(ctx, "sent_owner", None) == owner:
             return
-        ctx.weights_owner = None
+        ctx.sent_owner = None
         for k, v in self.state_dict().items():
             if not v.dtype.is_floating_point:
                 continue  # num_batches_tracked
             h = v.detach().to("cpu", torch.float32).contiguous()
             shape = (ctypes.c_int64 * max(h.dim(), 1))(*h.shape)
             ctx.call("e2emv_set_weight", k.encode(), ctypes.c_void_p(h.data_ptr()), shape, h.dim())
+        ctx.sent_owner = owner
+
+    def _push_weights(self, ctx):
+        # the context holds one weight set: re-push whenever another module (or other parameter values) own it
+        owner = (self._token, self._fingerprint())
+        if ctx.weights_owner == owner:
+            return
+        ctx.weights_owner = None
+        self._send_weights(ctx, owner)
         md = self._model_desc()
         ctx.call("e2emv_commit_weights", ctypes.byref(md))
         ctx.weights_owner = owner
 
     def _push_train_weights(self, ctx):
-        self._push_weights(ctx)
-        if ctx.train_owner != ctx.weights_owner:
-            md = self._model_desc()
-            ctx.call("e2emv_train_commit", ctypes.byref(md))
-            ctx.train_owner = ctx.weights_owner
+        """Training commit only: after an optimiser step the parameters changed, and what the differentiable path needs is the
+        training arena (e2emv_train_commit: BN / head-order folds, arenas and tape kept) - NOT the inference commit with its
+        fp64 merge fold and the bf16x3 / f16x2 planes, which is made when (if) an inference forward next needs it."""
+        owner = (self._token, self._fingerprint())
+        if ctx.train_owner == owner:
+            return
+        self._send_weights(ctx, owner)
+        md = self._model_desc()
+        ctx.call("e2emv_train_commit", ctypes.byref(md))
+        ctx.train_owner = owner
 
     def _differentiable(self):
         if self.config.get("autograd", None) is False or not self.training or not torch.is_grad_enabled():
@@ -322,6 +347,12 @@ class MultiViewMatcher(nn.Module):
                                           "(the reference's training batches do, datasets pad to max_keypoints)")
             if T > 2 and not cfg["multi_frame_matching"]:
                 raise NotImplementedError("training path: tuples of more than two images need multi_frame_matching")
+            if not cfg.get("frozen_batchnorm") and not getattr(self, "_warned_bn", False):
+                self._warned_bn = True
+                import warnings
+                warnings.warn("MultiViewMatcher in .train() mode: BatchNorm layers use their running statistics (frozen) and do not "
+                              "update them - batch-statistics BatchNorm is not implemented on the differentiable path.  Set "
+                              "config['frozen_batchnorm'] = True to acknowledge (e.g. fine-tuning from a checkpoint).", stacklevel=3)
             self._push_train_weights(ctx)
             named = [(k, p) for k, p in self.named_parameters()]
             holder = []
@@ -369,6 +400,19 @@ class MultiViewMatcher(nn.Module):
                 out[f"matching_scores{j}_{i}_{j}"] = s1[p]
                 out[f"conf_scores_{i}_{j}"] = cf[p].unsqueeze(-1)
         return out
+
+
+def last_descriptors(device):
+    """The matched descriptors (upstream's mdesc, final_proj output) of the last forward on `device`: [B*T, N, D] fp32,
+    keypoint-major (``e2emv_get_descriptors``) - an audit output for parity tests of the GNN arithmetic."""
+    dev = torch.device(device)
+    ctx = _lib.context(dev)
+    n_img, n, d = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    with torch.cuda.device(dev):
+        ctx.call("e2emv_get_descriptors", None, 0, ctypes.byref(n_img), ctypes.byref(n), ctypes.byref(d), _lib.stream_ptr(dev))
+        out = torch.empty((n_img.value, n.value, d.value), dtype=torch.float32, device=dev)
+        ctx.call("e2emv_get_descriptors", _lib.ptr(out), out.numel(), ctypes.byref(n_img), ctypes.byref(n), ctypes.byref(d), _lib.stream_ptr(dev))
+    return out
 
 
 SuperGlue = MultiViewMatcher  # the north-star's name for the same forward()

@@ -117,8 +117,9 @@ def _w8pt_call(cf, ctx, dev, B, N, k0, k1, K0, K1, kdim, Tg, choose_closest, det
     T = torch.empty((B, 4, 4), dtype=torch.float32, device=dev)
     k0n, k1n = torch.empty_like(k0), torch.empty_like(k1)
     cfn = torch.empty((B, N), dtype=torch.float32, device=dev)
-    inl = torch.empty((B, N), dtype=torch.uint8, device=dev) if determine_inliers else None
-    pos = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    # (the kernels write the masks as 0 / 1 bytes - the storage format of torch.bool: no conversion kernel behind the call)
+    inl = torch.empty((B, N), dtype=torch.bool, device=dev) if determine_inliers else None
+    pos = torch.empty((B, N), dtype=torch.bool, device=dev)
     F = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
     status = torch.empty((B,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
@@ -127,7 +128,7 @@ def _w8pt_call(cf, ctx, dev, B, N, k0, k1, K0, K1, kdim, Tg, choose_closest, det
                  _lib.ptr(k1n), _lib.ptr(cfn), _lib.ptr(inl), _lib.ptr(pos), _lib.ptr(F), _lib.ptr(status),
                  _lib.stream_ptr(dev))
     info = {"kpts0_norm": k0n, "kpts1_norm": k1n, "confidence": cfn.reshape(conf_shape),
-            "inliers": inl.bool() if inl is not None else None, "pos_depth_mask": pos.bool(),
+            "inliers": inl, "pos_depth_mask": pos,
             "F": F, "status": status}
     return T, info
 
@@ -233,8 +234,8 @@ def run_weighted_8_point_tuple(data, result, choose_closest=False, targets=None,
     k0n = torch.empty((P, B, N, 2), dtype=torch.float32, device=dev)
     k1n = torch.empty_like(k0n)
     cfn = torch.empty((P, B, N), dtype=torch.float32, device=dev)
-    inl = torch.empty((P, B, N), dtype=torch.uint8, device=dev) if determine_inliers else None
-    pos = torch.empty((P, B, N), dtype=torch.uint8, device=dev)
+    inl = torch.empty((P, B, N), dtype=torch.bool, device=dev) if determine_inliers else None  # (0 / 1 bytes, see above)
+    pos = torch.empty((P, B, N), dtype=torch.bool, device=dev)
     F = torch.empty((P, B, 3, 3), dtype=torch.float32, device=dev)
     status = torch.empty((P, B), dtype=torch.int32, device=dev)
     keep, args = [], []
@@ -246,8 +247,7 @@ def run_weighted_8_point_tuple(data, result, choose_closest=False, targets=None,
         ctx.call("e2emv_w8pt_tuple", B, T, N, args[0], args[1], kdim, nb, args[2], args[3], 1 if choose_closest else 0, args[4],
                  1 if determine_inliers else 0, _lib.ptr(Tout), _lib.ptr(k0n), _lib.ptr(k1n), _lib.ptr(cfn), _lib.ptr(inl),
                  _lib.ptr(pos), _lib.ptr(F), _lib.ptr(status), _lib.stream_ptr(dev))
-    posb = pos.bool()
-    inlb = inl.bool() if inl is not None else None
+    posb, inlb = pos, inl
     out = {}
     for q, p in enumerate(pairs):
         info = {"kpts0_norm": k0n[q], "kpts1_norm": k1n[q], "confidence": cfn[q].reshape(conf_shapes[q]),
@@ -263,7 +263,7 @@ def _pose_error_buffers(T0, T1, means):
     B = a.shape[0]
     rot = torch.empty((B,), dtype=torch.float32, device=dev)
     tr = torch.empty((B,), dtype=torch.float32, device=dev)
-    valid = torch.empty((B,), dtype=torch.uint8, device=dev)
+    valid = torch.empty((B,), dtype=torch.bool, device=dev)  # (0 / 1 bytes)
     m2 = torch.empty((2,), dtype=torch.float32, device=dev) if means else None
     with torch.cuda.device(dev):
         ctx.call("e2emv_pose_error_means", B, _lib.ptr(a), _lib.ptr(b), _lib.ptr(rot), _lib.ptr(tr), _lib.ptr(valid),
@@ -322,10 +322,10 @@ def compute_translation_error_as_angle(T0, T1, reduce=True):
     entries (shape [n_valid], like the reference's boolean indexing).  Differentiable with respect to ``T0`` like the above."""
     if _wants_grad(T0):
         _, tr, valid = _PoseErrors.apply(T0, T1)
-        sel = tr[valid.bool()]
+        sel = tr[valid]
         return sel.mean() if reduce else sel
     _, tr, valid, m2 = _pose_error_buffers(T0, T1, means=reduce)
-    return m2[1] if reduce else tr[valid.bool()]
+    return m2[1] if reduce else tr[valid]
 
 
 def mask_confidence(confidence, mask):

@@ -356,6 +356,12 @@ int e2emv_qkv_p2(e2emv_ctx* ctx, int n_img, int n_rows, int D, int H, const floa
 int e2emv_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv, int flags,
                        float* d_out, void* stream);
 
+/* The matched descriptors of the LAST e2emv_matcher_forward call on this context (upstream's mdesc0 / mdesc1 = final_proj
+ * output, models/superglue.py:269 upstream; with multi_frame_matching off and T > 2: of its last pair): d_out
+ * [n_img = B*T][n_kpts][dim] fp32, keypoint-major.  d_out == NULL only reports the three sizes.  An audit output: the
+ * quantity the arithmetic modes of the GNN differ in (tests/test_gpu_round4.py, tools/parity_margins.py). */
+int e2emv_get_descriptors(e2emv_ctx* ctx, float* d_out, int64_t capacity_floats, int* n_img, int* n_kpts, int* dim, void* stream);
+
 /* ---- range statistics ------------------------------------------------------------------------------------------------
  * The f16x2 mode keeps its fp16 planes inside fp16's range with one exponent per block of 64 x 64 activations (see
  * DESIGN.md 4d): there is no out-of-range fallback to take.  stats[0] = plane blocks that needed a non-zero exponent since
@@ -363,8 +369,9 @@ int e2emv_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, in
  * Sinkhorn problems whose scores were non-finite (their outputs are NaN / inf and e2emv_sync reports them), stats[2] =
  * Sinkhorn problems the exponential-domain resident kernel could not finish (a scaling left fp32's range, or an
  * inter-workgroup wait gave up under contention) and the rescue pass behind it re-solved in the log domain inside the same
- * call: their outputs are correct, nothing is raised; once the host has seen such an event (here or in e2emv_sync) the
- * context runs the log-domain launch chain for every later call; stats[3] = (wave, stream, 64-key tile) softmaxes that
+ * call: their outputs are correct, nothing is raised.  The host tells the two causes apart: the SECOND observation (here or
+ * in e2emv_sync) of calls with range rescues moves the context to the log-domain launch chain - after 16 calls on it the
+ * resident kernel gets another try -, rescues behind a timeout (stats[4] counts those) never do; stats[3] = (wave, stream, 64-key tile) softmaxes that
  * attention_p2w redid on its slow path (a performance counter: results are the same).  Host-synchronising. */
 int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset);
 

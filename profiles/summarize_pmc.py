@@ -8,6 +8,7 @@ re-calibrated here on a kernel with a known byte count in the same access patter
 B*N*N*4 bytes with 16-B/lane loads; it writes 2 partial planes) - see the `calibration` entry of the JSON.
 """
 import json
+import os
 import sqlite3
 import sys
 
@@ -73,6 +74,12 @@ def main(sq_db, fetch_db, write_db, out_md, out_json, config="c2", mode="f32", p
     except Exception:
         allj = {}
     allj.setdefault("unit", "HBM bytes per launch (average over the launches of one bench.py run); FETCH_SIZE x 2 per MI355X_MICROARCH.md")
+    try:  # the sources these counters were taken on: bench.py reports `traffic` only while csrc/ still hashes to this
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from e2e_multi_view_matching_amd.build import _stamp
+        js["csrc_stamp"] = _stamp()
+    except Exception:
+        js["csrc_stamp"] = None
     allj.setdefault("workloads", {}).setdefault(config, {})[mode] = js
     json.dump(allj, open(out_json, "w"), indent=1)
     print(text)

@@ -98,3 +98,25 @@ def test_gpus_8_world_of_eight_ranks_over_gloo():
     assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["global_pairs"] == 8 * 3 and out["auc_pairs"] == 8 * 3
     assert out["config"]["parallelism"] == "tuple-sharded x8"
     assert abs(out["value"] - 8 * 3 * 2 / (out["ms_per_step"] * 2e-3)) < 0.02 * out["value"]
+
+
+def test_rank_cpu_slices_partition_the_host_cores():
+    """bench.pin_cpus: the ranks of a node get disjoint, contiguous slices of the cores the process may use (run in a child:
+    the affinity of the test process is left alone)."""
+    import subprocess
+    import sys
+    code = ("import os, sys, json; sys.path.insert(0, %r); import bench; "
+            "base = sorted(os.sched_getaffinity(0)); out = []\n"
+            "for r in range(4):\n"
+            "    os.sched_setaffinity(0, base); m = bench.pin_cpus(r, 4); out.append(sorted(m) if m else None)\n"
+            "print(json.dumps({'base': base, 'slices': out}))") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    if len(d["base"]) < 4:
+        pytest.skip("fewer than 4 usable cores")
+    sl = d["slices"]
+    assert all(s for s in sl)
+    assert len({c for s in sl for c in s}) == sum(len(s) for s in sl)            # disjoint
+    assert all(s == d["base"][i * len(s):(i + 1) * len(s)] for i, s in enumerate(sl))  # contiguous, in rank order

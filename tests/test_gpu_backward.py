@@ -122,6 +122,18 @@ def test_pair_two_layers_parameter_gradients(gpu):
     assert len(worst) == sum(1 for _ in model.parameters())
 
 
+def test_full_depth_1024_keypoints_one_pair(gpu):
+    """The shape a training step really has (train.py:406-425 at the reference's defaults): 18 layers, 1024 keypoints, 100
+    Sinkhorn iterations, one pair - every parameter gradient against torch.autograd over the oracle (the oracle's backward
+    costs a few seconds on the host cores)."""
+    cfg = {"GNN_layers": ["self", "cross"] * 9, "sinkhorn_iterations": 100, "frozen_batchnorm": True}
+    model, leaves, out, ref, pairs = _grads(cfg, dict(batch=1, tuple_size=2, n_kpts=1024), gpu, seed=11)
+    z, zr = out["scores_0_1"].detach().cpu(), ref["scores_0_1"].detach()
+    assert float((z - zr).abs().max()) < 1e-4
+    worst = _check(model, leaves)
+    assert len(worst) == sum(1 for _ in model.parameters())
+
+
 def test_ragged_rows_and_four_layers(gpu):
     """N = 200 (rows padded to 256 inside the library: padded rows must not leak into any weight gradient), 4 layers."""
     cfg = {"GNN_layers": ["self", "cross"] * 2, "sinkhorn_iterations": 20}

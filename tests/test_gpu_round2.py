@@ -191,6 +191,10 @@ def _full_size(gpu, n_kpts, desc_dtype, precisions):
     one = {k: (v[:1].float() if (torch.is_tensor(v) and v.dtype == torch.float16) else (v[:1] if torch.is_tensor(v) else v))
            for k, v in data.items()}
     ref = matcher_forward(one, {k: v.clone() for k, v in model.state_dict().items()}, {**model.config, "full_output": True})
+    # ... and the LAST tuple of the batch (other output tiles, other CUs, another place in the persistent-tile schedules)
+    lastt = {k: (v[B - 1:].float() if (torch.is_tensor(v) and v.dtype == torch.float16) else (v[B - 1:] if torch.is_tensor(v) else v))
+             for k, v in data.items()}
+    ref_last = matcher_forward(lastt, {k: v.clone() for k, v in model.state_dict().items()}, {**model.config, "full_output": True})
     model = model.to(gpu)
     dg = _dev(data, gpu)
     for precision in precisions:
@@ -206,6 +210,9 @@ def _full_size(gpu, n_kpts, desc_dtype, precisions):
             assert float((z[:1].cpu() - ref[f"scores_{i}_{j}"]).abs().max()) < 1e-4, (precision, i, j)
             assert torch.equal(out[f"matches{i}_{i}_{j}"][:1].cpu(), ref[f"matches{i}_{i}_{j}"]), (precision, i, j)
             assert torch.equal(out[f"matches{j}_{i}_{j}"][:1].cpu(), ref[f"matches{j}_{i}_{j}"]), (precision, i, j)
+            assert float((z[B - 1:].cpu() - ref_last[f"scores_{i}_{j}"]).abs().max()) < 1e-4, (precision, i, j, "last tuple")
+            assert torch.equal(out[f"matches{i}_{i}_{j}"][B - 1:].cpu(), ref_last[f"matches{i}_{i}_{j}"]), (precision, i, j, "last tuple")
+            assert torch.equal(out[f"matches{j}_{i}_{j}"][B - 1:].cpu(), ref_last[f"matches{j}_{i}_{j}"]), (precision, i, j, "last tuple")
             # Sinkhorn marginals on the whole batch: the last half-iteration is the column update -> exact columns
             P = z.exp()
             assert float((P[:, :, :N].sum(1) - 1).abs().max()) < 1e-3

@@ -77,9 +77,10 @@ def main():
         rows.append((k, v))
     # ---- a training step: forward with a tape + match loss + pose loss + backward, full-depth network
     for (Bt, Nt) in ((4, 1024), (8, 1024)):
-        cfg = {"GNN_layers": ["self", "cross"] * 9, "sinkhorn_iterations": 100, "conf_mlp": True, "full_output": True}
+        cfg = {"GNN_layers": ["self", "cross"] * 9, "sinkhorn_iterations": 100, "conf_mlp": True, "full_output": True, "frozen_batchnorm": True}
         torch.manual_seed(0)
         model = synthetic.identity_like_state(E.MultiViewMatcher(cfg)).to(dev).train()
+        opt = torch.optim.SGD(model.parameters(), lr=1e-6)  # (a real step: the parameters change, the next forward re-commits them)
         data = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synthetic.make_tuples(batch=Bt, tuple_size=2, n_kpts=Nt, seed=5).items()}
         gt = data["gt_matches0_0_1"]
         idx = torch.full((Bt, Nt + 1), Nt, dtype=torch.int64, device=dev)
@@ -92,11 +93,12 @@ def main():
             pred, _ = E.run_weighted_8_point(data, res, 0, 1, choose_closest=True, target_T_021=data["T_0to1"])
             loss = nll + E.compute_rotation_error(pred, data["T_0to1"]) + E.compute_translation_error_as_angle(pred, data["T_0to1"])
             loss.backward()
+            opt.step()
         with torch.no_grad():
             model.eval()
             f_inf = timeit(lambda: model(data), iters=5, warm=2)
             model.train()
-        rows.append((f"training step (fwd with tape + match & pose loss + backward), {Bt} pairs x {Nt}, 18 layers, 100 iterations", timeit(step, iters=3, warm=1)))
+        rows.append((f"training step (weights re-commit + fwd with tape + match & pose loss + backward + SGD step), {Bt} pairs x {Nt}, 18 layers, 100 iterations", timeit(step, iters=3, warm=1)))
         rows.append((f"  for comparison: inference forward of the same batch", f_inf))
     print("| stage | ms |\n|---|---|")
     for k, v in rows:

@@ -1,5 +1,7 @@
-"""Prints the score / index margins of the three arithmetic modes against the CPU oracle (fp32 and fp64) on one 18-layer
-problem - the numbers quoted in DESIGN.md.  GPU box only (the oracle is used as the checker)."""
+"""Prints the score / index / descriptor margins of the arithmetic modes against the CPU oracle (fp32 and fp64) on 18-layer
+problems at BASELINE configs[1]'s size (1024 keypoints, 100 Sinkhorn iterations) - the numbers quoted in DESIGN.md.  logZ is
+dominated by the fp32 Sinkhorn; the matched descriptors (e2emv_get_descriptors) are where the GNN arithmetic shows.  GPU box
+only (the oracle is used as the checker)."""
 import os
 import sys
 
@@ -17,7 +19,9 @@ def main():
     from test_gpu_matcher import _randomize_bn
     gpu = torch.device("cuda", 0)
     _lib.context(gpu).set_split_min_rows(0)
-    for name, w_id, n in (("random weights", False, 512), ("identity-like weights (matches found)", True, 512)):
+    from e2e_multi_view_matching_amd import last_descriptors
+    n_ = int(os.environ.get("PARITY_N", "1024"))
+    for name, w_id, n in (("random weights", False, n_), ("identity-like weights (matches found)", True, n_)):
         torch.manual_seed(5)
         cfg = {"sinkhorn_iterations": 100, "conf_mlp": True, "match_threshold": 0.0}
         model = MultiViewMatcher(cfg).eval()
@@ -42,17 +46,27 @@ def main():
             z32, z64 = ref32["scores_0_1"], ref64["scores_0_1"]
             print(f"   oracle fp32 vs fp64: max |dZ| {float((z32.double() - z64).abs().max()):.2e}  index mismatches "
                   f"{int((ref32['matches0_0_1'] != ref64['matches0_0_1']).sum())}")
-        for precision in ("f32", "bf16x3", "f16x2"):
+        Dm = ref32["_mdesc"][0].shape[1]  # the oracle keeps [B, D, N] per image; the library [image g = b * T + t][N][D]
+        md32 = torch.stack([m.transpose(1, 2) for m in ref32["_mdesc"]], 1).reshape(-1, n, Dm)
+        md64 = torch.stack([m.transpose(1, 2) for m in ref64["_mdesc"]], 1).reshape(-1, n, Dm) if ref64 is not None else None
+        scale = float(md32.abs().max())
+        if md64 is not None:
+            print(f"   descriptors: max |mdesc| {scale:.3f}; oracle fp32 vs fp64 max |d| {float((md32.double() - md64).abs().max()):.2e}")
+        for precision in ("f32", "bf16x3", "f16x2", "f16x2-r3"):
             model.config["mfma_precision"] = precision
             with torch.no_grad():
                 out = model(dg)
+            md = last_descriptors(gpu).cpu()
             z = out["scores_0_1"].cpu()
             line = f"   {precision:7s} vs oracle fp32: max |dZ| {float((z - ref32['scores_0_1']).abs().max()):.2e}  index mismatches " \
                    f"{int((out['matches0_0_1'].cpu() != ref32['matches0_0_1']).sum())}"
             if ref64 is not None:
                 line += f" | vs fp64: max |dZ| {float((z.double() - ref64['scores_0_1']).abs().max()):.2e}  index mismatches " \
                         f"{int((out['matches0_0_1'].cpu() != ref64['matches0_0_1']).sum())}"
-            print(line + f"  matched {int((out['matches0_0_1'] >= 0).sum())}")
+            line += f"  matched {int((out['matches0_0_1'] >= 0).sum())} | descriptors vs fp32 {float((md - md32).abs().max()):.2e}"
+            if md64 is not None:
+                line += f" vs fp64 {float((md.double() - md64).abs().max()):.2e} (rms {float((md.double() - md64).pow(2).mean().sqrt()):.2e})"
+            print(line)
 
 
 if __name__ == "__main__":
