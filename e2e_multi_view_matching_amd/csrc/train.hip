@@ -276,7 +276,7 @@ extern "C" int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     }
     train_free(ctx);
     ctx->train = t;
-    const int D = m->desc_dim, H = m->num_heads, d = D / H;
+    const int d = D / H;
     E2EMV_HIP(ctx, hipMalloc((void**)&t->d_w, t->w_floats * sizeof(float)));
     E2EMV_HIP(ctx, hipMalloc((void**)&t->d_gw, t->w_floats * sizeof(float)));
     E2EMV_HIP(ctx, hipMalloc((void**)&t->d_raw, t->raw_floats * sizeof(float)));
