@@ -61,6 +61,19 @@ struct GemmP2Params {
     long long* dbg;  // E2EMV_STAMPS builds only: phase timestamps of two workgroups
 };
 
+// MFMAs of the pipelined K step as asm statements (order = source order; see compute_p below)
+__device__ __forceinline__ void gp_mfma(p2_f32x16& c, p2_f16x8 a, p2_f16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void gp_mfma0(p2_f32x16& c, p2_f16x8 a, p2_f16x8 b) {  // zero C operand: the first product of a tile
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ unsigned gp_pk_mul(unsigned x, unsigned k) {  // two fp16 products (2^-11 w_hi)
+    unsigned d;
+    asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(d) : "v"(x), "v"(k));
+    return d;
+}
+
 // DBG (instantiated only in -DE2EMV_STAMPS builds, tools/p2_stamps.py): 1 no MFMA, 2 no operand loads after the first two K
 // steps, 4 no epilogue, 8 s_memtime stamps per K step, 16 loads of step g + 1 issued one per MFMA group, 32 every wave issues
 // its loads before it computes (no opposite orders on a SIMD), 256 vmcnt(0) at every step (no store overlap)
@@ -178,6 +191,65 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         }
     };
 
+    // ---- the same K step, software-pipelined inside the wave (the default; `compute` above is kept for the measurement
+    // build's ablations).  hipcc's schedule of `compute` reads a group's weight fragments right in front of its MFMAs and
+    // waits for them at once (lgkmcnt(0) behind the ds_reads): every group of 6 MFMAs opened with an exposed LDS round trip
+    // that only the SIMD's other wave could fill.  Here the 8 groups of a step (2 k-halves x 4 weight row blocks) run as one
+    // stream: the fragments of group g + 1 (and the activation fragments of the next k-half) are read under the MFMAs of
+    // group g, the four v_pk_mul_f16 that make 2^-11 w_hi sit behind the group's first MFMA; MFMAs and multiplies are asm
+    // statements (source order = machine order, fenced per slot), so the distances the hardware needs are kept by
+    // placement: multiplies -> the MFMA that reads them: one MFMA and two ds_reads apart.
+    auto compute_p = [&](int buf, auto FIRST) {
+        constexpr bool first_step = decltype(FIRST)::value;
+        const char* xs = smem_p2 + buf * P2_BUFB + (wr * 64 + l31) * P2_ROWB;
+        const char* ws = smem_p2 + buf * P2_BUFB + P2_TILEB + (wc * 128 + l31) * P2_ROWB;
+        auto rd_x = [&](int ks, int t, int pl) { return *reinterpret_cast<const p2_f16x8*>(xs + t * 32 * P2_ROWB + (((4 * pl + 2 * ks + lh) ^ swz) << 4)); };
+        auto rd_w = [&](int ks, int j, int pl) { return *reinterpret_cast<const p2_f16x8*>(ws + j * 32 * P2_ROWB + (((4 * pl + 2 * ks + lh) ^ swz) << 4)); };
+        p2_f16x8 xb[2][2][2];  // [k-half parity][row block][plane]
+        p2_f16x8 wb[2][2];     // [group parity][plane]
+        unsigned k2048 = 0x10001000u;  // two fp16 2^-11
+        asm volatile("" : "+v"(k2048));
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) xb[0][t][pl] = rd_x(0, t, pl);
+        wb[0][1] = rd_w(0, 0, 1);
+        wb[0][0] = rd_w(0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int ks = g >> 2, j = g & 3, gp = g & 1;
+            const p2_u32x4 wh = __builtin_bit_cast(p2_u32x4, wb[gp][0]);
+            p2_u32x4 w2u;
+            const bool z = first_step && ks == 0;
+            // slot 0: x_hi w_lo of row block 0; then 2^-11 w_hi
+            if (z) gp_mfma0(acc[j][0], wb[gp][1], xb[ks][0][0]); else gp_mfma(acc[j][0], wb[gp][1], xb[ks][0][0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w2u[e] = gp_pk_mul(wh[e], k2048);
+            __builtin_amdgcn_sched_barrier(0);
+            // slot 1: x_hi w_lo of row block 1; the next group's weight fragments
+            if (z) gp_mfma0(acc[j][1], wb[gp][1], xb[ks][1][0]); else gp_mfma(acc[j][1], wb[gp][1], xb[ks][1][0]);
+            if (g < 7) {
+                wb[gp ^ 1][1] = rd_w((g + 1) >> 2, (g + 1) & 3, 1);
+                wb[gp ^ 1][0] = rd_w((g + 1) >> 2, (g + 1) & 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const p2_f16x8 w2 = __builtin_bit_cast(p2_f16x8, w2u);
+            // slots 2, 3: x_lo' (2^-11 w_hi); the next k-half's activation fragments behind them (groups 2 and 3)
+            gp_mfma(acc[j][0], w2, xb[ks][0][1]);
+            if (ks == 0 && j == 2) { xb[1][0][0] = rd_x(1, 0, 0); xb[1][1][0] = rd_x(1, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            gp_mfma(acc[j][1], w2, xb[ks][1][1]);
+            if (ks == 0 && j == 3) { xb[1][0][1] = rd_x(1, 0, 1); xb[1][1][1] = rd_x(1, 1, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            // slots 4, 5: x_hi w_hi
+            gp_mfma(acc[j][0], wb[gp][0], xb[ks][0][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            gp_mfma(acc[j][1], wb[gp][0], xb[ks][1][0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     // ---- epilogue (see the header).  Each wave owns ONE slab of 32 rows x 32 floats behind the two tile buffers (16-byte
     // chunk c of row r at position c ^ (r & 7): conflict-free b128 writes, 2-way reads).  The 8 blocks (32 rows x 32
     // columns) of a wave are software-pipelined through registers: block b + 1 goes through the slab and its residual
@@ -189,6 +261,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
     //     instead of being skipped), so the K loop of the next tile can wait with a COUNTED vmcnt for its operand loads,
     //     which were issued before these stores, and leave the stores in flight (see the pipeline below).
     auto epilogue = [&](int t, int e_run, int ev) {
+        asm volatile("s_nop 15");  // (the last step's asm MFMAs -> their first VALU readers below)
         char* sl = smem_p2 + 2 * P2_BUFB + wave * P2_SLABB;
         const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
         const int o_r = lane >> 2, o_c = (lane & 3) * 8;  // row-contiguous view: 16 rows per pass, 8 columns per lane
@@ -480,6 +553,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         if (has_e) {
             const int e_step = p.EA ? __builtin_amdgcn_readlane(ev, cur_kt >> 1) : 0;
             if (!decltype(FIRST)::value && e_step != e_run) {
+                asm volatile("s_nop 15");  // (the previous step's asm MFMAs -> the VALU below: hipcc does not pad an asm's results)
                 const int d = e_run - e_step;
                 const float f = d < -126 ? 0.f : p2_exp2i(d);
 #pragma unroll
@@ -503,7 +577,8 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         ++dbg_steps;
         if (!(DBG & 16) && issue_first && ldv) issue(buf ^ 1, ld_kt, 0u);
         if (DBG & 8) t2 = clock64();
-        compute(buf, FIRST, (DBG & 16) && ldv, buf ^ 1, ld_kt);  // ONE call site: two would double the accumulator live ranges
+        if constexpr (DBG == 0) compute_p(buf, FIRST);
+        else compute(buf, FIRST, (DBG & 16) && ldv, buf ^ 1, ld_kt);  // ONE call site: two would double the accumulator live ranges
         if (!(DBG & 16) && !issue_first && ldv) {
             unsigned dep = 0;
             if (!(DBG & 1)) asm("" : "+v"(dep) : "v"(acc[3][1]));  // scheduling-only: keeps the loads behind the MFMAs
