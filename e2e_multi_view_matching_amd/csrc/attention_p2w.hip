@@ -443,14 +443,19 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
         //   slot 3k      x0 = S sinv + e0            lo(k-1).lo = p0 - hi     x1 = S sinv + e0
         //   slot 3k + 1  p0 = exp2 x0                lo(k-1).hi = p1 - hi     p1 = exp2 x1
         //   slot 3k + 2  psA += p0                   hi(k) = (fp16 p0, p1)    psB += p1
+        bool slow = false;
         float xa[16][2], pa[16][2], psA = 0.f, psB = 0.f, sinv_v = sinv;
         asm volatile("" : "+v"(sinv_v), "+v"(e0));
         unsigned hi_k[16], lo_k[16];
         auto micro = [&](auto MM) __attribute__((always_inline)) {
             constexpr int m = decltype(MM)::value;
             constexpr int k = m / 3, ph = m % 3;
-            constexpr int kb = k >> 3, r = 2 * (k & 7);
-            if constexpr (ph == 0) {
+            constexpr int kb = (k & 15) >> 3, r = 2 * (k & 7);
+            if constexpr (m == 48) {         // the last pair's low plane, first half
+                lo_k[15] = aw_mixlo(hi_k[15], pa[15][0]);
+            } else if constexpr (m == 49) {  // ... second half
+                Pf[B][1][3][3] = aw_mixhi(lo_k[15], hi_k[15], pa[15][1]);
+            } else if constexpr (ph == 0) {
                 xa[k][0] = aw_fma((ABL & 64) ? e0 : S[B][kb][r], sinv_v, e0);  // (ABL 64: the softmax does not read MFMA results)
                 if constexpr (k > 0) lo_k[k - 1] = aw_mixlo(hi_k[k - 1], pa[k - 1][0]);
                 xa[k][1] = aw_fma((ABL & 64) ? e0 : S[B][kb][r + 1], sinv_v, e0);
@@ -494,9 +499,25 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
                 if constexpr (s == 0 && q == 0) aw_mfma_s0(S[A][kb], F[(4 + s) & 3][2 * kb + PA[q]], Qf[A][PB[q]][s]);
                 else aw_mfma_s(S[A][kb], F[(4 + s) & 3][2 * kb + PA[q]], Qf[A][PB[q]][s]);
             }
-            // (2) the other stream's softmax
+            // (2) the other stream's softmax.  A full segment runs its 50 micro-steps in slots 0 .. 41 (two per slot in the first
+            // eight), sums up in slot 42 and evaluates the range check in slot 43 - INSIDE the stream: behind the last MFMA of a
+            // segment comes one branch on a scalar flag and the first MFMA of the next, not the tail of a softmax (measured:
+            // ~300 cycles of idle matrix pipe per segment boundary).
             if constexpr (HAS_SM && !(ABL & 1)) {
-                aw_for<0, MPS>([&](auto JJ) __attribute__((always_inline)) { micro(std::integral_constant<int, MPS * i + decltype(JJ)::value>{}); });
+                if constexpr (LAST) {
+                    aw_for<0, MPS>([&](auto JJ) __attribute__((always_inline)) { micro(std::integral_constant<int, MPS * i + decltype(JJ)::value>{}); });
+                } else if constexpr (i < 8) {
+                    micro(std::integral_constant<int, 2 * i>{});
+                    micro(std::integral_constant<int, 2 * i + 1>{});
+                } else if constexpr (i < 42) {
+                    micro(std::integral_constant<int, i + 8>{});
+                } else if constexpr (i == 42) {
+                    ps = psA;
+                    aw_acc(ps, psB);
+                } else if constexpr (i == 43) {
+                    slow = (ABL & 28) == 28 ? false : (__builtin_amdgcn_ballot_w64(!(ps < AW_LIMIT)) != 0 || valid < 64);
+                    l_run[B] += slow ? 0.f : ps;
+                }
             }
             // (3) the tile's barrier (segment Y only, head of group 6): the pieces issued in X(j) have landed, everybody's; nobody
             // reads region j % 3 any more (the fragments of this segment's last groups were read in slots 25..34)
@@ -544,19 +565,24 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
             }
         }
 
-        if constexpr (HAS_SM && !(ABL & 1)) {
-            // the last pair's split, then the range check of the fast path
+        if constexpr (HAS_SM && LAST && !(ABL & 1)) {
+            // (the peeled last tile: its softmax ran two micro-steps per slot over 24 slots; split of the last pair and the range
+            // check behind the stream)
             lo_k[15] = aw_mixlo(hi_k[15], pa[15][0]);
             ps = psA + psB;
             Pf[B][1][3][3] = aw_mixhi(lo_k[15], hi_k[15], pa[15][1]);
-            // one wave-uniform branch, taken (almost) never: the fast path adds its sum without one
-            const bool slow = (ABL & 28) == 28 ? false : (__builtin_amdgcn_ballot_w64(!(ps < AW_LIMIT)) != 0 || valid < 64);
+            const bool slow = __builtin_amdgcn_ballot_w64(!(ps < AW_LIMIT)) != 0 || valid < 64;
             l_run[B] += slow ? 0.f : ps;
             if (__builtin_expect(slow, 0)) {
                 sm_slow(std::integral_constant<int, B>{}, sinv, valid);
                 if (p.stats && lane == 0) atomicAdd(p.stats, 1u);
             }
-            asm volatile("s_nop 1");  // (aw_lo's result -> the next segment's first MFMAs)
+        }
+        if constexpr (HAS_SM && !LAST && !(ABL & 1)) {
+            if (__builtin_expect(slow, 0)) {  // (out of line: the fast path falls through)
+                sm_slow(std::integral_constant<int, B>{}, sinv, valid);
+                if (p.stats && lane == 0) atomicAdd(p.stats, 1u);
+            }
         }
         if (A == 0) cur_next(cS);  // X used tile j, Y uses tile j + 1
     };
