@@ -499,22 +499,25 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
                 if constexpr (s == 0 && q == 0) aw_mfma_s0(S[A][kb], F[(4 + s) & 3][2 * kb + PA[q]], Qf[A][PB[q]][s]);
                 else aw_mfma_s(S[A][kb], F[(4 + s) & 3][2 * kb + PA[q]], Qf[A][PB[q]][s]);
             }
-            // (2) the other stream's softmax.  A full segment runs its 50 micro-steps in slots 0 .. 41 (two per slot in the first
-            // eight), sums up in slot 42 and evaluates the range check in slot 43 - INSIDE the stream: behind the last MFMA of a
+            // (2) the other stream's softmax.  A full segment runs its 50 micro-steps in slots 0 .. 45 (two in four of the first
+            // nine), sums up in slot 46 and evaluates the range check in slot 47 - INSIDE the stream: behind the last MFMA of a
             // segment comes one branch on a scalar flag and the first MFMA of the next, not the tail of a softmax (measured:
             // ~300 cycles of idle matrix pipe per segment boundary).
             if constexpr (HAS_SM && !(ABL & 1)) {
                 if constexpr (LAST) {
                     aw_for<0, MPS>([&](auto JJ) __attribute__((always_inline)) { micro(std::integral_constant<int, MPS * i + decltype(JJ)::value>{}); });
-                } else if constexpr (i < 8) {
-                    micro(std::integral_constant<int, 2 * i>{});
-                    micro(std::integral_constant<int, 2 * i + 1>{});
-                } else if constexpr (i < 42) {
-                    micro(std::integral_constant<int, i + 8>{});
-                } else if constexpr (i == 42) {
+                } else if constexpr (i < 9) {
+                    // slots 2, 4, 6, 8 take two micro-steps: the sums / high plane of a pair and the first step of the next pair
+                    // (independent of each other but for the mixlo, which reads the high plane formed two instructions before)
+                    constexpr int m0 = i + i / 2 - (i > 0 && i % 2 == 0 ? 1 : 0);  // 0 1 2 4 5 7 8 10 11
+                    micro(std::integral_constant<int, m0>{});
+                    if constexpr (i >= 2 && i % 2 == 0) micro(std::integral_constant<int, m0 + 1>{});
+                } else if constexpr (i < 46) {
+                    micro(std::integral_constant<int, i + 4>{});
+                } else if constexpr (i == 46) {
                     ps = psA;
                     aw_acc(ps, psB);
-                } else if constexpr (i == 43) {
+                } else if constexpr (i == 47) {
                     slow = (ABL & 28) == 28 ? false : (__builtin_amdgcn_ballot_w64(!(ps < AW_LIMIT)) != 0 || valid < 64);
                     l_run[B] += slow ? 0.f : ps;
                 }

@@ -199,8 +199,32 @@ class MultiViewMatcher(nn.Module):
 
     # ------------------------------------------------------------------ weights -> library
     def _fingerprint(self):
-        sd = self.state_dict()
-        return tuple((k, v.data_ptr(), v._version) for k, v in sd.items() if v.dtype.is_floating_point)
+        # (storage, version) of every floating-point tensor: what the library's committed copy is compared with on every call.
+        # The tensor list is kept (state_dict() alone costs ~0.2 ms per call - a tenth of a batch-1 forward); anything that can
+        # replace tensor OBJECTS (.to() / .cuda() / .float() go through _apply, load_state_dict may assign) drops it.
+        t = self.__dict__.get("_fp_tensors")
+        if t is None:
+            t = [(k, v) for k, v in self.state_dict(keep_vars=True).items() if v.dtype.is_floating_point]
+            self.__dict__["_fp_tensors"] = t
+        return tuple((k, v.data_ptr(), v._version) for k, v in t)
+
+    def invalidate_weight_cache(self):
+        """Call after replacing a parameter / buffer OBJECT somewhere inside the module tree by hand (in-place updates -
+        optimiser steps, copy_, load_state_dict - and .to() / .cuda() are seen without it)."""
+        self.__dict__["_fp_tensors"] = None
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (torch.Tensor, nn.Module)):
+            self.__dict__["_fp_tensors"] = None
+        super().__setattr__(name, value)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__["_fp_tensors"] = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__["_fp_tensors"] = None
+        return super().load_state_dict(*args, **kwargs)
 
     def _model_desc(self):
         cfg = self.config
