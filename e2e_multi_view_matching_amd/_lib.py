@@ -222,7 +222,7 @@ class Context:
         """{'rescaled_blocks': plane blocks that needed a non-zero tile exponent, 'sinkhorn_bad': Sinkhorn problems with
         non-finite scores, 'sinkhorn_rescued': problems re-solved in the log domain behind the resident kernel (correct
         outputs), 'attention_slow_tiles': (wave, stream, key tile) softmaxes attention_p2w redid on its slow path - a row
-        maximum outgrew the running one by more than ~2^9, or a ragged last tile} since the last reset (host-synchronising)."""
+        maximum outgrew the running one by more than ~2^9} since the last reset (host-synchronising)."""
         v = (ctypes.c_uint64 * 5)()
         self.call("e2emv_get_stats", v, 5, 1 if reset else 0)
         return {"rescaled_blocks": int(v[0]), "sinkhorn_bad": int(v[1]), "sinkhorn_rescued": int(v[2]), "attention_slow_tiles": int(v[3]),

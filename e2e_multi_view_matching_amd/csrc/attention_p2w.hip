@@ -266,6 +266,8 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
     float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
     int e_o = 0;
     bool o_started = false;
+    unsigned n_slow = 0;  // softmaxes this wave redid on the slow path (one atomic per wave behind the epilogue: an atomic per
+                          // event sat in the loop's in-order memory queue - 8192 of them on one address cost a ragged launch 45 us)
 
     // ---- slow path of a tile's softmax (first tile; a tile whose fast-path sum left fp16's range): true row maximum, O and l
     // of the stream rescaled, numerators against the new maximum
@@ -337,7 +339,12 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
     // one queue, in issue order: exponents, Q fragments, K(0) | V(0), K(1) | V(1), K(2).  The first scores need the first three:
     // the 16 youngest pieces stay in flight (every workgroup of the chip starts at the same time: the prologue's loads are a
     // 37 MB burst, its tail lands under the first scores and the first softmax)
-    aw_wait_q(Qf);
+    if constexpr ((ABL & 256) != 0) {  // measurement (wrong results): what the prologue's wait for Q / K(0) costs a launch
+        asm volatile("s_waitcnt vmcnt(63)" : "+a"(Qf[0][0][0]), "+a"(Qf[0][0][1]), "+a"(Qf[0][0][2]), "+a"(Qf[0][0][3]), "+a"(Qf[0][1][0]), "+a"(Qf[0][1][1]), "+a"(Qf[0][1][2]), "+a"(Qf[0][1][3]),
+                     "+a"(Qf[1][0][0]), "+a"(Qf[1][0][1]), "+a"(Qf[1][0][2]), "+a"(Qf[1][0][3]), "+a"(Qf[1][1][0]), "+a"(Qf[1][1][1]), "+a"(Qf[1][1][2]), "+a"(Qf[1][1][3]) :: "memory");
+    } else {
+        aw_wait_q(Qf);
+    }
     __syncthreads();
     p2_u32x2 e_pair = {0u, 0u};  // {e_k, e_v} of the tile whose exponents are needed next (all lanes equal)
     if constexpr (HAS_E) e_pair = read_e(0);
@@ -367,7 +374,8 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
             }
         // K(0) sits where X(0) puts K(3): everybody is through with it before anybody's pieces go out; and
         // V(0) | K(1) have landed, everybody's (8 pieces - V(1) | K(2) - may still be in flight: the barrier of tile 0 waits for them)
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr ((ABL & 256) != 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         sm_slow(std::integral_constant<int, 0>{}, sinv, cS.nv - cS.kt * 64);
         // stream 1's first tile takes the fast path in X(0): its running maximum starts at the tile's row maxima (a ragged
         // first tile is left to the slow path, which masks)
@@ -436,7 +444,18 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
             if (HAS_E) sinv = AW_SINV * p2_exp2i(e_q + __builtin_amdgcn_readfirstlane((int)e_pair[0]));
             if (HAS_E && A == 0 && !LAST) e_pair = read_e(seg_tile + 1);
             e0 = AW_PLOG - m_run[B];
-            valid = cS.nv - cS.kt * 64;  // a ragged tile (valid < 64) is redone on the slow path, which masks
+            valid = cS.nv - cS.kt * 64;
+        }
+        // a ragged tile (the last one of a source with nv % 64 != 0): scores of the keys beyond nv to -inf in front of the
+        // fast path (p = 0; the S of this stream are a segment old: no MFMA in flight writes them)
+        if (HAS_SM && !(ABL & 1) && __builtin_expect(valid < 64, 0)) {
+            asm volatile("s_nop 7" : "+v"(S[B][0]), "+v"(S[B][1]));
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= valid) S[B][kb][r] = -INFINITY;
+            asm volatile("" : "+v"(S[B][0]), "+v"(S[B][1]));
         }
         // fast-path softmax of the tile, 3 instructions per slot, ordered so that NO instruction reads the result of one of the
         // two before it (one wave per SIMD: a dependent pair stalls the issue, nobody fills the gap) - pair k = scores 2k, 2k + 1:
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
                     ps = psA;
                     aw_acc(ps, psB);
                 } else if constexpr (i == 47) {
-                    slow = (ABL & 28) == 28 ? false : (__builtin_amdgcn_ballot_w64(!(ps < AW_LIMIT)) != 0 || valid < 64);
+                    slow = ((ABL & 28) == 28 || (ABL & 512)) ? false : __builtin_amdgcn_ballot_w64(!(ps < AW_LIMIT)) != 0;
                     l_run[B] += slow ? 0.f : ps;
                 }
             }
@@ -574,17 +593,17 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
             lo_k[15] = aw_mixlo(hi_k[15], pa[15][0]);
             ps = psA + psB;
             Pf[B][1][3][3] = aw_mixhi(lo_k[15], hi_k[15], pa[15][1]);
-            const bool slow = __builtin_amdgcn_ballot_w64(!(ps < AW_LIMIT)) != 0 || valid < 64;
+            const bool slow = __builtin_amdgcn_ballot_w64(!(ps < AW_LIMIT)) != 0;
             l_run[B] += slow ? 0.f : ps;
             if (__builtin_expect(slow, 0)) {
                 sm_slow(std::integral_constant<int, B>{}, sinv, valid);
-                if (p.stats && lane == 0) atomicAdd(p.stats, 1u);
+                ++n_slow;
             }
         }
         if constexpr (HAS_SM && !LAST && !(ABL & 1)) {
             if (__builtin_expect(slow, 0)) {  // (out of line: the fast path falls through)
                 sm_slow(std::integral_constant<int, B>{}, sinv, valid);
-                if (p.stats && lane == 0) atomicAdd(p.stats, 1u);
+                ++n_slow;
             }
         }
         if (A == 0) cur_next(cS);  // X used tile j, Y uses tile j + 1
@@ -629,6 +648,7 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
                 }
             }
     }
+    if (p.stats && n_slow && lane == 0) atomicAdd(p.stats, n_slow);
     stamp();  // 12: stores issued
     if constexpr ((ABL & 32) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -659,7 +679,9 @@ int launch_attention_p2w(e2emv_ctx* ctx, AttnP2Params& p, int n_valid, hipStream
         case 11: fn = reinterpret_cast<const void*>(attention_p2w_kernel<true, 92, false>); break;   // ... the softmax fed from a constant
         case 10: fn = reinterpret_cast<const void*>(attention_p2w_kernel<true, 30, false>); break;   // softmax only
         case 14: fn = reinterpret_cast<const void*>(attention_p2w_kernel<true, 32, false>); break;  // timestamps
-        case 9: fn = reinterpret_cast<const void*>(attention_p2w_kernel<true, 160, false>); break;  // ... and inside the segments of tile 2
+        case 9: fn = reinterpret_cast<const void*>(attention_p2w_kernel<true, 160, false>); break;
+        case 7: fn = reinterpret_cast<const void*>(attention_p2w_kernel<true, 256 + 512, false>); break;  // no wait for Q / K(0) in the prologue, never the slow path
+        case 6: fn = reinterpret_cast<const void*>(attention_p2w_kernel<true, 512, false>); break;        // never the slow path (the arm to compare it with)  // ... and inside the segments of tile 2
         default: break;
     }
     static long long* d_stamps = nullptr;

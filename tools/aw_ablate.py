@@ -37,8 +37,9 @@ if "--stamps" in sys.argv:
     sys.exit(0)
 NAMES = {0: "full", 1: "no softmax", 2: "no MFMA", 3: "no softmax, no MFMA", 4: "no fragment reads", 5: "no softmax, no fragment reads",
          8: "no LDS-direct loads", 13: "MFMAs only (no softmax / reads / loads)", 16: "no barrier", 15: "MFMAs only, no barrier", 12: "MFMAs + softmax only (no reads / loads / barrier)",
-         11: "MFMAs + softmax fed from a constant only", 10: "softmax only"}
-ORDER = (0, 1, 2, 3, 4, 5, 8, 13, 16, 15, 12, 11, 10)
+         11: "MFMAs + softmax fed from a constant only", 10: "softmax only",
+         6: "full, never the slow path", 7: "... and no wait for Q / K(0) in the prologue"}
+ORDER = (0, 1, 2, 3, 4, 5, 8, 13, 16, 15, 12, 11, 10, 6, 7)
 best = {}
 for rnd in range(3):  # the clock moves with what ran before: every variant in every round, the minimum counts
     for abl in ORDER:
