@@ -74,6 +74,66 @@ __device__ __forceinline__ unsigned gp_pk_mul(unsigned x, unsigned k) {  // two 
     return d;
 }
 
+// ---- epilogue arithmetic, one instruction where hipcc needs several (the epilogue of a tile is ~1000 VALU instructions per
+// wave with the matrix pipe idle: its instruction count is its time)
+// max(a, |x|, |y|): fmaxf(fabsf()) compiles to a canonicalising v_max_f32 |x|, |x| per value in front of the maximum
+__device__ __forceinline__ float gp_amax3(float a, float x, float y) {
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(a) : "v"(x), "v"(y));
+    return a;
+}
+// ReLU of 8 values as x <- x + |x| = 2 max(x, 0), in place, skipped when `on` is 0 - ONE statement with the branch inside: a
+// source-level `if` around in-place updates makes hipcc copy all 8 registers on both arms (12 v_mov per arm), a select
+// costs 2 instructions per value.  NaN stays NaN (ReLU must not hide one: common.h relu_nan; -inf, which has no finite
+// origin, turns NaN instead of 0); the factor 1/2 goes into the scale that follows (a power of two: exact)
+__device__ __forceinline__ void gp_relu2x8(p2_f32x4& v0, p2_f32x4& v1, int on) {
+    float a = v0[0], b = v0[1], c = v0[2], d = v0[3], e = v1[0], f = v1[1], g = v1[2], h = v1[3];
+    asm("s_cmp_eq_u32 %8, 0\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "v_add_f32_e64 %0, %0, |%0|\n\t"
+        "v_add_f32_e64 %1, %1, |%1|\n\t"
+        "v_add_f32_e64 %2, %2, |%2|\n\t"
+        "v_add_f32_e64 %3, %3, |%3|\n\t"
+        "v_add_f32_e64 %4, %4, |%4|\n\t"
+        "v_add_f32_e64 %5, %5, |%5|\n\t"
+        "v_add_f32_e64 %6, %6, |%6|\n\t"
+        "v_add_f32_e64 %7, %7, |%7|\n"
+        "1:"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "s"(on) : "scc");
+    v0 = p2_f32x4{a, b, c, d};
+    v1 = p2_f32x4{e, f, g, h};
+}
+// fp32 values of a pair of scaled-plane elements, hi + 2^-11 lo' (exact), straight from the packed halves
+__device__ __forceinline__ p2_f32x2 gp_join_scaled(unsigned hi, unsigned lo) {
+    float x0, x1;
+    asm("v_fma_mix_f32 %0, %2, %4, %3 op_sel_hi:[1,0,1]\n\tv_fma_mix_f32 %1, %2, %4, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]"
+        : "=&v"(x0), "=&v"(x1) : "v"(lo), "v"(hi), "s"(1.f / 2048.f));
+    return {x0, x1};
+}
+// 8 values -> 4 + 4 packed plane words.  a = the values, b = 2048 a (scaled planes; both products of ONE fp32 value with
+// powers of two) or b = a (plain planes, K = -1): hi = fp16(a), lo = fp16(b - K' hi) with K' = 2048 or 1
+template <bool SCALED>
+__device__ __forceinline__ void gp_split8(const p2_f32x4& a0, const p2_f32x4& a1, const p2_f32x4& b0, const p2_f32x4& b1, p2_u32x4& hi, p2_u32x4& lo) {
+    const p2_f32x2 q0 = {a0[0], a0[1]}, q1 = {a0[2], a0[3]}, q2 = {a1[0], a1[1]}, q3 = {a1[2], a1[3]};
+    const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(q0, p2_f16x2)), h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(q1, p2_f16x2));
+    const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_convertvector(q2, p2_f16x2)), h3 = __builtin_bit_cast(unsigned, __builtin_convertvector(q3, p2_f16x2));
+    unsigned l0, l1, l2, l3;
+    // (the four low words first, their high halves behind them: no v_fma_mixhi reads the word the instruction before it wrote)
+    asm("v_fma_mixlo_f16 %0, %4, %16, %8 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %5, %16, %10 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %6, %16, %12 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %7, %16, %14 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %4, %16, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %5, %16, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %6, %16, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %16, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(b0[0]), "v"(b0[1]), "v"(b0[2]), "v"(b0[3]), "v"(b1[0]), "v"(b1[1]), "v"(b1[2]), "v"(b1[3]),
+          "s"(SCALED ? -2048.f : -1.f));
+    hi = p2_u32x4{h0, h1, h2, h3};
+    lo = p2_u32x4{l0, l1, l2, l3};
+}
+
 // DBG (instantiated only in -DE2EMV_STAMPS builds, tools/p2_stamps.py): 1 no MFMA, 2 no operand loads after the first two K
 // steps, 4 no epilogue, 8 s_memtime stamps per K step, 16 loads of step g + 1 issued one per MFMA group, 32 every wave issues
 // its loads before it computes (no opposite orders on a SIMD), 256 vmcnt(0) at every step (no store overlap)
@@ -261,7 +321,9 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
     //     instead of being skipped), so the K loop of the next tile can wait with a COUNTED vmcnt for its operand loads,
     //     which were issued before these stores, and leave the stores in flight (see the pipeline below).
     auto epilogue = [&](int t, int e_run, int ev) {
-        asm volatile("s_nop 15");  // (the last step's asm MFMAs -> their first VALU readers below)
+        // (the last step's asm MFMAs -> their first VALU readers below: the accumulators pass through the statement, nothing that
+        // reads them moves above it)
+        asm volatile("s_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
         char* sl = smem_p2 + 2 * P2_BUFB + wave * P2_SLABB;
         const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
         const int o_r = lane >> 2, o_c = (lane & 3) * 8;  // row-contiguous view: 16 rows per pass, 8 columns per lane
@@ -273,7 +335,8 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         const int erow = tm * 4 + wr;
         float rsc[2] = {1.f, 1.f};   // 2^e of the residual blocks
         float osc[2] = {1.f, 1.f};   // 2^-e of the output blocks
-        float amx[2] = {0.f, 0.f};   // max |final value| of the output blocks (this lane's share)
+        float iosc[2] = {1.f, 1.f};  // 2^e
+        float amx[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // max |final value| of the output blocks (this lane's share, two chains)
         if ((OUT != P2_OUT_F32 && (p.EC || p.EVt)) || (HAS_R && p.ER)) {
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
@@ -288,17 +351,21 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                 rsc[ch] = p2_exp2i(er);
                 int* E = (OUT == P2_OUT_QKV && tn == 2) ? p.EVt : p.EC;
                 if (OUT == P2_OUT_F32 || !E) continue;
-                float am = 0.f;
+                float am = 0.f, am1 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(acc[2 * ch + jj][i][r]));
-                am = p2_wave_max(am);
+                        for (int r = 0; r < 16; r += 4) {
+                            am = gp_amax3(am, acc[2 * ch + jj][i][r], acc[2 * ch + jj][i][r + 1]);
+                            am1 = gp_amax3(am1, acc[2 * ch + jj][i][r + 2], acc[2 * ch + jj][i][r + 3]);
+                        }
+                am = p2_wave_max(fmaxf(am, am1));
                 const float bound = am * os + p.bias_amax + ar;
                 const int e = p2_pick_exponent(bound * cs);
                 osc[ch] = p2_exp2i(-e);
+                iosc[ch] = p2_exp2i(e);
                 const int ecb = (OUT == P2_OUT_QKV && tn == 2) ? wc * 2 + ch : cb;
                 const int eld = (OUT == P2_OUT_QKV && tn == 2) ? 4 : p.eld_c;
                 if (lane == 0 && erow * 64 < p.M && ecb < eld) {
@@ -338,12 +405,12 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                         }
                         const float b = (p.bias && n < p.N) ? p.bias[n] : 0.f;
                         p2_u32x4 hi, lo;
+                        // (v os + b) f with f = 16 x 2^-e: the power of two goes into both operands of ONE fma - the same value
+                        const float f = cs * osc[j >> 1], of = os * f, bf = b * f;
+                        p2_f32x4 w0, w1;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float f = cs * osc[j >> 1];
-                            const P2Pair pr = p2_split_plain((v[2 * e] * os + b) * f, (v[2 * e + 1] * os + b) * f);
-                            hi[e] = pr.hi; lo[e] = pr.lo;
-                        }
+                        for (int e = 0; e < 4; ++e) { w0[e] = __builtin_fmaf(v[e], of, bf); w1[e] = __builtin_fmaf(v[4 + e], of, bf); }
+                        gp_split8<false>(w0, w1, w0, w1, hi, lo);
                         const int img = m0 / p.n_rows, key0 = m0 - img * p.n_rows;
                         const int nv = n - 2 * P2_BN, head = nv >> 6, dd = nv & 63;
                         uint16_t* dst = p.Vt + ((int64_t)(img * p.heads + head) * 64 + dd) * (2 * (int64_t)p.n_rows) + (key0 >> 5) * 64 + q * 8;
@@ -370,12 +437,28 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         }
         p2_f32x4 rv[2][2][2];              // [parity][pass][half]: the block in the row-contiguous view
         p2_u32x4 rr[HAS_R ? 2 : 1][2][2];  // [parity][pass][plane]: its residual
+        // this lane's first row / column of the tile in the row-contiguous view; block (i, j), pass: row0 + 32 i + 16 pass,
+        // columns col0 + 32 j .. + 7.  Addresses = one per-tile base + wave-uniform steps (per-store index arithmetic in 64 bits
+        // was a tenth of the epilogue's instructions)
+        const int row0 = tm * P2_BM + wr * 64 + o_r, col0 = tn * P2_BN + wc * 128 + o_c;
+        const int rows_left = p.M - row0;  // row 32 i + 16 pass of the lane exists iff it is < rows_left
+        const int64_t rstep = (OUT == P2_OUT_F32 ? 16 : 32) * p.ldc;  // 16 rows further, in elements of the output
+        float* const c32_t = OUT == P2_OUT_F32 ? p.C32 + (int64_t)row0 * p.ldc + col0 : nullptr;
+        uint16_t* const cp_t = OUT == P2_OUT_F32 ? nullptr : p.Cp + p2_index(row0, col0, p.ldc);
+        // ReLU as x + |x| (gp_relu2): the factor 1/2 is folded into the plane scale where one follows directly
+        const bool relu = OUT != P2_OUT_QKV && p.relu;
+        const bool fold = relu && OUT == P2_OUT_PLANES && !HAS_R;
+        const float unfold = relu && !fold ? 0.5f : 1.f;
         auto stage = [&](auto BB) {  // block b -> slab -> registers; residual loads issued
             constexpr int b = decltype(BB)::value;
             constexpr int i = b >> 2, j = b & 3;
             slab_write(i, j);
-            const int n = tn * P2_BN + wc * 128 + j * 32 + o_c;
             if (HAS_R) load_bias(b & 1, j);
+            const uint16_t* rcol = nullptr;
+            if constexpr (HAS_R) {
+                const int nc = min(col0 + j * 32, p.N - 8);
+                rcol = p.Rp + ((nc >> 5) * 64 + (nc & 31));
+            }
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 const int r = o_r + 16 * pass;
@@ -383,8 +466,8 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
                 rv[b & 1][pass][0] = *reinterpret_cast<const p2_f32x4*>(sl + r * 128 + ((c0 ^ o_z) << 4));
                 rv[b & 1][pass][1] = *reinterpret_cast<const p2_f32x4*>(sl + r * 128 + (((c0 + 1) ^ o_z) << 4));
                 if constexpr (HAS_R) {
-                    const int m = min(tm * P2_BM + wr * 64 + i * 32 + r, p.M - 1);
-                    const uint16_t* rp = p.Rp + p2_index(m, min(n, p.N - 8), p.ldr);
+                    const int m = min(row0 + i * 32 + 16 * pass, p.M - 1);
+                    const uint16_t* rp = rcol + (int64_t)m * (2 * p.ldr);
                     rr[b & 1][pass][0] = *reinterpret_cast<const p2_u32x4*>(rp);
                     rr[b & 1][pass][1] = *reinterpret_cast<const p2_u32x4*>(rp + 32);
                 }
@@ -393,60 +476,60 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         auto finish = [&](auto BB) {
             constexpr int b = decltype(BB)::value;
             constexpr int i = b >> 2, j = b & 3;
-            const int m0 = tm * P2_BM + wr * 64 + i * 32;
-            const int n = tn * P2_BN + wc * 128 + j * 32 + o_c;
+            const bool col_ok = col0 + j * 32 < p.N;
+            // plane scale of the block (wave-uniform): 2^-e of its tile exponent (x the column scale of q / k), x 1/2 behind x + |x|
+            const float fa = OUT == P2_OUT_F32 ? 1.f : cs * osc[j >> 1] * (fold ? 0.5f : 1.f);
+            // scaled planes: fa is a power of two and goes into the operands of the first fma (the same values; ReLU and the
+            // residual sum commute with it) - the bias once per use of its registers, the accumulator scale as a uniform
+            float osf = os, rsf = 1.f;
+            if constexpr (HAS_R) rsf = rsc[j >> 1];
+            if constexpr (OUT == P2_OUT_PLANES) {
+                osf = os * fa;
+                rsf *= fa;
+                if (HAS_R || i == 0) { bias8[HAS_R ? (b & 1) : j][0] *= fa; bias8[HAS_R ? (b & 1) : j][1] *= fa; }
+            }
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
-                const int m = m0 + o_r + 16 * pass;
-                const bool ok = m < p.M && n < p.N;
-                p2_f32x4 v0 = rv[b & 1][pass][0] * os + bias8[HAS_R ? (b & 1) : j][0];
-                p2_f32x4 v1 = rv[b & 1][pass][1] * os + bias8[HAS_R ? (b & 1) : j][1];
-                if (OUT != P2_OUT_QKV && p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v0[e] = relu_nan(v0[e]); v1[e] = relu_nan(v1[e]); }
+                const bool ok = col_ok && i * 32 + 16 * pass < rows_left;
+                p2_f32x4 v0 = rv[b & 1][pass][0] * osf + bias8[HAS_R ? (b & 1) : j][0];
+                p2_f32x4 v1 = rv[b & 1][pass][1] * osf + bias8[HAS_R ? (b & 1) : j][1];
+                if constexpr (OUT != P2_OUT_QKV) {
+                    gp_relu2x8(v0, v1, p.relu);
+                    if constexpr (OUT == P2_OUT_F32 || HAS_R) { v0 *= unfold; v1 *= unfold; }  // (no plane scale to fold the 1/2 into)
                 }
                 if constexpr (HAS_R) {
                     const p2_u32x4 rh = rr[b & 1][pass][0], rl = rr[b & 1][pass][1];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const p2_f32x2 a = p2_join_scaled(rh[e], rl[e]), c = p2_join_scaled(rh[2 + e], rl[2 + e]);
-                        const float rs = rsc[j >> 1];
-                        v0[2 * e] += a[0] * rs; v0[2 * e + 1] += a[1] * rs;
-                        v1[2 * e] += c[0] * rs; v1[2 * e + 1] += c[1] * rs;
+                        const p2_f32x2 a = gp_join_scaled(rh[e], rl[e]), c = gp_join_scaled(rh[2 + e], rl[2 + e]);
+                        v0[2 * e] += a[0] * rsf; v0[2 * e + 1] += a[1] * rsf;
+                        v1[2 * e] += c[0] * rsf; v1[2 * e + 1] += c[1] * rsf;
                     }
                 }
-                if (OUT == P2_OUT_PLANES && p.AC && ok) {
-                    float a = amx[j >> 1];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a = fmaxf(a, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
-                    amx[j >> 1] = a;
+                if (OUT == P2_OUT_PLANES && p.AC && ok) {  // (of the values in the block's units, 2^-e: back to true units once, below)
+                    amx[j >> 1][0] = gp_amax3(amx[j >> 1][0], v0[0], v0[1]); amx[j >> 1][1] = gp_amax3(amx[j >> 1][1], v0[2], v0[3]);
+                    amx[j >> 1][0] = gp_amax3(amx[j >> 1][0], v1[0], v1[1]); amx[j >> 1][1] = gp_amax3(amx[j >> 1][1], v1[2], v1[3]);
                 }
                 if (OUT == P2_OUT_F32) {
-                    float* cp = ok ? p.C32 + (int64_t)m * p.ldc + n : reinterpret_cast<float*>(dummy);
-                    float* cq = (ok && n + 4 < p.N) ? cp + 4 : reinterpret_cast<float*>(dummy + 16);
+                    float* cp = c32_t + (2 * i + pass) * rstep + j * 32;
+                    float* cq = cp + 4;
+                    if (!ok) cp = reinterpret_cast<float*>(dummy);
+                    if (!(ok && col0 + j * 32 + 4 < p.N)) cq = reinterpret_cast<float*>(dummy + 16);
                     *reinterpret_cast<p2_f32x4*>(cp) = v0;
                     *reinterpret_cast<p2_f32x4*>(cq) = v1;
                 } else {
                     p2_u32x4 hi, lo;
-                    const float f = cs * osc[j >> 1];
                     if (OUT == P2_OUT_QKV) {
-                        v0 *= f; v1 *= f;
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const P2Pair a = p2_split_plain(v0[2 * e], v0[2 * e + 1]), c = p2_split_plain(v1[2 * e], v1[2 * e + 1]);
-                            hi[e] = a.hi; lo[e] = a.lo; hi[2 + e] = c.hi; lo[2 + e] = c.lo;
-                        }
+                        const p2_f32x4 a0 = v0 * fa, a1 = v1 * fa;  // (q: not a power of two - its own product)
+                        gp_split8<false>(a0, a1, a0, a1, hi, lo);
                     } else {
-                        if (f != 1.f) { v0 *= f; v1 *= f; }  // (wave-uniform; never taken inside the dead zone)
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const P2Pair a = p2_split_scaled(v0[2 * e], v0[2 * e + 1]), c = p2_split_scaled(v1[2 * e], v1[2 * e + 1]);
-                            hi[e] = a.hi; lo[e] = a.lo; hi[2 + e] = c.hi; lo[2 + e] = c.lo;
-                        }
+                        const p2_f32x4 b0 = v0 * 2048.f, b1 = v1 * 2048.f;
+                        gp_split8<true>(v0, v1, b0, b1, hi, lo);
                     }
-                    uint16_t* cp = ok ? p.Cp + p2_index(m, n, p.ldc) : reinterpret_cast<uint16_t*>(dummy);
+                    uint16_t* cp = cp_t + (2 * i + pass) * rstep + j * 64;
+                    if (!ok) cp = reinterpret_cast<uint16_t*>(dummy);
                     if (DBG & 64) { asm volatile("" :: "v"(hi), "v"(lo), "v"(cp)); continue; }          // measurement: no stores
-                    if (DBG & 128) cp = p.Cp + (p2_index(m, n, p.ldc) & ((1 << 19) - 1) & ~63ll);         // measurement: 1 MB target
+                    if (DBG & 128) cp = p.Cp + ((cp - p.Cp) & ((1 << 19) - 1) & ~63ll);                   // measurement: 1 MB target
                     *reinterpret_cast<p2_u32x4*>(cp) = hi;
                     *reinterpret_cast<p2_u32x4*>(cp + 32) = lo;
                 }
@@ -466,7 +549,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         if (OUT == P2_OUT_PLANES && p.AC) {
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
-                const float a = p2_wave_max(amx[ch]);
+                const float a = p2_wave_max(fmaxf(amx[ch][0], amx[ch][1])) * iosc[ch];
                 const int cb = tn * 4 + wc * 2 + ch;
                 if (lane == 0 && erow * 64 < p.M && cb < p.eld_c) p.AC[erow * p.eld_c + cb] = a;
             }
