@@ -385,40 +385,64 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         };
         if (OUT == P2_OUT_QKV && tn == 2) {
             // V^T: lane -> (dim d, 16-byte chunk q of the 32-key block) = 8 keys in accumulator order
+            const int dl0 = lane >> 2, q = lane & 3;
+            const int rb = 16 * (q >> 1) + 4 * (q & 1);
+            // the bias of this lane's 8 dims (4 column blocks x 2 passes) BEFORE the first store: gfx950 retires loads and stores
+            // in issue order, a load behind a store waits for that store (one bias load per pass drained the stores 16 times
+            // per tile)
+            float vb[4][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int n = tn * P2_BN + wc * 128 + j * 32 + dl0 + 16 * pass;
+                    vb[j][pass] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+                }
+            const unsigned vt_rd0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sl
+                                    + (unsigned)(rb * 128 + ((((dl0 >> 2) ^ (rb & 7)) << 4) | ((dl0 & 3) << 2)));
+            const int64_t row2 = 2 * (int64_t)p.n_rows;  // halves per dim row of V^T
+            uint16_t* const vt_lane = p.Vt + dl0 * row2 + q * 8;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m0 = tm * P2_BM + wr * 64 + i * 32;
+                const int img = m0 / p.n_rows, key0 = m0 - img * p.n_rows;
+                const int64_t off_i = (int64_t)img * p.heads * 64 * row2 + (key0 >> 5) * 64;  // (wave-uniform)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     slab_write(i, j);
-                    const int m0 = tm * P2_BM + wr * 64 + i * 32;
-                    const int n0 = tn * P2_BN + wc * 128 + j * 32;
+                    // (v os + b) f with f = 16 x 2^-e: the power of two goes into both operands of ONE fma - the same value
+                    const float f = cs * osc[j >> 1], of = os * f;
 #pragma unroll
                     for (int pass = 0; pass < 2; ++pass) {
-                        const int dl = (lane >> 2) + 16 * pass, q = lane & 3;
-                        const int n = n0 + dl;
-                        const int rb = 16 * (q >> 1) + 4 * (q & 1);
+                        const int dl = dl0 + 16 * pass;
+                        // slab[key row][dim dl]: row rb + t (t = 0..3; + 8: immediate offset) holds it in chunk (dl >> 2) ^ (row & 7),
+                        // i.e. address_t = (address_0 ^ 16 t) + 128 t, pass 1 = pass 0 ^ 64.  Recomputed from ONE register per pass
+                        // (the empty asm keeps hipcc from hoisting 8 addresses out of the loops: they were spilled, and a
+                        // scratch reload behind a store waits for that store)
+                        unsigned a0 = vt_rd0 ^ (pass ? 64u : 0u);
+                        asm volatile("" : "+v"(a0));
                         float v[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int row = rb + (e & 3) + 8 * (e >> 2);
-                            v[e] = *reinterpret_cast<const float*>(sl + row * 128 + ((((dl >> 2) ^ (row & 7)) << 4) | ((dl & 3) << 2)));
+                        for (int t = 0; t < 4; ++t) {
+                            typedef __attribute__((address_space(3))) const float* lds_f32_t;
+                            const unsigned at = (a0 ^ (16u * t)) + 128u * t;
+                            v[t] = *reinterpret_cast<lds_f32_t>((uintptr_t)at);
+                            v[4 + t] = *reinterpret_cast<lds_f32_t>((uintptr_t)(at + 1024u));
                         }
-                        const float b = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+                        const float bf = vb[j][pass] * f;
                         p2_u32x4 hi, lo;
-                        // (v os + b) f with f = 16 x 2^-e: the power of two goes into both operands of ONE fma - the same value
-                        const float f = cs * osc[j >> 1], of = os * f, bf = b * f;
                         p2_f32x4 w0, w1;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { w0[e] = __builtin_fmaf(v[e], of, bf); w1[e] = __builtin_fmaf(v[4 + e], of, bf); }
                         gp_split8<false>(w0, w1, w0, w1, hi, lo);
-                        const int img = m0 / p.n_rows, key0 = m0 - img * p.n_rows;
-                        const int nv = n - 2 * P2_BN, head = nv >> 6, dd = nv & 63;
-                        uint16_t* dst = p.Vt + ((int64_t)(img * p.heads + head) * 64 + dd) * (2 * (int64_t)p.n_rows) + (key0 >> 5) * 64 + q * 8;
-                        if (m0 >= p.M || n >= p.N) dst = reinterpret_cast<uint16_t*>(dummy);
+                        const int dim = (wc * 2 + (j >> 1)) * 64 + (j & 1) * 32 + 16 * pass;  // (+ dl0: in vt_lane)
+                        uint16_t* dst = vt_lane + off_i + dim * row2;
+                        if (m0 >= p.M || tn * P2_BN + wc * 128 + j * 32 + dl >= p.N) dst = reinterpret_cast<uint16_t*>(dummy);
                         *reinterpret_cast<p2_u32x4*>(dst) = hi;
                         *reinterpret_cast<p2_u32x4*>(dst + 32) = lo;
                     }
                 }
+            }
             return;
         }
         // bias: without a residual the epilogue issues NO load behind its first store (all four column blocks up front, 32
