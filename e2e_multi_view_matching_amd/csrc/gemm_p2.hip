@@ -684,7 +684,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_kernel(GemmP2Params p) {
         ++dbg_steps;
         if (!(DBG & 16) && issue_first && ldv) issue(buf ^ 1, ld_kt, 0u);
         if (DBG & 8) t2 = clock64();
-        if constexpr (DBG == 0) compute_p(buf, FIRST);
+        if constexpr ((DBG & ~8) == 0) compute_p(buf, FIRST);  // (8 = stamps around the real stream)
         else compute(buf, FIRST, (DBG & 16) && ldv, buf ^ 1, ld_kt);  // ONE call site: two would double the accumulator live ranges
         if (!(DBG & 16) && !issue_first && ldv) {
             unsigned dep = 0;
@@ -839,7 +839,7 @@ int launch_gemm_p2(e2emv_ctx* ctx, const GemmP2Args& a, hipStream_t s) {
         std::vector<long long> h(2 * 8 * 50 * 4);
         E2EMV_HIP(ctx, hipMemcpy(h.data(), d_buf, nb, hipMemcpyDeviceToHost));
         static int printed = 0;
-        if (printed++ < 1)
+        if (printed++ < 2)
             for (int wg = 0; wg < 2; ++wg)
                 for (int w = 0; w < 8; w += 5) {
                     const long long* o = &h[((size_t)wg * 8 + w) * 50 * 4];

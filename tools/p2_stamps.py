@@ -38,7 +38,7 @@ if "--one" in sys.argv:
         print(f"dbg={dbg:2d}  {M} {N} {K}: {ms * 1e3:7.1f} us  {2.0 * M * N * K / ms / 1e9:6.1f} TF-eq", flush=True)
     sys.exit(0)
 
-for dbg in [0, 256, 4, 128]:
+for dbg in [0, 4, 1, 2, 64, 128]:
     env = dict(os.environ, E2EMV_LIBRARY=LIB, E2EMV_P2_DBG=str(dbg))
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     print(r.stdout[-6000:] if dbg & 8 else r.stdout, flush=True)
