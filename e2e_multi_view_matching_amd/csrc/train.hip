@@ -257,6 +257,13 @@ extern "C" int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     (void)hipSetDevice(ctx->device);
     TrainState* t = new TrainState();
     Pack pk, raw;
+    {   // (every optimiser step comes through here: no re-allocation while the ~50 MB packs grow)
+        const TrainState* prev = ts_of(ctx);
+        size_t total = 0;
+        for (const auto& kv : ctx->raw) total += kv.second.data.size() + 64;
+        pk.host.reserve(prev ? prev->w_floats + 64 : total);
+        raw.host.reserve(prev ? prev->raw_floats + 64 : total);
+    }
     if (int rc = train_build(ctx, m, t, pk, raw)) { delete t; return rc; }
     // Every optimiser step comes through here (the parameters changed).  A context that already trains this model keeps
     // its arenas and its tape: the new values are copied over the old ones - no free / malloc, one synchronisation (the

@@ -250,12 +250,15 @@ class MultiViewMatcher(nn.Module):
         if getattr(ctx, "sent_owner", None) == owner:
             return
         ctx.sent_owner = None
-        for k, v in self.state_dict().items():
-            if not v.dtype.is_floating_point:
-                continue  # num_batches_tracked
-            h = v.detach().to("cpu", torch.float32).contiguous()
-            shape = (ctypes.c_int64 * max(h.dim(), 1))(*h.shape)
-            ctx.call("e2emv_set_weight", k.encode(), ctypes.c_void_p(h.data_ptr()), shape, h.dim())
+        items = [(k, v.detach()) for k, v in self.state_dict().items() if v.dtype.is_floating_point]  # (not num_batches_tracked)
+        # ONE device-to-host copy of all tensors (a training loop comes through here after every optimiser step: 250 separate
+        # .cpu() calls were 250 synchronisations)
+        flat = torch.cat([v.reshape(-1).to(torch.float32) for _, v in items]).cpu()
+        base, off = flat.data_ptr(), 0
+        for k, v in items:
+            shape = (ctypes.c_int64 * max(v.dim(), 1))(*v.shape)
+            ctx.call("e2emv_set_weight", k.encode(), ctypes.c_void_p(base + 4 * off), shape, v.dim())
+            off += v.numel()
         ctx.sent_owner = owner
 
     def _push_weights(self, ctx):
@@ -309,7 +312,11 @@ class MultiViewMatcher(nn.Module):
 
     def _forward_locked(self, ctx, data, T, dev):
         cfg = self.config
-        self._push_weights(ctx)
+        # the differentiable path runs from the TRAINING arena (_push_train_weights below): the inference commit (fp64 merge
+        # fold on the host, split-operand planes: 0.4 s) is made when an inference forward next needs it, not after every
+        # optimiser step
+        if not self._differentiable():
+            self._push_weights(ctx)
         # the precision switch is context-global and sticky: resolve it on EVERY call (None = the context's explicit
         # override, else the library default), so a model never inherits what the previous model selected
         mode = cfg.get("mfma_precision")
