@@ -112,6 +112,8 @@ SIGNATURES = {
     "e2emv_qkv_p2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_attention_p2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "e2emv_train_commit": (c_int, [c_void_p, ctypes.POINTER(ModelDesc)]),
+    "e2emv_train_update": (c_int, [c_void_p, ctypes.POINTER(ModelDesc), c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_void_p),
+                           ctypes.POINTER(ctypes.c_int64), ctypes.c_float, c_void_p]),
     "e2emv_matcher_forward_train": (c_int, [c_void_p, ctypes.POINTER(ForwardDesc), _PP, _PP, _PP, _PP, c_void_p]),
     "e2emv_conf_forward_train": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "e2emv_matcher_backward": (c_int, [c_void_p, _PP, _PP, c_void_p]),

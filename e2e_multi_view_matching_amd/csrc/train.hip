@@ -301,6 +301,66 @@ extern "C" int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* m) {
 
 static size_t al256(size_t b) { return (b + 255) & ~size_t(255); }
 
+// After an optimiser step: the new parameter values straight from the caller's DEVICE tensors into the training arena of a
+// context that already trains this model - D2D copies into the raw arena, the folds (BatchNorm, head order) as kernels, all
+// in stream order: no host copy of the weights, no synchronisation, the tape and the arenas stay.
+extern "C" int e2emv_train_update(e2emv_ctx* ctx, const e2emv_model_desc* m, int n, const char* const* keys, const float* const* d_params,
+                                  const int64_t* numels, float bin_score, void* stream) {
+    if (!ctx || !m || n < 0 || (n && (!keys || !d_params || !numels))) return E2EMV_EINVAL;
+    E2EMV_ENTER(ctx, stream);
+    TrainState* t = ts_of(ctx);
+    if (!t || !t->d_w || !t->d_raw || !t->d_maps || memcmp(&t->model, m, sizeof(*m)) != 0)
+        return set_err(ctx, E2EMV_ESTATE, "train_update: no training arena of this model on the context (e2emv_train_commit first)");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    size_t seen = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!keys[i] || !d_params[i]) return set_err(ctx, E2EMV_EINVAL, "train_update: null entry %d", i);
+        std::string k(keys[i]);
+        if (k.rfind("module.", 0) == 0) k = k.substr(7);
+        auto it = t->raw.find(k);
+        if (it == t->raw.end()) continue;  // (a tensor the differentiable path does not use)
+        if ((int64_t)it->second.numel != numels[i])
+            return set_err(ctx, E2EMV_ESHAPE, "train_update: '%s' has %zu elements, not %lld", keys[i], it->second.numel, (long long)numels[i]);
+        E2EMV_HIP(ctx, hipMemcpyAsync(t->d_raw + it->second.off, d_params[i], numels[i] * sizeof(float), hipMemcpyDeviceToDevice, s));
+        ++seen;
+    }
+    if (seen != t->raw.size()) return set_err(ctx, E2EMV_ESTATE, "train_update: %zu of the %zu tensors of the model handed over", seen, t->raw.size());
+    const int D = m->desc_dim;
+    float* W = t->d_w;
+    auto ref = [&](const std::string& k) -> const float* { auto it = t->raw.find(k); return it == t->raw.end() ? nullptr : t->d_raw + it->second.off; };
+    auto fold = [&](const std::string& conv, const std::string& bn, float* Wf, float* bf, int64_t ldwf, int rows, int cols, const int* rmap, int rbase, const int* cmap) {
+        FoldArgs a{};
+        a.W = ref(conv + ".weight"); a.b = ref(conv + ".bias");
+        if (!bn.empty() && ref(bn + ".running_mean")) { a.gamma = ref(bn + ".weight"); a.beta = ref(bn + ".bias"); a.mean = ref(bn + ".running_mean"); a.var = ref(bn + ".running_var"); }
+        a.Wf = Wf + (int64_t)rbase * ldwf; a.bf = bf + rbase; a.ldwf = ldwf; a.col0 = 0; a.rows = rows; a.cols = cols; a.rmap = rmap; a.cmap = cmap;
+        hipLaunchKernelGGL(fold_kernel, dim3(rows), dim3(256), 0, s, a);
+    };
+    const int nk = (int)t->kdims.size() - 1;
+    for (int i = 0; i < nk; ++i)
+        fold("kenc.encoder." + std::to_string(3 * i), i < nk - 1 ? "kenc.encoder." + std::to_string(3 * i + 1) : std::string(), W + t->kw[i], W + t->kb[i], t->kdims[i],
+             t->kdims[i + 1], t->kdims[i], nullptr, 0, nullptr);
+    for (int l = 0; l < (int)t->layers.size(); ++l) {
+        const TrainLayer& Lw = t->layers[l];
+        const std::string base = "gnn.layers." + std::to_string(l);
+        for (int p = 0; p < 3; ++p) fold(base + ".attn.proj." + std::to_string(p), "", W + Lw.wqkv, W + Lw.bqkv, D, D, D, t->d_maps, p * D, nullptr);
+        fold(base + ".attn.merge", "", W + Lw.wm, W + Lw.bm, D, D, D, nullptr, 0, t->d_maps);
+        fold(base + ".mlp.0", base + ".mlp.1", W + Lw.w0, W + Lw.b0, 2 * D, 2 * D, 2 * D, nullptr, 0, nullptr);
+        fold(base + ".mlp.3", "", W + Lw.w1, W + Lw.b1, 2 * D, D, 2 * D, nullptr, 0, nullptr);
+    }
+    fold("final_proj", "", W + t->wf, W + t->bf, D, D, D, nullptr, 0, nullptr);
+    if (t->conf_mlp) {
+        fold("conf_mlp.0", "conf_mlp.1", W + t->wc0, W + t->bc0, 2 * D, D, 2 * D, nullptr, 0, nullptr);
+        fold("conf_mlp.3", "", W + t->wc1, W + t->bc1, D, 1, D, nullptr, 0, nullptr);
+    }
+    E2EMV_CHECK_LAUNCH(ctx, "fold kernels");
+    E2EMV_HIP(ctx, hipMemcpyAsync(W + t->alpha, ref("bin_score"), sizeof(float), hipMemcpyDeviceToDevice, s));
+    t->bin_score = bin_score;
+    E2EMV_HIP(ctx, hipMemsetAsync(t->d_graw, 0, t->raw_floats * sizeof(float), s));
+    t->have_tape = false;
+    return E2EMV_OK;
+}
+
 extern "C" int e2emv_matcher_forward_train(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const float* const* d_kpts, const float* const* d_kscores,
                                            const void* const* d_desc, float* const* d_logZ, void* stream) {
     if (!ctx || !fd || !d_kpts || !d_kscores || !d_desc || !d_logZ) return E2EMV_EINVAL;

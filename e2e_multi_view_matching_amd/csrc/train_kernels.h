@@ -23,8 +23,13 @@ struct GG {
     int splits = 1;  // K is cut into `splits` ranges (mode 2)
 };
 
-constexpr int GG_T = 64, GG_BK = 16, GG_LD = 65;
+constexpr int GG_T = 64, GG_BK = 32, GG_LD = 65;
 
+// 64 x 64 tile, 4 waves of one 32 x 32 fp32-MFMA block each, 32-deep K steps.  The operands of step s + 1 are fetched into
+// registers while step s is computed from LDS: with load -> LDS -> MFMA between two barriers and nothing in flight, one global
+// round trip per step was exposed (backward of a 4-pair step 55 -> 33 ms).  Rows / columns beyond the matrix read as zero.
+// (128-wide tiles - 2 x 2 MFMA blocks per wave, every LDS read used twice - run at 2 - 3 waves per SIMD and were SLOWER,
+// 78 ms: this plain loop lives on its 8 waves per SIMD.)
 __global__ __launch_bounds__(256) void gg_kernel(GG g) {
     __shared__ float As[GG_BK * GG_LD];
     __shared__ float Bs[GG_BK * GG_LD];
@@ -42,25 +47,37 @@ __global__ __launch_bounds__(256) void gg_kernel(GG g) {
     tr_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int k0 = k_begin; k0 < k_end; k0 += GG_BK) {
-        // A tile [64 m][16 k] -> As[k][m]; threads run along whichever index is contiguous in memory
+    // element (m, k) of pass i: threads run along whichever index is contiguous in memory
+    const bool a_kc = g.ak == 1, b_kc = g.bk == 1;
+    constexpr int NP = GG_T * GG_BK / 256;  // 8 values per thread and operand
+    float ra[NP], rb[NP];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             int m, k;
-            if (g.ak == 1) { k = t & 15; m = (t >> 4) + 16 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
-            float v = 0.f;
-            if (m0 + m < g.M && k0 + k < k_end) v = A[(int64_t)(m0 + m) * g.am + (int64_t)(k0 + k) * g.ak];
-            As[k * GG_LD + m] = v;
+            if (a_kc) { k = t & 31; m = (t >> 5) + 8 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
+            ra[i] = (m0 + m < g.M && k0 + k < k_end) ? A[(int64_t)(m0 + m) * g.am + (int64_t)(k0 + k) * g.ak] : 0.f;
+            int n, kb;
+            if (b_kc) { kb = t & 31; n = (t >> 5) + 8 * i; } else { n = t & 63; kb = (t >> 6) + 4 * i; }
+            rb[i] = (n0 + n < g.N && k0 + kb < k_end) ? B[(int64_t)(k0 + kb) * g.bk + (int64_t)(n0 + n) * g.bn] : 0.f;
         }
+    };
+    auto stash = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int n, k;
-            if (g.bk == 1) { k = t & 15; n = (t >> 4) + 16 * i; } else { n = t & 63; k = (t >> 6) + 4 * i; }
-            float v = 0.f;
-            if (n0 + n < g.N && k0 + k < k_end) v = B[(int64_t)(k0 + k) * g.bk + (int64_t)(n0 + n) * g.bn];
-            Bs[k * GG_LD + n] = v;
+        for (int i = 0; i < NP; ++i) {
+            int m, k;
+            if (a_kc) { k = t & 31; m = (t >> 5) + 8 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
+            As[k * GG_LD + m] = ra[i];
+            int n, kb;
+            if (b_kc) { kb = t & 31; n = (t >> 5) + 8 * i; } else { n = t & 63; kb = (t >> 6) + 4 * i; }
+            Bs[kb * GG_LD + n] = rb[i];
         }
+    };
+    if (k_begin < k_end) fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += GG_BK) {
+        stash();
         __syncthreads();
+        if (k0 + GG_BK < k_end) fetch(k0 + GG_BK);
 #pragma unroll
         for (int kk = 0; kk < GG_BK / 2; ++kk) {
             const float a = As[(2 * kk + lh) * GG_LD + wm * 32 + l31];
@@ -389,6 +406,29 @@ __global__ __launch_bounds__(256) void unfold_kernel(UnfoldArgs a) {
             a.dbeta[r] = gb;
         }
     }
+}
+
+// ---- upstream parameters -> folded training weights, on the device (e2emv_train_update): the inverse walk of unfold_kernel ----
+// one workgroup per row r of conv weight W [rows][cols] (+ BatchNorm behind it): Wf[rmap(r)][col0 + cmap(c)] = W[r][c] g / sqrt(var + eps),
+// bf[rmap(r)] = (b[r] - mean) g / sqrt(var + eps) + beta - the expressions and the fp64 of the host fold (train_build)
+struct FoldArgs {
+    const float* W; const float* b;
+    const float* gamma; const float* beta; const float* mean; const float* var;
+    float* Wf; float* bf;
+    int64_t ldwf;
+    int col0, rows, cols;
+    const int* rmap; const int* cmap;
+};
+__global__ __launch_bounds__(256) void fold_kernel(FoldArgs a) {
+    const int r = blockIdx.x, rf = a.rmap ? a.rmap[r] : r;
+    double sc = 1.0;
+    if (a.gamma) sc = (double)a.gamma[r] / sqrt((double)a.var[r] + 1e-5);
+    float* o = a.Wf + (int64_t)rf * a.ldwf + a.col0;
+    for (int c = threadIdx.x; c < a.cols; c += 256) {
+        const float w = a.W[(int64_t)r * a.cols + c];
+        o[a.cmap ? a.cmap[c] : c] = a.gamma ? (float)((double)w * sc) : w;
+    }
+    if (threadIdx.x == 0 && a.bf) a.bf[rf] = a.gamma ? (float)(((double)a.b[r] - (double)a.mean[r]) * sc + (double)a.beta[r]) : a.b[r];
 }
 
 }  // namespace e2emv

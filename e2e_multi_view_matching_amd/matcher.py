@@ -279,8 +279,25 @@ class MultiViewMatcher(nn.Module):
         owner = (self._token, self._fingerprint())
         if ctx.train_owner == owner:
             return
-        self._send_weights(ctx, owner)
         md = self._model_desc()
+        if ctx.train_owner is not None and ctx.train_owner[0] == self._token:
+            # the context already trains THIS module: new values device-to-device into its arena (e2emv_train_update), no host
+            # round trip, no synchronisation beyond reading the scalar bin_score
+            items = [(k, v.detach()) for k, v in self.state_dict().items() if v.dtype.is_floating_point]
+            keep = [v if (v.dtype == torch.float32 and v.is_contiguous()) else v.to(torch.float32).contiguous() for _, v in items]
+            n = len(items)
+            keys = (ctypes.c_char_p * n)(*[k.encode() for k, _ in items])
+            ptrs = (ctypes.c_void_p * n)(*[v.data_ptr() for v in keep])
+            numels = (ctypes.c_int64 * n)(*[v.numel() for v in keep])
+            dev = self.bin_score.device
+            with torch.cuda.device(dev):
+                rc = ctx.lib.e2emv_train_update(ctx.h, ctypes.byref(md), n, keys, ptrs, numels, float(self.bin_score.detach()), _lib.stream_ptr(dev))
+            if rc == _lib.OK:
+                ctx.train_owner = owner
+                return
+            if rc != _lib.ESTATE:
+                ctx.check(rc)
+        self._send_weights(ctx, owner)
         ctx.call("e2emv_train_commit", ctypes.byref(md))
         ctx.train_owner = owner
 

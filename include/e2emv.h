@@ -400,6 +400,15 @@ int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset);
  * e2emv_get_grad            copies the gradient of parameter `key` (the reference's state_dict name, an optional "module."
  *                           prefix is ignored) into d_dst (device, fp32, numel elements); stream-ordered.                 */
 int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* model);
+/* After an optimiser step (helpers.py / train.py: optimizer.step() between two forwards): the new values of the model's
+ * floating-point state_dict tensors straight from DEVICE memory (d_params[i] = fp32, contiguous, numels[i] elements, name
+ * keys[i]; tensors the differentiable path does not use are ignored) into the training arena that e2emv_train_commit built for
+ * this model - device-to-device copies and the BatchNorm / head-order folds as kernels, stream-ordered, no host copy and no
+ * synchronisation.  bin_score = the scalar parameter's value.  E2EMV_ESTATE when the context holds no arena of this model
+ * (then: e2emv_set_weight for every tensor + e2emv_train_commit, once).  The host-side weight store of e2emv_set_weight is
+ * NOT updated: hand the tensors over again before the next e2emv_commit_weights.                                          */
+int e2emv_train_update(e2emv_ctx* ctx, const e2emv_model_desc* model, int n, const char* const* keys, const float* const* d_params,
+                       const int64_t* numels, float bin_score, void* stream);
 int e2emv_matcher_forward_train(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const float* const* d_kpts, const float* const* d_kscores,
                                 const void* const* d_desc, float* const* d_logZ, void* stream);
 int e2emv_conf_forward_train(e2emv_ctx* ctx, int pair, const int64_t* d_matches0, float* d_conf, void* stream);

@@ -171,6 +171,47 @@ def test_optimizer_step_is_seen_by_the_next_forward(gpu):
     assert losses[2] < losses[1] < losses[0], losses
 
 
+def test_device_side_weight_update_equals_the_host_commit(gpu):
+    """After an optimiser step the parameters go device-to-device into the training arena (e2emv_train_update: folds as
+    kernels); the host path (e2emv_set_weight + e2emv_train_commit) on the same values must give the SAME scores and gradients,
+    the scores bit for bit - BatchNorm with non-trivial statistics, conf_mlp, and the inference forward afterwards sees the new weights."""
+    from e2e_multi_view_matching_amd import MultiViewMatcher, _lib
+    from e2e_multi_view_matching_amd.synthetic import make_tuples
+    torch.manual_seed(11)
+    model = MultiViewMatcher({"GNN_layers": ["self", "cross"], "sinkhorn_iterations": 20, "conf_mlp": True, "frozen_batchnorm": True})
+    _randomize_bn(model, 5)
+    model = model.to(gpu).train()
+    data = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in make_tuples(batch=2, tuple_size=2, n_kpts=128, seed=11).items()}
+    idx, w = _targets(2, 128, 71)
+    idx, w = idx.to(gpu), w.to(gpu)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+    ctx = _lib.context(gpu)
+
+    def run():
+        opt.zero_grad()
+        scores = model(data)["scores_0_1"]
+        _match_loss(scores, idx, w).backward()
+        return scores.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    run()
+    opt.step()                       # new values: the next forward takes the device path (the context trains this module)
+    assert ctx.train_owner is not None and ctx.train_owner[0] == model._token
+    s_dev, g_dev = run()
+    assert ctx.sent_owner != ctx.train_owner, "the device path must not have gone through e2emv_set_weight"
+    ctx.train_owner = None           # the same values through the host commit
+    s_host, g_host = run()
+    assert ctx.sent_owner == ctx.train_owner
+    assert torch.equal(s_dev, s_host)
+    assert g_dev.keys() == g_host.keys()
+    scale = max(float(g.norm()) for g in g_host.values())
+    for k in g_dev:  # (weight gradients are sums of atomics: equal up to their order; the key bias has a zero gradient - noise)
+        d = float((g_dev[k] - g_host[k]).norm()) / max(float(g_host[k].norm()), 1e-4 * scale)
+        assert d < 1e-4, (k, d)
+    with torch.no_grad():            # and the inference path re-commits from the updated tensors
+        inf = model.eval()(data)["scores_0_1"]
+    assert float((inf - s_host).abs().max()) < 1e-3
+
+
 def test_stale_tape_raises(gpu):
     from e2e_multi_view_matching_amd import MultiViewMatcher
     from e2e_multi_view_matching_amd.synthetic import make_tuples
