@@ -114,7 +114,7 @@ static int dgrad(e2emv_ctx* ctx, const float* dY, int64_t ldy, int n_out, const 
     return launch_gg(ctx, g, s);
 }
 static int colsum(e2emv_ctx* ctx, const float* X, int64_t rows, int N, int64_t ld, float* out, hipStream_t s) {
-    const int64_t per = 256;  // (rows per workgroup: the loop is a chain of dependent loads - keep it short, many workgroups)
+    const int64_t per = 64;  // (rows per workgroup: short loops, many workgroups - a bias gradient of 8192 x 768 fills the chip)
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (unsigned)((rows + per - 1) / per)), dim3(256), 0, s, X, rows, N, ld, out, per);
     E2EMV_CHECK_LAUNCH(ctx, "colsum_kernel");
     return E2EMV_OK;
