@@ -458,6 +458,22 @@ def run(args):
                           "value": round(B * P * world * args.steps / alt_elapsed, 2), "unit": "pairs/s"}, alt_prof))
         wl.set_precision(mode)
 
+    # ---- the same workload with the batch as two halves on two HIP streams (config["streams"] = 2, an opt-in of the matcher:
+    # one half's launch boundaries filled by the other half's kernels).  Reported beside the headline, never as it: the
+    # per-kernel durations of concurrently running launches are not comparable with the single-stream kernel trace.
+    two_streams = None
+    if not args.no_alt and not stub and world == 1 and B >= 2:
+        wl.model.config["streams"] = 2
+        try:
+            for _ in range(3):
+                wl.step()
+            ts_elapsed = timed_steps(args.steps)
+            two_streams = {"ms_per_step": round(1000.0 * ts_elapsed / args.steps, 3), "value": round(B * P * args.steps / ts_elapsed, 2), "unit": "pairs/s",
+                           "note": "config['streams'] = 2: two half batches, two streams, two library contexts; the outputs are those of the "
+                                   "two halves bit for bit (tests/test_gpu_round4.py); not the headline"}
+        finally:
+            wl.model.config["streams"] = 1
+
     # ---- optional: the image-in pipeline (SuperPoint front-end feeding the same matcher / pose path)
     image_in = None
     if args.front_end and not stub:
@@ -547,6 +563,8 @@ def run(args):
         out["ms_per_step_without_event_brackets"] = round(1000.0 * bare / args.steps, 3)
     if alts:
         out["other_precisions"] = [a for a, _ in alts]
+    if two_streams:
+        out["two_streams"] = two_streams
     if image_in:
         out["image_in_pipeline"] = image_in
     if latency:

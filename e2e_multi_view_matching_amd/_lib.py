@@ -234,6 +234,17 @@ class Context:
         """Calls with fewer keypoint rows than this run the fp32-MFMA kernels even in a split-operand mode
         (-1 = library default, 0 = never)."""
         self.call("e2emv_set_split_min_rows", int(min_rows))
+        self.split_min_rows = int(min_rows)
+
+    def mirror_settings(self, other):
+        """The arithmetic selection of `other` (the device's main context) on this context - a peer context (config["streams"] =
+        2) must compute what the main one would."""
+        self.forced_precision = other.forced_precision
+        self.default_precision = other.default_precision
+        self.default_f16x2_kernels = other.default_f16x2_kernels
+        want = getattr(other, "split_min_rows", -1)
+        if getattr(self, "split_min_rows", -1) != want:
+            self.set_split_min_rows(want)
 
     def check(self, rc):
         if rc != OK:
@@ -260,6 +271,24 @@ def context(device=None):
         ctx = _contexts.get(device)
         if ctx is None:
             ctx = _contexts[device] = Context(device)
+    return ctx
+
+
+_peers = {}
+
+
+def peer_context(device=None):
+    """A SECOND library context on the device (own workspace, own weight copy): what `config["streams"] = 2` runs the second
+    half of a batch on, on its own HIP stream, so that one half's launch boundaries are filled by the other half's kernels."""
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if isinstance(device, torch.device):
+        device = device.index if device.index is not None else torch.cuda.current_device()
+    with _ctx_lock:
+        ctx = _peers.get(device)
+        if ctx is None:
+            ctx = _peers[device] = Context(device)
+            ctx.side_stream = torch.cuda.Stream(device=device)
     return ctx
 
 

@@ -195,6 +195,13 @@ struct CallGuard {
 #define E2EMV_ENTER(ctx, stream) e2emv::CallGuard _call_guard(ctx, stream)
 #define E2EMV_LOCK(ctx) std::unique_lock<std::recursive_mutex> _call_lock((ctx)->mu)
 
+// The synchronous-API uploads and memsets of the commit / allocation paths (hipMemcpy from pageable memory, hipMemset) are
+// work of the legacy NULL stream: hipMemcpy may return once the data is staged, hipMemset is asynchronous - and the caller's
+// streams (torch's) are non-blocking, i.e. not ordered with the null stream.  Every entry point that used them ends with
+// this fence, so that the kernels the caller enqueues next find the bytes in place (seen as wrong first results of a second
+// context created while another stream kept the GPU busy).
+#define E2EMV_NULL_STREAM_FENCE(ctx) E2EMV_HIP(ctx, hipStreamSynchronize(nullptr))
+
 // workspace: makes ctx->d_ws at least `bytes` large, growing the arena (synchronising) when needed; each
 // top-level entry point carves it with 256-byte aligned offsets.
 int ws_reserve(e2emv_ctx* ctx, size_t bytes);

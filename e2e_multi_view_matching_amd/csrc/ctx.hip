@@ -37,6 +37,7 @@ int ensure_flags(e2emv_ctx* ctx) {
     if (ctx->d_flags) return E2EMV_OK;
     E2EMV_HIP(ctx, hipMalloc((void**)&ctx->d_flags, 256));
     E2EMV_HIP(ctx, hipMemset(ctx->d_flags, 0, 256));
+    E2EMV_NULL_STREAM_FENCE(ctx);
     return E2EMV_OK;
 }
 
@@ -54,6 +55,7 @@ int ws_reserve(e2emv_ctx* ctx, size_t bytes) {
     }
     // padded rows of activation buffers must start finite (see forward.hip)
     E2EMV_HIP(ctx, hipMemset(p, 0, want));
+    E2EMV_NULL_STREAM_FENCE(ctx);
     ctx->d_ws = static_cast<char*>(p);
     ctx->ws_bytes = want;
     return E2EMV_OK;
@@ -267,6 +269,7 @@ int e2emv_sync(e2emv_ctx* ctx, void* stream) {
                            "mode, or the inputs were non-finite) - the outputs of those problems are NaN/inf", f[1]);
         }
     }
+    E2EMV_NULL_STREAM_FENCE(ctx);  // (the flag resets above)
     return E2EMV_OK;
 }
 
@@ -593,6 +596,7 @@ extern "C" int e2emv_commit_weights(e2emv_ctx* ctx, const e2emv_model_desc* m) {
     }
     ctx->model = *m;
     ctx->committed = true;
+    E2EMV_NULL_STREAM_FENCE(ctx);  // (the arenas and the weight planes uploaded above)
     return E2EMV_OK;
 }
 
@@ -631,6 +635,7 @@ int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset) {
         if (ctx->d_flags) E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 2, 0, sizeof(unsigned)));
         if (ctx->d_flags) E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 5, 0, sizeof(unsigned)));
     }
+    E2EMV_NULL_STREAM_FENCE(ctx);
     return E2EMV_OK;
 }
 

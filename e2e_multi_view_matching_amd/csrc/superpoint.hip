@@ -379,6 +379,7 @@ extern "C" int e2emv_superpoint_commit(e2emv_ctx* ctx) {
     E2EMV_HIP(ctx, hipMemcpy(ctx->d_sparena, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
     for (int l = 0; l < 12; ++l) { ctx->sp_w[l] = ctx->d_sparena + w_off[l]; ctx->sp_b[l] = ctx->d_sparena + b_off[l]; }
     ctx->sp_committed = true;
+    E2EMV_NULL_STREAM_FENCE(ctx);
     return E2EMV_OK;
 }
 

@@ -279,6 +279,7 @@ extern "C" int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         E2EMV_HIP(ctx, hipMemcpy(t->d_w, pk.host.data(), t->w_floats * sizeof(float), hipMemcpyHostToDevice));
         E2EMV_HIP(ctx, hipMemcpy(t->d_raw, raw.host.data(), t->raw_floats * sizeof(float), hipMemcpyHostToDevice));
         E2EMV_HIP(ctx, hipMemset(t->d_graw, 0, t->raw_floats * sizeof(float)));
+        E2EMV_NULL_STREAM_FENCE(ctx);
         return E2EMV_OK;
     }
     train_free(ctx);
@@ -296,6 +297,7 @@ extern "C" int e2emv_train_commit(e2emv_ctx* ctx, const e2emv_model_desc* m) {
         for (int dd = 0; dd < d; ++dd) map[dd * H + h] = h * d + dd;
     E2EMV_HIP(ctx, hipMalloc((void**)&t->d_maps, D * sizeof(int)));
     E2EMV_HIP(ctx, hipMemcpy(t->d_maps, map.data(), D * sizeof(int), hipMemcpyHostToDevice));
+    E2EMV_NULL_STREAM_FENCE(ctx);
     return E2EMV_OK;
 }
 

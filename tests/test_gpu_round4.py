@@ -45,3 +45,40 @@ def test_configs1_batch32_first_and_last_pair_against_the_oracle(gpu, precision)
             r = ref["_mdesc"][t][0].transpose(0, 1)
             e = float((md[b, t] - r).abs().max()) / float(r.abs().max())
             assert e < 1e-4, (precision, b, t, e)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+def test_two_streams_give_the_single_stream_result(gpu, split_always, precision):
+    """config["streams"] = 2: the batch as two halves on two HIP streams / two library contexts (launch boundaries of one half
+    filled by the other's kernels).  Tuples are independent: the outputs are those of the two halves run one after the other on
+    the main context, BIT for bit, and the whole batch's within rounding (kernel shapes follow the batch size) - an odd batch,
+    a 3-tuple with joint matching, the plane kernels (1024 keypoints) and the small-call kernels.  The FIRST two-stream call
+    comes while the main stream is busy: the second context's weight upload must be complete before its first kernel
+    (the null-stream fence of the commit paths)."""
+    import e2e_multi_view_matching_amd as E
+    from e2e_multi_view_matching_amd.synthetic import make_tuples
+    for (B, T, N, layers) in ((5, 2, 1024, ["self", "cross"]), (4, 3, 256, ["self", "cross"] * 2)):
+        torch.manual_seed(3 + B)   # (new weights: the peer context has to take them over as well)
+        cfg = {"GNN_layers": layers, "sinkhorn_iterations": 20, "conf_mlp": True, "tuple_size": T, "multi_frame_matching": T > 2,
+               "mfma_precision": precision}
+        model = E.MultiViewMatcher(cfg).eval().to(gpu)
+        data = _dev(make_tuples(seed=3, batch=B, tuple_size=T, n_kpts=N), gpu)
+        h = (B + 1) // 2
+
+        def part(lo, hi):
+            return {k: (v[lo:hi] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v) for k, v in data.items()}
+
+        with torch.no_grad():
+            one = model(data)
+            model.config["streams"] = 2
+            two = model(data)
+            model.config["streams"] = 1
+            lo, hi = model(part(0, h)), model(part(h, B))
+        assert one.keys() == two.keys()
+        for k, v in one.items():
+            if not torch.is_tensor(v):
+                continue
+            assert v.shape == two[k].shape, (precision, B, T, k)
+            assert torch.equal(two[k], torch.cat([lo[k], hi[k]], 0)), (precision, B, T, k)
+            if k.startswith("scores_"):
+                assert float((v - two[k]).abs().max()) < 2e-5, (precision, B, T, k)
