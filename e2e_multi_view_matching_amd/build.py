@@ -18,7 +18,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 
 def _stamp():
     h = hashlib.sha256()
-    for f in sorted(f for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))) + ["../../include/e2emv.h"]:
+    # (sources only: the stamp file itself lives in this directory - hashing it made the stamp depend on the build before)
+    for f in sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and os.path.isfile(os.path.join(CSRC, f))) + ["../../include/e2emv.h"]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
