@@ -496,12 +496,14 @@ extern "C" int e2emv_matcher_forward_train(e2emv_ctx* ctx, const e2emv_forward_d
             if ((rc = launch_gemm_nt(ctx, g, s))) return rc;
             sk.S = S;
             float* uv = t->t_uv + (int64_t)pidx * B * uvs;  // [b][t][{u, v}][N + 1]
+            const bool col32 = (int64_t)B * ((N + 1 + 63) / 64) < ctx->num_cus;  // (64-column workgroups would not fill the chip)
             for (int it = 1; it <= iters; ++it) {
                 float* u_t = uv + (int64_t)it * 2 * (N + 1);
                 float* v_t = u_t + (N + 1);
                 const float* v_p = uv + (int64_t)(it - 1) * 2 * (N + 1) + (N + 1);
                 hipLaunchKernelGGL(skt_row_kernel, dim3((N + 1 + 3) / 4, B), dim3(256), 0, s, sk, v_p, u_t, uvs, uvs);
-                hipLaunchKernelGGL(skt_col_kernel, dim3((N + 1 + 63) / 64, B), dim3(1024), 0, s, sk, (const float*)u_t, v_t, uvs, uvs);
+                if (col32) hipLaunchKernelGGL((skt_col_kernel<32>), dim3((N + 1 + 31) / 32, B), dim3(1024), 0, s, sk, (const float*)u_t, v_t, uvs, uvs);
+                else hipLaunchKernelGGL((skt_col_kernel<64>), dim3((N + 1 + 63) / 64, B), dim3(1024), 0, s, sk, (const float*)u_t, v_t, uvs, uvs);
             }
             if (!d_logZ[pidx]) return set_err(ctx, E2EMV_EINVAL, "matcher_forward_train: null logZ for pair %d", pidx);
             const float* u_T = uv + (int64_t)iters * 2 * (N + 1);
@@ -650,12 +652,14 @@ extern "C" int e2emv_matcher_backward(e2emv_ctx* ctx, const float* const* d_dlog
             hipLaunchKernelGGL(skb_init_kernel, dim3((N + 1 + 3) / 4, B), dim3(256), 0, s, N, N, d_dlogZ[pidx], dC, du, dv, (int64_t)(N + 1), (int64_t)(N + 1));
             float* dv_cur = dv;
             float* dv_nxt = dv2;
+            const bool col32 = (int64_t)B * ((N + 1 + 63) / 64) < ctx->num_cus;
             for (int it = iters; it >= 1; --it) {
                 const float* u_t = uv + (int64_t)it * 2 * (N + 1);
                 const float* v_t = u_t + (N + 1);
                 const float* v_p = uv + (int64_t)(it - 1) * 2 * (N + 1) + (N + 1);
                 hipLaunchKernelGGL(skb_vhalf_kernel, dim3((N + 1 + 3) / 4, B), dim3(256), 0, s, sk, u_t, v_t, (const float*)dv_cur, du, dC, uvs, uvs, (int64_t)(N + 1));
-                hipLaunchKernelGGL(skb_uhalf_kernel, dim3((N + 1 + 63) / 64, B), dim3(1024), 0, s, sk, u_t, v_p, (const float*)du, dv_nxt, dC, uvs, uvs, (int64_t)(N + 1));
+                if (col32) hipLaunchKernelGGL((skb_uhalf_kernel<32>), dim3((N + 1 + 31) / 32, B), dim3(1024), 0, s, sk, u_t, v_p, (const float*)du, dv_nxt, dC, uvs, uvs, (int64_t)(N + 1));
+                else hipLaunchKernelGGL((skb_uhalf_kernel<64>), dim3((N + 1 + 63) / 64, B), dim3(1024), 0, s, sk, u_t, v_p, (const float*)du, dv_nxt, dC, uvs, uvs, (int64_t)(N + 1));
                 E2EMV_HIP(ctx, hipMemsetAsync(du, 0, (size_t)B * (N + 1) * sizeof(float), s));
                 std::swap(dv_cur, dv_nxt);
             }

@@ -199,25 +199,29 @@ __global__ __launch_bounds__(256) void skt_row_kernel(SkT p, const float* v, flo
 // v[j] = log_nu_j - LSE_i(C[i][j] + u[i]); a workgroup of 16 waves owns 64 columns: wave w walks the rows i = w, w + 16, ...
 // (65 dependent steps instead of M + 1 - a thread per column was latency-bound: 0.5 ms per launch), lane = column; the 16
 // partial (max, sum) pairs of a column are merged through LDS in a fixed order
+template <int CW>  // columns per workgroup: 64 (lane = column, 16 row phases) or 32 (lane & 31 = column, 32 row phases: twice the
+                    // workgroups - a training batch of 4 problems filled 68 of 256 CUs)
 __global__ __launch_bounds__(1024) void skt_col_kernel(SkT p, const float* u, float* v, int64_t ustride, int64_t vstride) {
-    __shared__ float smx[16][64], ssm[16][64];
+    constexpr int NPH = 16 * 64 / CW;
+    __shared__ float smx[NPH][CW], ssm[NPH][CW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
-    const int j = blockIdx.x * 64 + lane;
+    const int cl = lane & (CW - 1), ph = wv * (64 / CW) + lane / CW;
+    const int j = blockIdx.x * CW + cl;
     const float* Sb = p.S + (int64_t)b * p.M * p.ldS;
     const float* ub = u + b * ustride;
     float mx = -INFINITY, s = 0.f;
     if (j <= p.N)
-        for (int i = wv; i <= p.M; i += 16) {
+        for (int i = ph; i <= p.M; i += NPH) {
             const float x = skt_c(p, Sb, i, j) + ub[i];
             if (x > mx) { s = s * __expf(mx - x) + 1.f; mx = x; } else { s += __expf(x - mx); }
         }
-    smx[wv][lane] = mx;
-    ssm[wv][lane] = s;
+    smx[ph][cl] = mx;
+    ssm[ph][cl] = s;
     __syncthreads();
-    if (wv == 0 && j <= p.N) {
-        float M = smx[0][lane], S = ssm[0][lane];
-        for (int k = 1; k < 16; ++k) {
-            const float m2 = smx[k][lane], s2 = ssm[k][lane];
+    if (threadIdx.x < CW && j <= p.N) {
+        float M = smx[0][cl], S = ssm[0][cl];
+        for (int k = 1; k < NPH; ++k) {
+            const float m2 = smx[k][cl], s2 = ssm[k][cl];
             const float nm = fmaxf(M, m2);
             S = (M == -INFINITY ? 0.f : S * __expf(M - nm)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - nm));
             M = nm;
@@ -275,11 +279,14 @@ __global__ __launch_bounds__(256) void skb_vhalf_kernel(SkT p, const float* u, c
 }
 // u_t = log_mu - LSE_j(C + v_{t-1}):  P = exp(C + v_{t-1}[j] + u_t[i] - log_mu_i);  dC -= du[i] P;  dv_prev[j] = -sum_i du[i] P
 // (16 waves x 64 columns like skt_col_kernel: wave w takes the rows i = w, w + 16, ...; column sums merged through LDS)
+template <int CW>  // (as skt_col_kernel)
 __global__ __launch_bounds__(1024) void skb_uhalf_kernel(SkT p, const float* u, const float* v_prev, const float* du, float* dv_prev, float* dC,
                                                          int64_t ustride, int64_t vstride, int64_t dstride) {
-    __shared__ float part[16][64];
+    constexpr int NPH = 16 * 64 / CW;
+    __shared__ float part[NPH][CW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = blockIdx.y;
-    const int j = blockIdx.x * 64 + lane;
+    const int cl = lane & (CW - 1), ph = wv * (64 / CW) + lane / CW;
+    const int j = blockIdx.x * CW + cl;
     const float* Sb = p.S + (int64_t)b * p.M * p.ldS;
     const float* ub = u + b * ustride;
     const float* dub = du + b * dstride;
@@ -287,18 +294,18 @@ __global__ __launch_bounds__(1024) void skb_uhalf_kernel(SkT p, const float* u, 
     if (j <= p.N) {
         float* d = dC + (int64_t)b * (p.M + 1) * (p.N + 1) + j;
         const float vj = v_prev[b * vstride + j];
-        for (int i = wv; i <= p.M; i += 16) {
+        for (int i = ph; i <= p.M; i += NPH) {
             const float g = dub[i];
             const float P = __expf(skt_c(p, Sb, i, j) + vj + ub[i] - (i < p.M ? p.norm : p.logN + p.norm));
             d[(int64_t)i * (p.N + 1)] -= g * P;
             s += g * P;
         }
     }
-    part[wv][lane] = s;
+    part[ph][cl] = s;
     __syncthreads();
-    if (wv == 0 && j <= p.N) {
-        float t = part[0][lane];
-        for (int k = 1; k < 16; ++k) t += part[k][lane];
+    if (threadIdx.x < CW && j <= p.N) {
+        float t = part[0][cl];
+        for (int k = 1; k < NPH; ++k) t += part[k][cl];
         dv_prev[b * dstride + j] = -t;
     }
 }
