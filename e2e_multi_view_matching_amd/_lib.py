@@ -10,7 +10,8 @@ import threading
 import torch  # noqa: F401  (imported first so libamdhip64.so.7 resolves to the runtime torch loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# E2EMV_LIBRARY: a measurement build of the same sources (tools/p2_stamps.py); the product is always libe2emv.so next to this file
+# E2EMV_LIBRARY: a measurement build of the same sources (tools/p2_stamps.py -> tools/*.bin), announced on stderr when
+# used; the product is always libe2emv.so next to this file
 LIB_PATH = os.environ.get("E2EMV_LIBRARY") or os.path.join(_HERE, "libe2emv.so")
 
 MAX_TUPLE, MAX_LAYERS, MAX_KENC, PROF_SLOTS = 8, 64, 8, 16
@@ -19,7 +20,8 @@ DESC_F32, DESC_F16 = 0, 1
 OK, EINVAL, ENOMEM, EHIP, ESHAPE, ESTATE = 0, -1, -2, -3, -4, -5
 PRECISION_F32, PRECISION_BF16X3, PRECISION_F16X2 = 0, 1, 2
 PRECISION_NAMES = {"f32": PRECISION_F32, "bf16x3": PRECISION_BF16X3, "f16x2": PRECISION_F16X2,
-                   "f16x2-r2": PRECISION_F16X2, "f16x2-r3": PRECISION_F16X2}  # "-r2": the same arithmetic on the round-2 kernels (fp32 activations)
+                   "f16x2-r2": PRECISION_F16X2, "f16x2-r3": PRECISION_F16X2, "f16x2-r4": PRECISION_F16X2,
+                   "f16x2-chain": PRECISION_F16X2}  # "-r2": the same arithmetic on the round-2 kernels (fp32 activations)
 
 c_void_p, c_int, c_float, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_char_p
 c_int64, c_size_t = ctypes.c_int64, ctypes.c_size_t
@@ -154,6 +156,9 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing - build it with `python -m e2e_multi_view_matching_amd.build` "
                               "(there is no CPU/PyTorch fallback for the hot path)")
+        if os.environ.get("E2EMV_LIBRARY"):  # never silent: a run on a measurement / earlier build says so
+            import sys
+            print(f"[e2emv] E2EMV_LIBRARY is set: loading {LIB_PATH} instead of the product library", file=sys.stderr)
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
@@ -189,7 +194,7 @@ class Context:
         self.train_owner = None       # (module, fingerprint) whose weights e2emv_train_commit folded last
         self.train_generation = 0     # bumped by every forward_train: the context keeps the tape of the LAST one only
         self.default_precision = self.precision()  # E2EMV_PRECISION at creation time (else f32)
-        self.f16x2_kernels = {"r2": 2, "r3": 3}.get(os.environ.get("E2EMV_F16X2_KERNELS"), 4)
+        self.f16x2_kernels = {"r2": 2, "r3": 3, "r4": 4}.get(os.environ.get("E2EMV_F16X2_KERNELS"), 5)
         self.default_f16x2_kernels = self._env_f16x2_kernels = self.f16x2_kernels
         self.forced_precision = None               # set_precision(): explicit process-wide override for models with
         #                                            config["mfma_precision"] = None
@@ -207,10 +212,11 @@ class Context:
         self.forced_precision = precision
         self.call("e2emv_set_precision", self.default_precision if precision is None else precision)
 
-    def set_f16x2_kernels(self, generation=4):
-        """f16x2 implementation: 4 = plane activations (gemm_p2 / attention_p2w above 256 keys, the default), 3 = the same
-        with the round-3 attention (attention_p2), 2 = the round-2 kernels (fp32 activations split inside the consuming
-        kernel)."""
+    def set_f16x2_kernels(self, generation=5):
+        """f16x2 implementation: 5 = plane activations (gemm_p2 / attention_p2w above 256 keys) with the GEMMs between two
+        attentions chained in one launch where that pays (gemm_p2c; the default), 105 = chained wherever the shapes allow,
+        4 = one launch per GEMM, 3 = the same with the round-3 attention (attention_p2), 2 = the round-2 kernels (fp32
+        activations split inside the consuming kernel)."""
         self.call("e2emv_set_f16x2_kernels", int(generation))
         self.f16x2_kernels = int(generation)
 

@@ -32,6 +32,11 @@ enum ProfSlot {
     PS_CONF,
     PS_W8PT,
     PS_MISC,
+    // the layer GEMMs of the plane kernels, one slot per kernel instantiation (bench.py: roofline.per_kernel); "gemm" keeps the rest
+    PS_GEMM_QKV,
+    PS_GEMM_MLP0,
+    PS_GEMM_MLP1,
+    PS_GEMM_CHAIN,
     PS_COUNT
 };
 
@@ -96,7 +101,8 @@ struct e2emv_ctx {
     int precision = 0;  // E2EMV_PRECISION_F32 | _BF16X3 | _F16X2 (dense GNN contractions)
     int64_t split_min_rows = -1;  // split-operand kernels from this many keypoint rows per call (-1: half a 128-row tile per CU)
     bool h2_legacy = false;  // f16x2 mode on the round-2 kernels (fp32 activations split inside gemm_h2 / attention_h2f): the A/B arm of the plane path
-    bool attn_wide = true;   // f16x2 kernel generation 4 (default): attention_p2w above 256 keys; false = generation 3 (attention_p2 everywhere)
+    int gemm_chain = 1;      // f16x2 kernel generation 5 (default): MLP0 -> MLP1 -> next q|k|v chained in one launch (gemm_p2c.hip); 0 = generation 4 (a launch per GEMM), 2 = chained whenever the shapes allow (e2emv_set_f16x2_kernels(105))
+    bool attn_wide = true;   // f16x2 kernel generations 4, 5: attention_p2w above 256 keys; false = generation 3 (attention_p2 everywhere)
     int attn_abl = 0;        // measurement build: ablation of attention_p2w's main loop
     int attn_p2_nw = 0;      // attention on planes: 0 = by key count, 4 | 8 = attention_p2 with that many waves, 1 = attention_p2w (micro-benchmarks)
     bool b3_planes = false;  // bf16x3 mode: q|k|v handed to the attention as planes from the GEMM epilogue (E2EMV_B3_PLANES=1)

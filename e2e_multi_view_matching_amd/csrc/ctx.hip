@@ -42,6 +42,9 @@ int ensure_flags(e2emv_ctx* ctx) {
 }
 
 int ws_reserve(e2emv_ctx* ctx, size_t bytes) {
+    // every entry point that carves the arena comes through here first: whatever the previous call left in it (the matched
+    // descriptors e2emv_get_descriptors hands out) is about to be overwritten, or freed by the regrow below
+    ctx->last_mdesc = nullptr;
     if (bytes <= ctx->ws_bytes) return E2EMV_OK;
     E2EMV_HIP(ctx, hipDeviceSynchronize());
     if (ctx->d_ws) E2EMV_HIP(ctx, hipFree(ctx->d_ws));
@@ -141,7 +144,7 @@ size_t add_split_h2(std::vector<uint16_t>& out, const std::vector<float>& w, int
 using namespace e2emv;
 
 static const char* kProfNames[PS_COUNT] = {"ingest", "gemm", "attention", "score_gemm", "sinkhorn",
-                                           "match", "conf", "w8pt", "misc"};
+                                           "match", "conf", "w8pt", "misc", "gemm_qkv", "gemm_mlp0", "gemm_mlp1", "gemm_chain"};
 
 extern "C" {
 
@@ -168,8 +171,10 @@ int e2emv_create(e2emv_ctx** out, int device) {
     if (dbg_knob("E2EMV_B3_PLANES", 0) == 1) ctx->b3_planes = true;
     if (const char* e = getenv("E2EMV_F16X2_KERNELS")) {  // earlier kernel generations of the f16x2 mode (A/B measurements)
         ctx->h2_legacy = strcmp(e, "r2") == 0;
-        ctx->attn_wide = strcmp(e, "r3") != 0;
+        ctx->attn_wide = strcmp(e, "r3") != 0 && !ctx->h2_legacy;
+        if (strcmp(e, "r2") == 0 || strcmp(e, "r3") == 0 || strcmp(e, "r4") == 0) ctx->gemm_chain = 0;
     }
+
     // default arithmetic of the dense GNN contractions: the split-operand fp16 x 2 path (22-bit operands, fp32 accumulate;
     // every parity test runs in all three modes at the same bar); E2EMV_PRECISION=bf16x3 selects the 24-bit bf16 x 3
     // split, =f32 the exact fp32-MFMA kernels
@@ -642,9 +647,12 @@ int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset) {
 int e2emv_set_f16x2_kernels(e2emv_ctx* ctx, int generation) {
     if (!ctx) return E2EMV_EINVAL;
     E2EMV_LOCK(ctx);
-    if (generation < 2 || generation > 4) return set_err(ctx, E2EMV_EINVAL, "f16x2 kernel generation %d (2, 3 or 4)", generation);
+    const bool always = generation == 105;  // generation 5 with the GEMM chain on every shape that allows it (tests, A/B runs)
+    if (always) generation = 5;
+    if (generation < 2 || generation > 5) return set_err(ctx, E2EMV_EINVAL, "f16x2 kernel generation %d (2 .. 5)", generation);
     ctx->h2_legacy = generation == 2;
-    ctx->attn_wide = generation == 4;
+    ctx->attn_wide = generation >= 4;
+    ctx->gemm_chain = generation >= 5 ? (always ? 2 : 1) : 0;
     return E2EMV_OK;
 }
 

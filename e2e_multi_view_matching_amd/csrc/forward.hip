@@ -271,17 +271,35 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
         prof_end(ctx, s);
         if (rc) return rc;
     }
+    // f16x2 kernel generation 5: the row-local GEMMs between two attentions - MLP0, MLP1 of layer l and q | k | v of layer l + 1
+    // (final_proj behind the last layer) - chained per 256-row block in ONE launch (gemm_p2c.hip).  A workgroup then walks 6 tiles
+    // where the three launches walk ceil(2 rb / CUs) + ceil(rb / CUs) + ceil(3 rb / CUs) (rb = row blocks): chained when that is
+    // not more (configs[1]: 256 row blocks on 256 CUs, 6 = 6, and 36 launches fewer per forward; T = 5 shapes with 160 / 320 row
+    // blocks keep the three launches).  e2emv_set_f16x2_kernels: 4 = never, 105 = whenever the shapes allow.
+    bool chain = false;
+    if (p2 && ctx->gemm_chain && Mtot % 256 == 0) {
+        const int64_t rb = Mtot / 256, cu = std::max(1, ctx->num_cus);
+        auto rounds = [&](int64_t tiles) { return (tiles + cu - 1) / cu; };
+        chain = ctx->gemm_chain == 2 || 6 * rounds(rb) <= rounds(2 * rb) + rounds(rb) + rounds(3 * rb);
+    }
+    bool final_done = false;
+    auto qkv_args = [&](const LayerWeights& L) {
+        GemmP2Args q;
+        q.M = (int)Mtot; q.N = 3 * D; q.K = D; q.K1 = D; q.A = xp; q.lda = D; q.W = L.wp_qkv; q.out_scale = L.hs_qkv; q.bias = L.b_qkv;
+        q.out = P2_OUT_QKV; q.Cp = qkp; q.Vt = vtp; q.n_rows = n_rows; q.heads = H;
+        q.EA = e_x; q.EC = e_qk; q.EVt = e_vt; q.bias_amax = L.ba_qkv;
+        return q;
+    };
     for (size_t l = 0; l < ctx->layers.size(); ++l) {
         const LayerWeights& L = ctx->layers[l];
         GemmArgs g;
         if (p2) {
             const bool last = l + 1 == ctx->layers.size();
-            GemmP2Args q;
-            q.M = (int)Mtot; q.N = 3 * D; q.K = D; q.K1 = D; q.A = xp; q.lda = D; q.W = L.wp_qkv; q.out_scale = L.hs_qkv; q.bias = L.b_qkv;
-            q.out = P2_OUT_QKV; q.Cp = qkp; q.Vt = vtp; q.n_rows = n_rows; q.heads = H;
-            q.EA = e_x; q.EC = e_qk; q.EVt = e_vt; q.bias_amax = L.ba_qkv;
-            prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_p2(ctx, q, s); prof_end(ctx, s);
-            if (rc) return rc;
+            if (!chain || l == 0) {  // (chained: the chain of layer l - 1 made this layer's q | k | v)
+                const GemmP2Args q = qkv_args(L);
+                prof_begin(ctx, PS_GEMM_QKV, s); rc = launch_gemm_p2(ctx, q, s); prof_end(ctx, s);
+                if (rc) return rc;
+            }
             prof_begin(ctx, PS_ATTN, s);
             rc = launch_attention_p2(ctx, B, T, n_rows, Nt, D, H, qkp, vtp, L.type, attp, s, e_qk, e_vt, e_att);
             prof_end(ctx, s);
@@ -292,8 +310,6 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
             m0.W = L.wp_mlp0; m0.out_scale = L.hs_mlp0; m0.bias = L.b_mlp0; m0.relu = true;
             m0.out = P2_OUT_PLANES; m0.Cp = hidp; m0.ldc = 2 * D;
             m0.EA = e_x; m0.EA2 = e_att; m0.EC = e_hid; m0.bias_amax = L.ba_mlp0;
-            prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_p2(ctx, m0, s); prof_end(ctx, s);
-            if (rc) return rc;
             // x += W1 hidden + b1; the last layer hands x to final_proj as fp32
             GemmP2Args m1;
             m1.M = (int)Mtot; m1.N = D; m1.K = 2 * D; m1.K1 = 2 * D; m1.A = hidp; m1.lda = 2 * D;
@@ -301,7 +317,26 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
             m1.EA = e_hid; m1.ER = e_x; m1.AR = a_x; m1.bias_amax = L.ba_mlp1;
             if (last && !ctx->wp_final) { m1.out = P2_OUT_F32; m1.C32 = x; m1.ldc = D; }  // (final_proj then runs on the fp32-input kernel)
             else { m1.out = P2_OUT_PLANES; m1.Cp = xp; m1.ldc = D; m1.EC = e_x; m1.AC = a_x; }
-            prof_begin(ctx, PS_GEMM, s); rc = launch_gemm_p2(ctx, m1, s); prof_end(ctx, s);
+            if (chain && (!last || ctx->wp_final)) {
+                GemmP2Args st[3] = {m0, m1, GemmP2Args()};
+                if (!last) {
+                    st[2] = qkv_args(ctx->layers[l + 1]);
+                } else {
+                    GemmP2Args& q = st[2];
+                    q.M = (int)Mtot; q.N = D; q.K = D; q.K1 = D; q.A = xp; q.lda = D; q.W = ctx->wp_final; q.out_scale = ctx->hs_final; q.bias = ctx->b_final;
+                    q.out = P2_OUT_F32; q.C32 = att; q.ldc = D; q.EA = e_x; q.bias_amax = ctx->ba_final;  // (att = mdesc below)
+                    final_done = true;
+                }
+                // MLP1's K steps 8 .. 15 read the hidden columns MLP0's SECOND tile stores right in front of it; q | k | v and
+                // final_proj read x_new from their first K step on
+                const int dep[3] = {P2_CHAIN_INDEP, (2 * D - 256) / 32, 0};
+                prof_begin(ctx, PS_GEMM_CHAIN, s); rc = launch_gemm_p2_chain(ctx, st, dep, 3, s); prof_end(ctx, s);
+                if (rc) return rc;
+                continue;
+            }
+            prof_begin(ctx, PS_GEMM_MLP0, s); rc = launch_gemm_p2(ctx, m0, s); prof_end(ctx, s);
+            if (rc) return rc;
+            prof_begin(ctx, PS_GEMM_MLP1, s); rc = launch_gemm_p2(ctx, m1, s); prof_end(ctx, s);
             if (rc) return rc;
             continue;
         }
@@ -373,7 +408,9 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
 
     // ---- final projection ----
     float* mdesc = att;
-    if (p2 && ctx->wp_final) {  // x arrives as planes with their tile exponents: any magnitude fp32 holds is fine
+    if (final_done) {
+        // (the last layer's chain wrote mdesc)
+    } else if (p2 && ctx->wp_final) {  // x arrives as planes with their tile exponents: any magnitude fp32 holds is fine
         GemmP2Args q;
         q.M = (int)Mtot; q.N = D; q.K = D; q.K1 = D; q.A = xp; q.lda = D; q.W = ctx->wp_final; q.out_scale = ctx->hs_final; q.bias = ctx->b_final;
         q.out = P2_OUT_F32; q.C32 = mdesc; q.ldc = D; q.EA = e_x; q.bias_amax = ctx->ba_final;
@@ -548,7 +585,8 @@ extern "C" int e2emv_matcher_forward(e2emv_ctx* ctx, const e2emv_forward_desc* f
 extern "C" int e2emv_get_descriptors(e2emv_ctx* ctx, float* d_out, int64_t capacity, int* n_img, int* n_kpts, int* dim, void* stream) {
     if (!ctx) return E2EMV_EINVAL;
     E2EMV_ENTER(ctx, stream);
-    if (!ctx->last_mdesc || ctx->last_mdesc < (const float*)ctx->d_ws) return set_err(ctx, E2EMV_ESTATE, "get_descriptors: no forward on this context yet");
+    // (ws_reserve clears the pointer: it is valid only until the next call that uses the workspace)
+    if (!ctx->last_mdesc) return set_err(ctx, E2EMV_ESTATE, "get_descriptors: no matcher_forward on this context since the workspace was last reused");
     if (n_img) *n_img = ctx->md_imgs;
     if (n_kpts) *n_kpts = ctx->md_n;
     if (dim) *dim = ctx->md_dim;

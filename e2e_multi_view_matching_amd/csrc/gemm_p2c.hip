@@ -1,0 +1,308 @@
+// The row-local GEMMs of a GNN layer CHAINED in one persistent launch (f16x2 kernel generation 5).
+//
+// With D = 256 a block of 256 keypoint rows is closed under everything in a layer except the attention:
+//     MLP0 (2 column tiles, K = [x | attention] = 512)  ->  MLP1 + residual (1 tile: the complete x_new of the rows)
+//     ->  q | k | v of the NEXT layer (3 tiles, K = 256)        [last layer: -> final_proj (1 tile)]
+// gemm_p2.hip runs these as three launches of 1 - 3 tiles per workgroup; every launch pays its ramp (first operand tiles of
+// 256 workgroups at once) and its tail, and every tile's epilogue - a 67 MB store burst that all CUs reach together - has
+// nothing to run under but the next launch's ramp.  Here ONE workgroup walks the 6 tiles of its row block back to back:
+//   * tile shape, bytes per MAC, weight traffic, the K step and the epilogues are gemm_p2's (gemm_p2_core.h): the results
+//     are bit-identical to the three launches (tests/test_gpu_round5.py compares them);
+//   * the hand-off between the GEMMs goes through HBM / L2 exactly as before - the producer tile stores its planes, the
+//     consumer tile loads them - but inside ONE workgroup: "my stores have retired" (s_waitcnt vmcnt) + the workgroup barrier
+//     is all the synchronisation there is (the CU's vector L1 is write-through and coherent for the waves of a workgroup; no
+//     grid barrier, no flags, no other workgroup ever touches these rows);
+//   * 5 of the 6 store bursts drain under the K loop of the following tile (the counted-vmcnt pipeline of gemm_p2), the
+//     operand loads of the next tile run two K steps ahead across the epilogue as before.
+// Dependencies between consecutive tiles of a row block (dep_kt of a stage = the first K step of its FIRST tile that reads
+// what the tile right before it stored):
+//   * none (MLP0's tiles; the 2nd, 3rd tile of a stage): loads and the exponent fetch run ahead as in gemm_p2;
+//   * soft, dep_kt >= 4 (MLP1: K steps 0 - 7 read the hidden columns of MLP0's FIRST tile, whose stores retired - counted
+//     vmcnt(0) of K step 2 + the barrier of step 3 - long before; steps 8 - 15 read the second tile's, stored by the epilogue
+//     right in front): the loads still run ahead - the steps that depend are issued behind step 3's barrier by
+//     construction - and only the exponent side-band of the tile is fetched again at step 3;
+//   * hard, dep_kt == 0 (q | k | v / final_proj read x_new from K step 0 on): no run-ahead; after the producer's epilogue
+//     the workgroup waits for its stores (vmcnt(0)), meets at a barrier and starts the consumer like a first tile.  This is
+//     the one exposed store drain per row block and launch (gemm_p2 exposes one per launch and tile round).
+#include <algorithm>
+
+#include "gemm_p2_core.h"
+
+namespace e2emv {
+
+constexpr int P2C_MAX_STAGES = 4, P2C_MAX_TILES = 16;
+constexpr int P2C_INDEP = P2_CHAIN_INDEP;
+
+struct GemmP2ChainParams {
+    GemmP2Params st[P2C_MAX_STAGES];
+    int kind[P2C_MAX_STAGES];       // P2_OUT_* | 4 = with residual
+    int dep_kt[P2C_MAX_STAGES];     // see above; P2C_INDEP = the stage's operands come from earlier launches
+    int first[P2C_MAX_STAGES + 1];  // index of a stage's first tile among the tiles of a row block; [n_stages] = tiles per row block
+    int n_stages, row_blocks;
+    int t_info[P2C_MAX_TILES];      // per tile of a row block: stage | column tile << 8 | hard << 16 | soft << 17 (one scalar load)
+};
+
+__global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams cp_by_value) {
+    extern __shared__ __attribute__((aligned(16))) char smem_p2c[];
+    // The stage of a tile is a run-time index into the parameter block.  Indexing the by-value argument makes hipcc copy the
+    // whole block to scratch (and every field a vector load); the same bytes read through the kernarg segment pointer
+    // (constant address space, the block is the kernel's only argument: offset 0) stay scalar loads.
+    (void)cp_by_value;
+    const GemmP2ChainParams& cp = *(const GemmP2ChainParams*)(const __attribute__((address_space(4))) GemmP2ChainParams*)__builtin_amdgcn_kernarg_segment_ptr();
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    // Nothing derived from the lane index lives longer than it must (gp_lane_now): the K loop's fragment addresses are derived
+    // anew per tile (so the epilogue between two K loops has their registers), the loader's offsets per K step, the exponent
+    // fetch's per fetch.  The four epilogues of this kernel need every register gemm_p2's single one has.
+    int l31 = 0, lh = 0;
+    const int nst = cp.n_stages, tpr = cp.first[nst];
+    // workgroup b walks row blocks b, b + gridDim.x, ...; flat tile index f = (row block of mine) * tpr + tile within the block
+    const int n_my = (cp.row_blocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = n_my * tpr;
+    if (total <= 0) return;
+    auto is_hard = [&](int f) { return f > 0 && (cp.t_info[f % tpr] & (1 << 16)) != 0; };  // reads, from K step 0 on, what the tile before it stores
+
+    // ---- loader (gemm_p2's, with the operand descriptors of the LOAD position's stage): wave w moves rows 32 w .. 32 w + 31 of
+    // the activation tile and of the weight tile, 4 + 4 LDS-direct loads per K step; load i = rows 8 i .. 8 i + 7 of the wave's
+    // 32, lane -> (row lane >> 3, LDS position lane & 7), source chunk = position ^ ((row >> 1) & 7).  Whole tiles only (M, N
+    // multiples of 256: the launcher checks), so row 8 i + r of a wave sits 8 i rows behind row r - a wave-uniform byte offset
+    // that rides in the load's scalar offset together with the tile's base - and its swizzle is that of row r with bit 2
+    // flipped for odd i: the lane's part of an offset is a handful of VALU instructions per K step, recomputed there (gemm_p2
+    // holds twelve offset registers across the whole kernel).
+    unsigned a_base = 0, w_base = 0;  // byte offset of row 0 of this wave's 32 rows of the load position's tiles (scalar)
+    unsigned lda_l = 0, ldw_l = 0;    // row strides in bytes
+    __amdgpu_buffer_rsrc_t rsA, rsA2, rsW;
+    int nk_l = 0, nk1_l = 0;
+    auto setup = [&](int f) {
+        const int rbi = f / tpr, r = f - rbi * tpr, ti = cp.t_info[r], s = ti & 255;
+        const int tm = (int)blockIdx.x + rbi * (int)gridDim.x, tn = (ti >> 8) & 255;
+        const GemmP2Params& q = cp.st[s];
+        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(q.A), 0, (int)q.a_bytes, 0x00020000);
+        rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(q.A2), 0, (int)q.a2_bytes, 0x00020000);
+        rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(q.W), 0, (int)q.w_bytes, 0x00020000);
+        nk_l = q.K / P2_BK;
+        nk1_l = q.K1 / P2_BK;
+        lda_l = q.lda_b;
+        ldw_l = q.ldw_b;
+        a_base = ((unsigned)tm * P2_BM + 32u * wave) * lda_l;
+        w_base = ((unsigned)tn * P2_BN + 32u * wave) * ldw_l;
+    };
+    auto issue = [&](int buf, int kt, unsigned dep) {
+        char* dst = smem_p2c + buf * P2_BUFB + 32 * wave * P2_ROWB;
+        const unsigned ln = (unsigned)gp_lane_now() + dep, ld_r = ln >> 3, ld_p = ln & 7;
+        const unsigned c16 = (ld_p ^ (ld_r >> 1)) * 16u;
+        const unsigned a0 = ld_r * lda_l + c16, a1 = a0 ^ 64u, w0 = ld_r * ldw_l + c16, w1 = w0 ^ 64u;
+        const unsigned a_step = 8u * lda_l, w_step = 8u * ldw_l;
+        if (kt < nk1_l) {
+            const unsigned so = a_base + (unsigned)kt * 128u;
+            p2_glds16(rsA, dst, a0, so);
+            p2_glds16(rsA, dst + 1024, a1, so + a_step);
+            p2_glds16(rsA, dst + 2048, a0, so + 2 * a_step);
+            p2_glds16(rsA, dst + 3072, a1, so + 3 * a_step);
+        } else {
+            const unsigned so = a_base + (unsigned)(kt - nk1_l) * 128u;
+            p2_glds16(rsA2, dst, a0, so);
+            p2_glds16(rsA2, dst + 1024, a1, so + a_step);
+            p2_glds16(rsA2, dst + 2048, a0, so + 2 * a_step);
+            p2_glds16(rsA2, dst + 3072, a1, so + 3 * a_step);
+        }
+        const unsigned sw = w_base + (unsigned)kt * 128u;
+        p2_glds16(rsW, dst + P2_TILEB, w0, sw);
+        p2_glds16(rsW, dst + P2_TILEB + 1024, w1, sw + w_step);
+        p2_glds16(rsW, dst + P2_TILEB + 2048, w0, sw + 2 * w_step);
+        p2_glds16(rsW, dst + P2_TILEB + 3072, w1, sw + 3 * w_step);
+    };
+
+    // ---- tile exponents of a tile's A operand (+ the residual blocks' exponents / maxima in lanes 32 - 35): gemm_p2's fetch
+    auto fetch_e = [&](int f) {
+        const int rbi = f / tpr, r = f - rbi * tpr, ti = cp.t_info[r], s = ti & 255;
+        const int tm_ = (int)blockIdx.x + rbi * (int)gridDim.x, tn_ = (ti >> 8) & 255;
+        const GemmP2Params& q = cp.st[s];
+        const bool has_r = (cp.kind[s] & 4) != 0;
+        const int lane = gp_lane_now();
+        int v = 0;
+        const int erow = tm_ * 4 + wr;
+        const int nb1 = (q.K1 / P2_BK) >> 1, nb = (q.K / P2_BK + 1) >> 1;
+        if (erow * 64 < q.M) {
+            if (lane < nb) {
+                if (q.EA) v = lane < nb1 ? q.EA[erow * q.eld_a + lane] : (q.EA2 ? q.EA2[erow * q.eld_a2 + lane - nb1] : 0);
+            } else if (has_r && q.ER && lane >= 32 && lane < 36) {
+                const int cb = tn_ * 4 + wc * 2 + (lane & 1);
+                if (cb < q.eld_r) {
+                    if (lane < 34) v = q.ER[erow * q.eld_r + cb];
+                    else if (q.AR) v = __builtin_bit_cast(int, q.AR[erow * q.eld_r + cb]);
+                }
+            }
+        }
+        return v;
+    };
+
+    p2_f32x16 acc[4][2];
+    int lf = 0, lkt = 0;                        // load position: (flat tile, K step)
+    bool ld_valid = true, ld_blocked = false;   // blocked: the next tile is hard-dependent - its loads wait for this tile's epilogue
+    auto advance = [&]() {
+        if (lkt + 1 < nk_l) { ++lkt; return; }
+        if (lf + 1 >= total) { ld_valid = false; return; }
+        if (is_hard(lf + 1)) { ld_blocked = true; return; }
+        ++lf;
+        lkt = 0;
+        setup(lf);
+    };
+    setup(0);
+    issue(0, 0, 0u);
+    advance();
+    int ev = fetch_e(0), ev_next = 0;
+    // (every exponent fetch is waited for where the wait is free and BEFORE the K loop is entered again: a fetch still pending at
+    // the loop's readlane would make hipcc put an s_waitcnt vmcnt(0) in front of it - in every K step)
+    asm volatile("" : "+v"(ev));
+    const bool issue_first = wave >= 4;  // the two waves of a SIMD take opposite orders (gemm_p2.hip)
+    int e_run = 0, cur_kt = 0;
+    int since = 8;       // K steps since the last epilogue
+    bool ahead = false;  // the loads of the step after next were issued before that epilogue
+    int buf = 0;
+    // per-tile state of the compute position (wave-uniform)
+    bool has_e = false, soft = false, prefetch_next = false;
+    int f = 0;
+    auto step = [&](auto FIRST) {
+        if (since == 0 && ahead) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+        else if (since <= 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (has_e) {
+            if (soft && cur_kt == 4) {  // (a soft tile never prefetches: the launcher checks - ev_next is free for its second fetch)
+                asm volatile("" : "+v"(ev_next));
+                ev = ev_next;
+            }
+            const int e_step = __builtin_amdgcn_readlane(ev, cur_kt >> 1);
+            if (!decltype(FIRST)::value && __builtin_expect(e_step != e_run, 0)) {
+                asm volatile("s_nop 15");  // (the previous step's asm MFMAs -> the VALU below: hipcc does not pad an asm's results)
+                const int d = e_run - e_step;
+                const float fs = d < -126 ? 0.f : p2_exp2i(d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[j][i][r] *= fs;
+            }
+            e_run = e_step;
+            // the NEXT tile's exponents: loaded beside the operand loads of K step 2, picked up at the head of step 3 (gemm_p2.hip)
+            if (prefetch_next) {
+                if (cur_kt == 2) ev_next = fetch_e(f + 1);
+                if (cur_kt == 3) asm volatile("" : "+v"(ev_next));
+            }
+            // soft dependency: the exponents of the K blocks the tile in front stored.  Its stores retired at step 2, everybody's
+            // by step 3's barrier: the tile's exponents are fetched AGAIN at the end of step 3 and picked up at the head of step 4,
+            // right behind that step's vmcnt(0)
+            if (soft && cur_kt == 3) ev_next = fetch_e(f);
+        }
+        ++cur_kt;
+        const bool ldv = ld_valid && !ld_blocked && !(since == 0 && ahead);
+        if (issue_first && ldv) issue(buf ^ 1, lkt, 0u);
+        gp_kstep<decltype(FIRST)::value>(smem_p2c, buf, wr, wc, l31, lh, acc);
+        if (!issue_first && ldv) {
+            unsigned dep = 0;
+            asm("" : "+v"(dep) : "v"(acc[3][1]));  // scheduling-only: keeps the loads behind the MFMAs
+            issue(buf ^ 1, lkt, dep);
+        }
+        if (ldv) advance();
+        if (since == 0) ahead = false;
+        ++since;
+        buf ^= 1;
+    };
+    for (f = 0; f < total; ++f) {
+        const int rbi = f / tpr, r = f - rbi * tpr, ti = cp.t_info[r], s = ti & 255;
+        const int tm = (int)blockIdx.x + rbi * (int)gridDim.x, tn = (ti >> 8) & 255;
+        const GemmP2Params& q = cp.st[s];
+        const int nk = q.K / P2_BK;
+        {
+            const int ln = gp_lane_now();
+            l31 = ln & 31;
+            lh = ln >> 5;
+        }
+        has_e = q.EA != nullptr || ((cp.kind[s] & 4) && q.ER != nullptr);
+        soft = f > 0 && (ti & (1 << 17)) != 0;
+        prefetch_next = f + 1 < total && !is_hard(f + 1);
+        step(std::true_type{});
+        for (int kt = 1; kt < nk; ++kt) step(std::false_type{});
+        if (ld_valid && !ld_blocked) {
+            // the buffer of the step just computed is free once every wave is through it: the loads of the step after next
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            unsigned dep = 0;
+            asm("" : "+v"(dep) : "v"(acc[3][1]));
+            issue(buf ^ 1, lkt, dep);
+            advance();
+            ahead = true;
+        }
+        cur_kt = 0;
+        gp_acc_fence(acc);
+        switch (cp.kind[s]) {
+            case P2_OUT_PLANES: gp_epilogue<P2_OUT_PLANES, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+            case P2_OUT_PLANES | 4: gp_epilogue<P2_OUT_PLANES, true, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+            case P2_OUT_QKV: gp_epilogue<P2_OUT_QKV, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+            default: gp_epilogue<P2_OUT_F32, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+        }
+        ev = ev_next;
+        since = 0;
+        if (ld_blocked) {
+            // hard hand-off: every wave's stores of this tile have retired, then everybody's have; the consumer starts like a first tile
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            ld_blocked = false;
+            ++lf;
+            lkt = 0;
+            setup(lf);
+            ev = fetch_e(lf);
+            issue(buf, 0, 0u);
+            advance();
+            asm volatile("" : "+v"(ev));
+            since = 8;
+            ahead = false;
+        }
+    }
+}
+
+// `a[0 .. n)`: the GEMMs of the chain in execution order, all over the same M rows; dep_kt[i] as described at the top.
+int launch_gemm_p2_chain(e2emv_ctx* ctx, const GemmP2Args* a, const int* dep_kt, int n, hipStream_t s) {
+    if (n < 1 || n > P2C_MAX_STAGES) return set_err(ctx, E2EMV_EINVAL, "gemm_p2 chain: %d stages (1 .. %d)", n, P2C_MAX_STAGES);
+    GemmP2ChainParams cp{};
+    cp.n_stages = n;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (int rc = fill_gemm_p2_params(ctx, a[i], cp.st[i])) return rc;
+        if (a[i].M != a[0].M) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2 chain: stage %d has %d rows, stage 0 %d", i, a[i].M, a[0].M);
+        if (a[i].K < 4 * P2_BK) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2 chain: K = %d (the store / load overlap needs >= 4 K steps)", a[i].K);
+        if (a[i].out == P2_OUT_F32 && a[i].Rp) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2 chain: fp32 output with a residual is not a chain stage");
+        if (dep_kt[i] != 0 && dep_kt[i] < 4) return set_err(ctx, E2EMV_EINVAL, "gemm_p2 chain: dep_kt %d (0, >= 4 or independent)", dep_kt[i]);
+        // a softly dependent stage is one tile, followed by a hard one (the kernel's second exponent fetch borrows the register of
+        // the next tile's prefetch, which a hard successor does not use)
+        if (dep_kt[i] >= 4 && dep_kt[i] != P2C_INDEP && (a[i].N != P2_BN || i + 1 >= n || dep_kt[i + 1] != 0))
+            return set_err(ctx, E2EMV_EINVAL, "gemm_p2 chain: a softly dependent stage must be one tile wide and be followed by a hard-dependent one");
+        if (i == 0 && dep_kt[i] != P2C_INDEP) return set_err(ctx, E2EMV_EINVAL, "gemm_p2 chain: the first stage cannot depend on a tile before it");
+        // a soft dependency may only reach back over the tile right in front: the tiles before that one must have retired their
+        // stores, which the K loop of one tile (>= 4 steps) guarantees
+        if ((cp.st[i].EA != nullptr) != (cp.st[0].EA != nullptr)) return set_err(ctx, E2EMV_EINVAL, "gemm_p2 chain: tile exponents on all stages or on none");
+        // whole tiles only, one row stride for both K segments (the one-register loader of the kernel)
+        if (a[i].M % P2_BM || a[i].N % P2_BN || (a[i].A2 && a[i].lda2 != a[i].lda))
+            return set_err(ctx, E2EMV_ESHAPE, "gemm_p2 chain: stage %d needs M, N multiples of 256 and lda2 == lda (M=%d N=%d)", i, a[i].M, a[i].N);
+        cp.kind[i] = a[i].out | (a[i].Rp ? 4 : 0);
+        cp.dep_kt[i] = dep_kt[i];
+        cp.first[i] = tiles;
+        for (int t = 0; t < cp.st[i].tiles_n; ++t) {
+            if (tiles + t >= P2C_MAX_TILES) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2 chain: more than %d tiles per row block", P2C_MAX_TILES);
+            cp.t_info[tiles + t] = i | t << 8 | ((t == 0 && dep_kt[i] == 0) ? 1 << 16 : 0) | ((t == 0 && dep_kt[i] >= 4 && dep_kt[i] != P2C_INDEP) ? 1 << 17 : 0);
+        }
+        tiles += cp.st[i].tiles_n;
+    }
+    cp.first[n] = tiles;
+    cp.row_blocks = (a[0].M + P2_BM - 1) / P2_BM;
+    const int grid = std::min(cp.row_blocks, std::max(1, ctx->num_cus));
+    const void* fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel);
+    if (int rc = ensure_dynamic_lds(ctx, fn, P2_LDSB)) return rc;
+    void* args[] = {&cp};
+    E2EMV_HIP(ctx, hipLaunchKernel(fn, dim3(grid), dim3(512), args, P2_LDSB, s));
+    E2EMV_CHECK_LAUNCH(ctx, "gemm_p2_chain_kernel");
+    return E2EMV_OK;
+}
+
+}  // namespace e2emv

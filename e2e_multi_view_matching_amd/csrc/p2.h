@@ -150,6 +150,10 @@ struct GemmP2Args {
     float bias_amax = 0.f;         // upper bound of |bias| (0 when there is none)
 };
 int launch_gemm_p2(e2emv_ctx* ctx, const GemmP2Args& a, hipStream_t s);
+// gemm_p2c.hip: the GEMMs a[0 .. n) over the same M rows, chained per 256-row block in ONE launch.  dep_kt[i] = the first K step
+// of stage i's first tile that reads what the tile right before it stored (0: from the start; >= 4; P2_CHAIN_INDEP: nothing)
+constexpr int P2_CHAIN_INDEP = 1 << 30;
+int launch_gemm_p2_chain(e2emv_ctx* ctx, const GemmP2Args* a, const int* dep_kt, int n, hipStream_t s);
 // fp32 [rows][C] (row stride ld_src floats) -> P2 scaled planes [rows][C]
 // E (optional) [rows/64][C/64]: the tile exponents are computed from the data (rows % 64 == 0, C % 64 == 0 then)
 int launch_to_planes(e2emv_ctx* ctx, const float* src, int64_t rows, int C, int64_t ld_src, uint16_t* dst, hipStream_t s, int* E = nullptr,

@@ -315,7 +315,11 @@ extern "C" int e2emv_train_update(e2emv_ctx* ctx, const e2emv_model_desc* m, int
         return set_err(ctx, E2EMV_ESTATE, "train_update: no training arena of this model on the context (e2emv_train_commit first)");
     (void)hipSetDevice(ctx->device);
     hipStream_t s = (hipStream_t)stream;
+    // pass 1 validates every entry, pass 2 enqueues: a rejected call leaves the raw arena, the folded weights and the tape as
+    // they were (the caller's owner record still describes them)
     size_t seen = 0;
+    std::vector<std::pair<size_t, int>> copies;  // (offset in the raw arena, entry)
+    copies.reserve(t->raw.size());
     for (int i = 0; i < n; ++i) {
         if (!keys[i] || !d_params[i]) return set_err(ctx, E2EMV_EINVAL, "train_update: null entry %d", i);
         std::string k(keys[i]);
@@ -324,10 +328,14 @@ extern "C" int e2emv_train_update(e2emv_ctx* ctx, const e2emv_model_desc* m, int
         if (it == t->raw.end()) continue;  // (a tensor the differentiable path does not use)
         if ((int64_t)it->second.numel != numels[i])
             return set_err(ctx, E2EMV_ESHAPE, "train_update: '%s' has %zu elements, not %lld", keys[i], it->second.numel, (long long)numels[i]);
-        E2EMV_HIP(ctx, hipMemcpyAsync(t->d_raw + it->second.off, d_params[i], numels[i] * sizeof(float), hipMemcpyDeviceToDevice, s));
+        copies.emplace_back(it->second.off, i);
         ++seen;
     }
     if (seen != t->raw.size()) return set_err(ctx, E2EMV_ESTATE, "train_update: %zu of the %zu tensors of the model handed over", seen, t->raw.size());
+    // from here on the arena is being rewritten: a failure below (a HIP error) must not leave a tape that pairs with it
+    t->have_tape = false;
+    for (const auto& c : copies)
+        E2EMV_HIP(ctx, hipMemcpyAsync(t->d_raw + c.first, d_params[c.second], numels[c.second] * sizeof(float), hipMemcpyDeviceToDevice, s));
     const int D = m->desc_dim;
     float* W = t->d_w;
     auto ref = [&](const std::string& k) -> const float* { auto it = t->raw.find(k); return it == t->raw.end() ? nullptr : t->d_raw + it->second.off; };

@@ -199,32 +199,50 @@ class MultiViewMatcher(nn.Module):
 
     # ------------------------------------------------------------------ weights -> library
     def _fingerprint(self):
-        # (storage, version) of every floating-point tensor: what the library's committed copy is compared with on every call.
-        # The tensor list is kept (state_dict() alone costs ~0.2 ms per call - a tenth of a batch-1 forward); anything that can
-        # replace tensor OBJECTS (.to() / .cuda() / .float() go through _apply, load_state_dict may assign) drops it.
-        t = self.__dict__.get("_fp_tensors")
-        if t is None:
-            t = [(k, v) for k, v in self.state_dict(keep_vars=True).items() if v.dtype.is_floating_point]
-            self.__dict__["_fp_tensors"] = t
-        return tuple((k, v.data_ptr(), v._version) for k, v in t)
+        # (object, storage, version) of every floating-point tensor: what the library's committed copy is compared with on
+        # every call.  state_dict() alone costs ~0.2 ms per call (a tenth of a batch-1 forward), so the WALK is cached - as
+        # (owning module, name, is-buffer) slots, never as tensor objects: each call re-reads module._parameters[name] /
+        # module._buffers[name], so a replaced object anywhere in the tree (submodule.load_state_dict(assign=True),
+        # submodule.float() / .cuda() re-assigning BN buffers, submodule.weight = nn.Parameter(...), pruning) is seen, and
+        # the module edges are re-checked so that a replaced SUBMODULE drops the walk.
+        c = self.__dict__.get("_fp_slots")
+        if c is not None:
+            slots, edges = c
+            for parent, name, child in edges:
+                if (len(parent._parameters) + len(parent._buffers) != child) if name is None else (parent._modules.get(name) is not child):
+                    c = None
+                    break
+        if c is None:
+            slots, edges = [], []
+            for prefix, mod in self.named_modules():
+                edges.append((mod, None, len(mod._parameters) + len(mod._buffers)))  # (a slot registered later)
+                for name, child in mod._modules.items():
+                    edges.append((mod, name, child))
+                for name, v in mod._parameters.items():
+                    if v is not None and v.dtype.is_floating_point:
+                        slots.append((prefix + "." + name if prefix else name, mod, name, False))
+                for name, v in mod._buffers.items():
+                    if v is not None and v.dtype.is_floating_point and name not in mod._non_persistent_buffers_set:
+                        slots.append((prefix + "." + name if prefix else name, mod, name, True))
+            self.__dict__["_fp_slots"] = (slots, edges)
+        fp = []
+        for key, mod, name, is_buf in slots:
+            v = (mod._buffers if is_buf else mod._parameters).get(name)
+            if v is None or not v.dtype.is_floating_point:  # the slot went away or changed kind: rebuild the walk
+                self.__dict__["_fp_slots"] = None
+                return self._fingerprint()
+            fp.append((key, id(v), v.data_ptr(), v._version))
+        return tuple(fp)
 
     def invalidate_weight_cache(self):
-        """Call after replacing a parameter / buffer OBJECT somewhere inside the module tree by hand (in-place updates -
-        optimiser steps, copy_, load_state_dict - and .to() / .cuda() are seen without it)."""
-        self.__dict__["_fp_tensors"] = None
+        """Drops the cached module walk (kept for callers of earlier versions; object replacement anywhere in the tree is now
+        seen without it)."""
+        self.__dict__["_fp_slots"] = None
 
     def __setattr__(self, name, value):
         if isinstance(value, (torch.Tensor, nn.Module)):
-            self.__dict__["_fp_tensors"] = None
+            self.__dict__["_fp_slots"] = None
         super().__setattr__(name, value)
-
-    def _apply(self, fn, *args, **kwargs):
-        self.__dict__["_fp_tensors"] = None
-        return super()._apply(fn, *args, **kwargs)
-
-    def load_state_dict(self, *args, **kwargs):
-        self.__dict__["_fp_tensors"] = None
-        return super().load_state_dict(*args, **kwargs)
 
     def _model_desc(self):
         cfg = self.config
@@ -295,6 +313,7 @@ class MultiViewMatcher(nn.Module):
             if rc == _lib.OK:
                 ctx.train_owner = owner
                 return
+            ctx.train_owner = None  # whatever failed: the arena no longer provably holds the values of any owner
             if rc != _lib.ESTATE:
                 ctx.check(rc)
         self._send_weights(ctx, owner)
@@ -334,14 +353,19 @@ class MultiViewMatcher(nn.Module):
         """config["streams"] = 2 (inference): the batch as two halves on two HIP streams and two library contexts.  A step is
         ~100 dependent launches; each boundary (tail of one kernel, drain, ramp of the next) idles part of the chip, and the
         other half's kernels fill it: 32 pairs of 1024 keypoints 10.26 -> 9.80 ms (tools/split_streams.py).  Tuples are
-        independent, so every output row is bit-identical to the single-stream call's.  last_descriptors() then holds the
-        first half only."""
+        independent, so every output row is bit-identical to the single-stream call's - as long as neither half's resident
+        Sinkhorn gives up on an inter-workgroup wait under the contention of the other (stats()["sinkhorn_timeouts"]): a
+        rescued problem is re-solved in the log domain, inside the 1e-4 bar but not bit for bit.  last_descriptors() then
+        holds the first half only."""
         peer = _lib.peer_context(dev)
         peer.mirror_settings(ctx)
         h = (B + 1) // 2
 
+        batched = ("keypoints", "scores", "descriptors", "image")  # + the image index; NOT image_size{m} ([h, w], B = 2 would split it)
+
         def part(lo, hi):
-            return {k: (v[lo:hi] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v) for k, v in data.items()}
+            return {k: (v[lo:hi] if torch.is_tensor(v) and k.rstrip("0123456789") in batched and v.dim() > 0 and v.shape[0] == B else v)
+                    for k, v in data.items()}
 
         cur = torch.cuda.current_stream(dev)
         side = peer.side_stream
@@ -376,7 +400,7 @@ class MultiViewMatcher(nn.Module):
             want = _lib.PRECISION_NAMES[mode]
         if ctx.precision() != want:
             ctx.call("e2emv_set_precision", want)
-        gen = {"f16x2-r2": 2, "f16x2-r3": 3}.get(mode, ctx.default_f16x2_kernels)
+        gen = {"f16x2-r2": 2, "f16x2-r3": 3, "f16x2-r4": 4, "f16x2-chain": 105}.get(mode, ctx.default_f16x2_kernels)
         if ctx.f16x2_kernels != gen:
             ctx.set_f16x2_kernels(gen)
         kpts, scores, descs = [], [], []
@@ -485,11 +509,12 @@ class MultiViewMatcher(nn.Module):
 
 def last_descriptors(device):
     """The matched descriptors (upstream's mdesc, final_proj output) of the last forward on `device`: [B*T, N, D] fp32,
-    keypoint-major (``e2emv_get_descriptors``) - an audit output for parity tests of the GNN arithmetic."""
+    keypoint-major (``e2emv_get_descriptors``) - an audit output for parity tests of the GNN arithmetic.  They live in the
+    library's workspace: valid until the next library call on the context that uses it (any later one raises ESTATE)."""
     dev = torch.device(device)
     ctx = _lib.context(dev)
     n_img, n, d = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-    with torch.cuda.device(dev):
+    with ctx.py_lock, torch.cuda.device(dev):
         ctx.call("e2emv_get_descriptors", None, 0, ctypes.byref(n_img), ctypes.byref(n), ctypes.byref(d), _lib.stream_ptr(dev))
         out = torch.empty((n_img.value, n.value, d.value), dtype=torch.float32, device=dev)
         ctx.call("e2emv_get_descriptors", _lib.ptr(out), out.numel(), ctypes.byref(n_img), ctypes.byref(n), ctypes.byref(d), _lib.stream_ptr(dev))

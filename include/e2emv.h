@@ -28,6 +28,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the functions declared between this push and its pop are its whole
+ * dynamic symbol table (tests/test_host_and_abi.py compares `nm -D` with this header). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define E2EMV_ABI_VERSION 1
 #define E2EMV_MAX_TUPLE 8
@@ -334,11 +339,13 @@ int e2emv_attention_bf16x3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid
 /* ---- f16x2 on plane activations (the default implementation of E2EMV_PRECISION_F16X2) ---------------------------
  * Activations live in HBM as the two fp16 planes of the f16x2 arithmetic (4 bytes per element like fp32, 32-column
  * blocks of {hi, lo}); every producer splits its output once in its epilogue, consumers move the planes from global
- * memory straight into LDS.  generation 4 (default) = these kernels (gemm_p2.hip; attention_p2w.hip - one wave per SIMD,
+ * memory straight into LDS.  generation 5 (default) = these kernels (gemm_p2.hip; attention_p2w.hip - one wave per SIMD,
  * matrix and softmax work interleaved inside the wave - above 256 keys, attention_p2.hip below; needs descriptor_dim 256 /
- * 4 heads, other widths use generation 2), 3 = the same with the round-3 attention (attention_p2.hip everywhere), 2 = the
+ * 4 heads, other widths use generation 2) with the row-local GEMMs between two attentions (MLP0, MLP1, the next layer's
+ * q | k | v) chained per 256-row block in ONE launch where that takes no more tile rounds than three launches (gemm_p2c.hip;
+ * bit-identical results; 105 = chained on every shape that allows it), 4 = a launch per GEMM, 3 = the same with the round-3 attention (attention_p2.hip everywhere), 2 = the
  * round-2 kernels that keep fp32 activations and split them inside the consuming GEMM / attention (kept as A/B arms and
- * for other widths).  Also E2EMV_F16X2_KERNELS=r2 | r3 at e2emv_create. */
+ * for other widths).  Also E2EMV_F16X2_KERNELS=r2 | r3 | r4 at e2emv_create. */
 int e2emv_set_f16x2_kernels(e2emv_ctx* ctx, int generation);
 /* building blocks on fp32 buffers (conversion to / from planes done by helper kernels; for tests and micro-benchmarks):
  * C = act([A | A2] W^T + bias) (+ R); A [M,K1], A2 [M,K-K1] or NULL, W [N,K], R [M,N] or NULL.  flags: bit0 relu, bit1 the
@@ -358,7 +365,9 @@ int e2emv_attention_p2(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, in
 
 /* The matched descriptors of the LAST e2emv_matcher_forward call on this context (upstream's mdesc0 / mdesc1 = final_proj
  * output, models/superglue.py:269 upstream; with multi_frame_matching off and T > 2: of its last pair): d_out
- * [n_img = B*T][n_kpts][dim] fp32, keypoint-major.  d_out == NULL only reports the three sizes.  An audit output: the
+ * [n_img = B*T][n_kpts][dim] fp32, keypoint-major.  d_out == NULL only reports the three sizes.  They live in the context's
+ * workspace: any other call that uses the workspace (w8pt, BA, sinkhorn, superpoint, ...) ends their life, and a later
+ * get_descriptors returns E2EMV_ESTATE instead of stale memory.  An audit output: the
  * quantity the arithmetic modes of the GNN differ in (tests/test_gpu_round4.py, tools/parity_margins.py). */
 int e2emv_get_descriptors(e2emv_ctx* ctx, float* d_out, int64_t capacity_floats, int* n_img, int* n_kpts, int* dim, void* stream);
 
@@ -438,6 +447,9 @@ int e2emv_profile(e2emv_ctx* ctx, int enable);
 int e2emv_profile_read(e2emv_ctx* ctx, float* ms, int64_t* launches, int n_slots, int reset);
 const char* e2emv_profile_name(int slot);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -57,7 +57,7 @@ def _compare(out, ref, pairs):
         assert c.shape == cr.shape and float((c - cr).abs().max()) < TOL
 
 
-PRECISIONS = ["f32", "bf16x3", "f16x2", "f16x2-r3", "f16x2-r2"]  # "-r2": the f16x2 arithmetic on the round-2 kernels
+PRECISIONS = ["f32", "bf16x3", "f16x2", "f16x2-chain", "f16x2-r4", "f16x2-r3", "f16x2-r2"]  # "-r2": the f16x2 arithmetic on the round-2 kernels; "-chain": generation 5 with the GEMM chain forced on; "-r4": a launch per GEMM
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

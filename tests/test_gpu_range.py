@@ -27,14 +27,15 @@ def _rescale(sd, layers, s_qk, s_v, s_h):
 
 @pytest.mark.parametrize("s_qk,s_v,s_h", [(1.0, 1.0, 1.0), (2.0 ** 6, 2.0 ** 8, 2.0 ** 10), (2.0 ** 9, 2.0 ** 12, 2.0 ** 14),
                                           (2.0 ** 12, 2.0 ** 20, 2.0 ** 24), (2.0 ** -10, 2.0 ** -14, 2.0 ** -16)])
-def test_network_with_large_activations_matches_the_oracle(gpu, s_qk, s_v, s_h):
+@pytest.mark.parametrize("mode", ["f16x2", "f16x2-chain"])
+def test_network_with_large_activations_matches_the_oracle(gpu, s_qk, s_v, s_h, mode):
     """18 layers; activations up to ~1e3 x s: inside the old limits of the mode, at them, far beyond them (an fp16 plane
     without the exponent would hold inf) and far below them.  Same bar as every matcher parity test."""
     from e2e_multi_view_matching_amd import MultiViewMatcher, _lib
     from e2e_multi_view_matching_amd.synthetic import make_tuples
     from oracle.matcher import matcher_forward
     from test_gpu_matcher import _randomize_bn
-    cfg = {"sinkhorn_iterations": 30, "conf_mlp": True, "match_threshold": 0.0, "mfma_precision": "f16x2"}
+    cfg = {"sinkhorn_iterations": 30, "conf_mlp": True, "match_threshold": 0.0, "mfma_precision": mode}
     torch.manual_seed(21)
     model = MultiViewMatcher(cfg).eval()
     _randomize_bn(model, 21)

@@ -25,6 +25,23 @@ def test_library_exports_every_declared_symbol(lib_built):
     assert _lib.load_library().e2emv_version() == 1
 
 
+def test_dynamic_symbol_table_is_exactly_the_header(lib_built):
+    """-fvisibility=hidden + the linker version script of build.py: no mangled C++ internals, no kernel host stubs."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", lib_built], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    hdr = open(os.path.join(ROOT, "include", "e2emv.h")).read()
+    declared = set(re.findall(r"\b(e2emv_[a-z0-9_]+)\s*\(", hdr)) - {"e2emv_ctx"}
+    assert exported == declared, sorted(exported ^ declared)[:10]
+
+
+def test_no_measurement_binaries_next_to_the_product():
+    pkg = os.path.join(ROOT, "e2e_multi_view_matching_amd")
+    assert [f for f in os.listdir(pkg) if f.endswith(".so")] == ["libe2emv.so"]
+
+
 def test_struct_layouts_match_the_header():
     from e2e_multi_view_matching_amd import _lib
     assert ctypes.sizeof(_lib.ModelDesc) == 4 * (3 + 8 + 1 + 64 + 1)
@@ -85,6 +102,40 @@ def test_module_contract_of_the_reference_callers():
     assert len(conf_params) == 6
     wrapped.module.config["full_output"] = True
     assert float(m2.kenc.encoder[-1].bias.detach().abs().sum()) == 0.0 and float(m2.bin_score.detach()) == 1.0
+
+
+def test_weight_fingerprint_sees_object_replacement_inside_submodules():
+    """the cached walk must not hold tensor OBJECTS - every way of swapping one below the top-level module has to
+    change the fingerprint (else the library keeps running on the weights it committed before)."""
+    import torch.nn as nn
+    import e2e_multi_view_matching_amd as E
+    m = E.MultiViewMatcher({"GNN_layers": ["self", "cross"], "conf_mlp": True}).eval()
+    seen = [m._fingerprint()]
+
+    def changed(what):
+        fp = m._fingerprint()
+        assert fp != seen[-1], what
+        assert fp == m._fingerprint(), what  # and it is stable between calls
+        seen.append(fp)
+
+    assert m._fingerprint() == seen[0]
+    with torch.no_grad():
+        m.gnn.layers[0].mlp[0].weight.add_(1.0)
+    changed("in-place update")
+    m.gnn.load_state_dict({k: v.clone() for k, v in m.gnn.state_dict().items()}, assign=True)
+    changed("submodule.load_state_dict(assign=True)")
+    m.kenc.double()
+    changed("submodule._apply re-assigning parameters and BN buffers")
+    m.kenc.float()
+    changed("back to float")
+    m.final_proj.weight = nn.Parameter(m.final_proj.weight.detach().clone())
+    changed("submodule.weight = nn.Parameter(...)")
+    m.gnn.layers[1] = type(m.gnn.layers[1])(m.config["descriptor_dim"])
+    changed("a replaced submodule")
+    m.kenc.encoder[1].running_mean = m.kenc.encoder[1].running_mean.clone()
+    changed("a re-assigned BatchNorm buffer")
+    keys = [k for k, v in m.state_dict().items() if v.dtype.is_floating_point]
+    assert [k for k, *_ in m._fingerprint()] == keys  # the same tensors, in state_dict order, that _send_weights uploads
 
 
 def test_synthetic_generator_is_seeded_and_consistent():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where the time of attention_p2w goes: the kernel of a measurement build (libe2emv_stamps.so, -DE2EMV_STAMPS) with parts of
+"""Where the time of attention_p2w goes: the kernel of a measurement build (tools/libe2emv_stamps.bin, -DE2EMV_STAMPS) with parts of
 its main loop removed (wrong results, timing only).  `--build` makes the measurement library (no GPU needed); `--pmc` runs
 the unablated kernel a few times (for rocprofv3 --pmc)."""
 import os
@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "e2e_multi_view_matching_amd", "libe2emv_stamps.so")
+LIB = os.path.join(ROOT, "tools", "libe2emv_stamps.bin")
 
 if "--build" in sys.argv:
     from e2e_multi_view_matching_amd.build import build_library

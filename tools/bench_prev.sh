@@ -1,10 +1,10 @@
 #!/bin/bash
-# bench.py A/B on one box: this tree's library vs libe2emv_prev.so (a build of an earlier commit, E2EMV_LIBRARY); [tag]
+# bench.py A/B on one box: this tree's library vs tools/libe2emv_prev.bin (a build of an earlier commit, E2EMV_LIBRARY); [tag]
 cd "$GRAFT_REPO_ROOT" || exit 1
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r4; mkdir -p $OUT; tag=${1:-prev}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r5; mkdir -p $OUT; tag=${1:-prev}
 for rep in 1 2; do
 timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_${tag}_new$rep.json 2> $OUT/bench_${tag}_new$rep.err
-E2EMV_LIBRARY=$GRAFT_REPO_ROOT/e2e_multi_view_matching_amd/libe2emv_prev.so timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_${tag}_old$rep.json 2> $OUT/bench_${tag}_old$rep.err
+E2EMV_LIBRARY=$GRAFT_REPO_ROOT/tools/libe2emv_prev.bin timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_${tag}_old$rep.json 2> $OUT/bench_${tag}_old$rep.err
 done
 python - $OUT/bench_${tag}_new1.json $OUT/bench_${tag}_old1.json $OUT/bench_${tag}_new2.json $OUT/bench_${tag}_old2.json <<'PY'
 import json, sys

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One parameterised GPU-box script (run through gpurun): tools/gpu.sh <stage> [...]; output under gpurun_out/r4/.
+# One parameterised GPU-box script (run through gpurun): tools/gpu.sh <stage> [...]; output under gpurun_out/r5/.
 #   planes   per-kernel parity of the plane kernels + matcher parity + micro-benchmarks + bench A/B (plane vs round-2 kernels)
 #   tests    the whole -m gpu suite
 #   bench    bench.py lines (c2 default, c4, c5)
@@ -7,7 +7,7 @@
 #   kt       rocprofv3 kernel trace of one config / mode
 #   prof     rocprofv3 kernel trace + the three PMC passes of config c2
 cd "$GRAFT_REPO_ROOT" || exit 1
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r4
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r5
 mkdir -p $OUT
 export TMPDIR=/tmp
 stage=${1:-tests}
@@ -100,16 +100,16 @@ kt)
   args="--config $cfg --precision $mode --steps 2 --warmup 1 --cpu-pairs 0 --no-alt --no-latency --no-profile"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_${cfg}_${mode} -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_${cfg}_${mode}.log 2>&1)
   db=$(find /tmp/kt_${cfg}_${mode} -name '*.db' | head -1)
-  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r4_kernel_stats_${cfg}_${mode}.md 2>&1
-  head -40 $OUT/r4_kernel_stats_${cfg}_${mode}.md
+  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r5_kernel_stats_${cfg}_${mode}.md 2>&1
+  head -40 $OUT/r5_kernel_stats_${cfg}_${mode}.md
   ;;
 prof)
   cfg=${2:-c2}; mode=${3:-f16x2}
   args="--config $cfg --precision $mode --steps 2 --warmup 1 --cpu-pairs 0 --no-alt --no-latency --no-profile"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_${cfg}_${mode} -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_${cfg}_${mode}.log 2>&1)
   db=$(find /tmp/kt_${cfg}_${mode} -name '*.db' | head -1)
-  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r4_kernel_stats_${cfg}_${mode}.md 2>&1
-  head -30 $OUT/r4_kernel_stats_${cfg}_${mode}.md
+  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r5_kernel_stats_${cfg}_${mode}.md 2>&1
+  head -30 $OUT/r5_kernel_stats_${cfg}_${mode}.md
   i=0
   for ctr in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
     (cd /tmp && timeout 400 rocprofv3 --pmc $ctr -d /tmp/pmc_${cfg}_${mode}_$i -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/pmc_${cfg}_${mode}_$i.log 2>&1)
@@ -118,8 +118,8 @@ prof)
   d0=$(find /tmp/pmc_${cfg}_${mode}_0 -name '*.db' | head -1); d1=$(find /tmp/pmc_${cfg}_${mode}_1 -name '*.db' | head -1); d2=$(find /tmp/pmc_${cfg}_${mode}_2 -name '*.db' | head -1)
   cp profiles/pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null
   pairs=32; kpts=1024; [ "$cfg" = c4 ] && pairs=80; [ "$cfg" = c5 ] && { pairs=80; kpts=2048; }
-  python profiles/summarize_pmc.py "$d0" "$d1" "$d2" $OUT/r4_pmc_${cfg}_${mode}.md $OUT/pmc_traffic.json $cfg $mode $pairs $kpts > /dev/null 2> $OUT/pmc_${cfg}_${mode}_summ.err
-  head -12 $OUT/r4_pmc_${cfg}_${mode}.md
+  python profiles/summarize_pmc.py "$d0" "$d1" "$d2" $OUT/r5_pmc_${cfg}_${mode}.md $OUT/pmc_traffic.json $cfg $mode $pairs $kpts > /dev/null 2> $OUT/pmc_${cfg}_${mode}_summ.err
+  head -12 $OUT/r5_pmc_${cfg}_${mode}.md
   ;;
 *) echo "unknown stage $stage"; exit 2;;
 esac

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where the time of gemm_p2 goes: runs the plane GEMM of a measurement build (libe2emv_stamps.so, -DE2EMV_STAMPS) with
+"""Where the time of gemm_p2 goes: runs the plane GEMM of a measurement build (tools/libe2emv_stamps.bin, -DE2EMV_STAMPS) with
 its ablation variants (E2EMV_P2_DBG: 1 no MFMA, 2 no operand loads, 4 no epilogue, 16 loads spread over the MFMA groups,
 8 in-kernel timestamps).  `--build` makes the measurement library (no GPU needed); without it every variant runs in its own
 process on the GPU."""
@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "e2e_multi_view_matching_amd", "libe2emv_stamps.so")
+LIB = os.path.join(ROOT, "tools", "libe2emv_stamps.bin")
 
 if "--build" in sys.argv:
     from e2e_multi_view_matching_amd.build import build_library

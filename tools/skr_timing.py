@@ -5,7 +5,7 @@ import sys
 import time
 
 os.environ.setdefault("E2EMV_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                    "e2e_multi_view_matching_amd", "libe2emv_stamps.so"))
+                                                    "tools", "libe2emv_stamps.bin"))
 
 import numpy as np
 import torch
