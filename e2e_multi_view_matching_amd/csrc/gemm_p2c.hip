@@ -25,6 +25,8 @@
 //     the workgroup waits for its stores (vmcnt(0)), meets at a barrier and starts the consumer like a first tile.  This is
 //     the one exposed store drain per row block and launch (gemm_p2 exposes one per launch and tile round).
 #include <algorithm>
+#include <cstdlib>
+#include <vector>
 
 #include "gemm_p2_core.h"
 
@@ -42,6 +44,9 @@ struct GemmP2ChainParams {
     int t_info[P2C_MAX_TILES];      // per tile of a row block: stage | column tile << 8 | hard << 16 | soft << 17 (one scalar load)
 };
 
+// DBG (instantiated only in -DE2EMV_STAMPS builds, tools/p2c_stamps.py; results wrong but for 8): 4 no epilogue, 8 s_memtime stamps
+// per tile (K loop | epilogue | hand-off) of two workgroups, 512 no wait at the hard hand-off
+template <int DBG>
 __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams cp_by_value) {
     extern __shared__ __attribute__((aligned(16))) char smem_p2c[];
     // The stage of a tile is a run-time index into the parameter block.  Indexing the by-value argument makes hipcc copy the
@@ -224,8 +229,11 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
         has_e = q.EA != nullptr || ((cp.kind[s] & 4) && q.ER != nullptr);
         soft = f > 0 && (ti & (1 << 17)) != 0;
         prefetch_next = f + 1 < total && !is_hard(f + 1);
+        long long ts0 = 0, ts1 = 0, ts2 = 0;
+        if (DBG & 8) ts0 = __builtin_amdgcn_s_memtime();
         step(std::true_type{});
         for (int kt = 1; kt < nk; ++kt) step(std::false_type{});
+        if (DBG & 8) ts1 = __builtin_amdgcn_s_memtime();
         if (ld_valid && !ld_blocked) {
             // the buffer of the step just computed is free once every wave is through it: the loads of the step after next
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -237,17 +245,23 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
         }
         cur_kt = 0;
         gp_acc_fence(acc);
-        switch (cp.kind[s]) {
-            case P2_OUT_PLANES: gp_epilogue<P2_OUT_PLANES, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
-            case P2_OUT_PLANES | 4: gp_epilogue<P2_OUT_PLANES, true, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
-            case P2_OUT_QKV: gp_epilogue<P2_OUT_QKV, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
-            default: gp_epilogue<P2_OUT_F32, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+        if (!(DBG & 4)) {
+            switch (cp.kind[s]) {
+                case P2_OUT_PLANES: gp_epilogue<P2_OUT_PLANES, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+                case P2_OUT_PLANES | 4: gp_epilogue<P2_OUT_PLANES, true, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+                case P2_OUT_QKV: gp_epilogue<P2_OUT_QKV, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+                default: gp_epilogue<P2_OUT_F32, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+            }
+        } else {
+            asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));
         }
+        if (DBG & 8) ts2 = __builtin_amdgcn_s_memtime();
         ev = ev_next;
         since = 0;
         if (ld_blocked) {
             // hard hand-off: every wave's stores of this tile have retired, then everybody's have; the consumer starts like a first tile
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (DBG & 512) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             ld_blocked = false;
             ++lf;
             lkt = 0;
@@ -258,6 +272,10 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
             asm volatile("" : "+v"(ev));
             since = 8;
             ahead = false;
+        }
+        if ((DBG & 8) && q.dbg && gp_lane_now() == 0 && (blockIdx.x == 0 || blockIdx.x == 101) && f < 12) {
+            long long* o = q.dbg + (((blockIdx.x ? 1 : 0) * 8 + wave) * 12 + f) * 4;
+            o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
         }
     }
 }
@@ -297,11 +315,48 @@ int launch_gemm_p2_chain(e2emv_ctx* ctx, const GemmP2Args* a, const int* dep_kt,
     cp.first[n] = tiles;
     cp.row_blocks = (a[0].M + P2_BM - 1) / P2_BM;
     const int grid = std::min(cp.row_blocks, std::max(1, ctx->num_cus));
-    const void* fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel);
+    const void* fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<0>);
+#ifdef E2EMV_STAMPS
+    // measurement build only (tools/p2c_stamps.py): E2EMV_P2C_DBG selects an ablation / the stamped variant
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("E2EMV_P2C_DBG"); dbg = e ? atoi(e) : 0; }
+    static long long* d_buf = nullptr;
+    const size_t nb = sizeof(long long) * 2 * 8 * 12 * 4;
+    switch (dbg) {
+        case 4: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<4>); break;
+        case 8: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<8>); break;
+        case 512: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<512>); break;
+        case 516: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<516>); break;
+        default: break;
+    }
+    if (dbg == 8) {
+        if (!d_buf) E2EMV_HIP(ctx, hipMalloc((void**)&d_buf, nb));
+        E2EMV_HIP(ctx, hipMemsetAsync(d_buf, 0, nb, s));
+        for (int i = 0; i < n; ++i) cp.st[i].dbg = d_buf;
+    }
+#endif
     if (int rc = ensure_dynamic_lds(ctx, fn, P2_LDSB)) return rc;
     void* args[] = {&cp};
     E2EMV_HIP(ctx, hipLaunchKernel(fn, dim3(grid), dim3(512), args, P2_LDSB, s));
     E2EMV_CHECK_LAUNCH(ctx, "gemm_p2_chain_kernel");
+#ifdef E2EMV_STAMPS
+    if (dbg == 8) {
+        static int printed = 0;
+        if (printed++ < 3) {
+            E2EMV_HIP(ctx, hipStreamSynchronize(s));
+            std::vector<long long> h(2 * 8 * 12 * 4);
+            E2EMV_HIP(ctx, hipMemcpy(h.data(), d_buf, nb, hipMemcpyDeviceToHost));
+            for (int wg = 0; wg < 2; ++wg)
+                for (int w = 0; w < 8; w += 5) {
+                    fprintf(stderr, "gemm_p2_chain wg %d wave %d: per tile  K loop | ahead-issue + epilogue | hand-off   (100 MHz ticks x 10 = ns)\n", wg ? 101 : 0, w);
+                    const long long* o = &h[((size_t)wg * 8 + w) * 12 * 4];
+                    for (int f = 0; f < tiles && f < 12; ++f)
+                        fprintf(stderr, "  tile %d: %6lld | %6lld | %6lld   (start +%lld)\n", f, 10 * (o[4 * f + 1] - o[4 * f]), 10 * (o[4 * f + 2] - o[4 * f + 1]),
+                                10 * (o[4 * f + 3] - o[4 * f + 2]), 10 * (o[4 * f] - o[0]));
+                }
+        }
+    }
+#endif
     return E2EMV_OK;
 }
 

@@ -27,6 +27,7 @@ def test_configs1_batch32_first_and_last_pair_against_the_oracle(gpu, precision)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(gpu)
     model.config["mfma_precision"] = precision
+    E._lib.context(gpu).stats(reset=True)  # (the counters are cumulative over the process: earlier range tests leave theirs)
     with torch.no_grad():
         out = model(_dev(data, gpu))
     md = E.last_descriptors(gpu).cpu().view(B, 2, N, -1)

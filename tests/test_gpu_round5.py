@@ -50,6 +50,7 @@ def test_chained_gemms_equal_the_per_gemm_launches_bit_for_bit(gpu, B, T, N, lay
     data = _dev(make_tuples(seed=50 + B, batch=B, tuple_size=T, n_kpts=N), gpu)
     ctx = E._lib.context(gpu)
     ctx.set_split_min_rows(0)
+    ctx.stats(reset=True)
     try:
         ref, md_ref = _run(model, data, gpu, "f16x2-r4")
         for rep in range(3):  # (a race in the hand-off would not show on every run)

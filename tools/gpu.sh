@@ -24,7 +24,27 @@ for f in sys.argv[1:]:
         except Exception: pass
 PY
 }
+B="--steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency"
 case $stage in
+chain)
+  # round 5: the chained GEMMs - bit-identity with the per-GEMM launches, the parity suites that run through the shared core,
+  # then A/B bench lines on this box: generation 5 (chain), generation 4 (same library), the round-4 library (tools/libe2emv_prev.bin)
+  timeout 600 python -m pytest tests/test_gpu_round5.py -x -q 2>&1 | tail -15 | tee $OUT/chain_tests.log
+  timeout 900 python -m pytest tests/test_gpu_planes.py tests/test_gpu_matcher.py tests/test_gpu_range.py tests/test_gpu_round4.py -x -q 2>&1 | tail -8 | tee $OUT/chain_suites.log
+  for rep in 1 2; do
+    timeout 300 python bench.py $B > $OUT/bench_g5_$rep.json 2> $OUT/bench_g5_$rep.err
+    E2EMV_F16X2_KERNELS=r4 timeout 300 python bench.py $B > $OUT/bench_g4_$rep.json 2> $OUT/bench_g4_$rep.err
+    [ -f tools/libe2emv_prev.bin ] && E2EMV_LIBRARY=$GRAFT_REPO_ROOT/tools/libe2emv_prev.bin E2EMV_F16X2_KERNELS=r4 timeout 300 python bench.py $B > $OUT/bench_prev_$rep.json 2> $OUT/bench_prev_$rep.err
+  done
+  show $OUT/bench_g5_1.json $OUT/bench_g4_1.json $OUT/bench_prev_1.json $OUT/bench_g5_2.json $OUT/bench_g4_2.json $OUT/bench_prev_2.json
+  python -c "
+import json; d=json.loads(open('$OUT/bench_g5_2.json').read().strip().splitlines()[-1]); print(json.dumps(d['roofline'].get('per_kernel'), indent=1))"
+  args="--steps 2 --warmup 1 --cpu-pairs 0 --no-alt --no-latency --no-profile"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_chain -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_chain.log 2>&1)
+  db=$(find /tmp/kt_chain -name '*.db' | head -1)
+  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r5_kernel_stats_c2_f16x2_chain.md 2>&1
+  head -24 $OUT/r5_kernel_stats_c2_f16x2_chain.md
+  ;;
 planes)
   timeout 900 python -m pytest tests/test_gpu_planes.py -x -q 2>&1 | tail -15 | tee $OUT/planes_tests.log
   timeout 900 python -m pytest tests/test_gpu_matcher.py tests/test_gpu_golden_direct.py -x -q 2>&1 | tail -15 | tee $OUT/planes_matcher.log
@@ -74,6 +94,9 @@ PY
   ;;
 stamps)
   timeout 900 python tools/p2_stamps.py 2>&1 | tee $OUT/p2_stamps.log
+  ;;
+cstamps)
+  timeout 900 python tools/p2c_stamps.py 2>&1 | tee $OUT/p2c_stamps.log
   ;;
 ab)
   timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_p2.json 2> $OUT/bench_p2.err
