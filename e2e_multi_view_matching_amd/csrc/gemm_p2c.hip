@@ -45,7 +45,7 @@ struct GemmP2ChainParams {
 };
 
 // DBG (instantiated only in -DE2EMV_STAMPS builds, tools/p2c_stamps.py; results wrong but for 8): 4 no epilogue, 8 s_memtime stamps
-// per tile (K loop | epilogue | hand-off) of two workgroups, 512 no wait at the hard hand-off
+// per tile (K loop | epilogue | hand-off) of two workgroups, 512 no wait at the hard hand-off, 1024 activation loads non-temporal
 template <int DBG>
 __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams cp_by_value) {
     extern __shared__ __attribute__((aligned(16))) char smem_p2c[];
@@ -61,6 +61,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
     // anew per tile (so the epilogue between two K loops has their registers), the loader's offsets per K step, the exponent
     // fetch's per fetch.  The four epilogues of this kernel need every register gemm_p2's single one has.
     int l31 = 0, lh = 0;
+    unsigned rc_t = 0;  // the loader's lane constants (lane_rc below), per tile like l31 / lh
     const int nst = cp.n_stages, tpr = cp.first[nst];
     // workgroup b walks row blocks b, b + gridDim.x, ...; flat tile index f = (row block of mine) * tpr + tile within the block
     const int n_my = (cp.row_blocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
     unsigned lda_l = 0, ldw_l = 0;    // row strides in bytes
     __amdgpu_buffer_rsrc_t rsA, rsA2, rsW;
     int nk_l = 0, nk1_l = 0;
+    bool rev_l = false;  // (measurement variant 2048: odd column tiles walk K backwards - their first steps re-read what the tile before read last)
     auto setup = [&](int f) {
         const int rbi = f / tpr, r = f - rbi * tpr, ti = cp.t_info[r], s = ti & 255;
         const int tm = (int)blockIdx.x + rbi * (int)gridDim.x, tn = (ti >> 8) & 255;
@@ -88,30 +90,41 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
         rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(q.W), 0, (int)q.w_bytes, 0x00020000);
         nk_l = q.K / P2_BK;
         nk1_l = q.K1 / P2_BK;
+        rev_l = (DBG & 2048) && (tn & 1);
         lda_l = q.lda_b;
         ldw_l = q.ldw_b;
         a_base = ((unsigned)tm * P2_BM + 32u * wave) * lda_l;
         w_base = ((unsigned)tn * P2_BN + 32u * wave) * ldw_l;
     };
-    auto issue = [&](int buf, int kt, unsigned dep) {
+    // (ld_r | c16 << 8) of a lane: its row among the 8 of a load and its swizzled 16-byte chunk - two VGPRs' worth of lane
+    // constants in one, made per tile for the K loop's steps and on the spot for the issues outside it
+    auto lane_rc = [&]() {
+        const unsigned ln = (unsigned)gp_lane_now(), ld_r = ln >> 3, ld_p = ln & 7;
+        return ld_r | ((ld_p ^ (ld_r >> 1)) * 16u) << 8;
+    };
+    auto issue = [&](int buf, int kt, unsigned rc) {
+        if ((DBG & 2048) && rev_l) kt = nk_l - 1 - kt;
         char* dst = smem_p2c + buf * P2_BUFB + 32 * wave * P2_ROWB;
-        const unsigned ln = (unsigned)gp_lane_now() + dep, ld_r = ln >> 3, ld_p = ln & 7;
-        const unsigned c16 = (ld_p ^ (ld_r >> 1)) * 16u;
-        const unsigned a0 = ld_r * lda_l + c16, a1 = a0 ^ 64u, w0 = ld_r * ldw_l + c16, w1 = w0 ^ 64u;
+        const unsigned ld_r = rc & 255u, c16 = rc >> 8;
+        // (24-bit multiplies: full rate - a 32-bit v_mad_u64_u32 per operand stood in front of every step's loads)
+        const unsigned a0 = __umul24(ld_r, lda_l) + c16, a1 = a0 ^ 64u, w0 = __umul24(ld_r, ldw_l) + c16, w1 = w0 ^ 64u;
         const unsigned a_step = 8u * lda_l, w_step = 8u * ldw_l;
+        // (E2EMV_STAMPS builds: DBG & 1024 = the activation stream with the non-temporal hint)
+#define P2C_LDA(rs, d, v, so) do { if constexpr ((DBG & 1024) != 0) p2_glds16_nt(rs, d, v, so); else p2_glds16(rs, d, v, so); } while (0)
         if (kt < nk1_l) {
             const unsigned so = a_base + (unsigned)kt * 128u;
-            p2_glds16(rsA, dst, a0, so);
-            p2_glds16(rsA, dst + 1024, a1, so + a_step);
-            p2_glds16(rsA, dst + 2048, a0, so + 2 * a_step);
-            p2_glds16(rsA, dst + 3072, a1, so + 3 * a_step);
+            P2C_LDA(rsA, dst, a0, so);
+            P2C_LDA(rsA, dst + 1024, a1, so + a_step);
+            P2C_LDA(rsA, dst + 2048, a0, so + 2 * a_step);
+            P2C_LDA(rsA, dst + 3072, a1, so + 3 * a_step);
         } else {
             const unsigned so = a_base + (unsigned)(kt - nk1_l) * 128u;
-            p2_glds16(rsA2, dst, a0, so);
-            p2_glds16(rsA2, dst + 1024, a1, so + a_step);
-            p2_glds16(rsA2, dst + 2048, a0, so + 2 * a_step);
-            p2_glds16(rsA2, dst + 3072, a1, so + 3 * a_step);
+            P2C_LDA(rsA2, dst, a0, so);
+            P2C_LDA(rsA2, dst + 1024, a1, so + a_step);
+            P2C_LDA(rsA2, dst + 2048, a0, so + 2 * a_step);
+            P2C_LDA(rsA2, dst + 3072, a1, so + 3 * a_step);
         }
+#undef P2C_LDA
         const unsigned sw = w_base + (unsigned)kt * 128u;
         p2_glds16(rsW, dst + P2_TILEB, w0, sw);
         p2_glds16(rsW, dst + P2_TILEB + 1024, w1, sw + w_step);
@@ -119,35 +132,53 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
         p2_glds16(rsW, dst + P2_TILEB + 3072, w1, sw + 3 * w_step);
     };
 
-    // ---- tile exponents of a tile's A operand (+ the residual blocks' exponents / maxima in lanes 32 - 35): gemm_p2's fetch
-    auto fetch_e = [&](int f) {
-        const int rbi = f / tpr, r = f - rbi * tpr, ti = cp.t_info[r], s = ti & 255;
-        const int tm_ = (int)blockIdx.x + rbi * (int)gridDim.x, tn_ = (ti >> 8) & 255;
-        const GemmP2Params& q = cp.st[s];
-        const bool has_r = (cp.kind[s] & 4) != 0;
-        const int lane = gp_lane_now();
-        int v = 0;
-        const int erow = tm_ * 4 + wr;
-        const int nb1 = (q.K1 / P2_BK) >> 1, nb = (q.K / P2_BK + 1) >> 1;
-        if (erow * 64 < q.M) {
-            if (lane < nb) {
-                if (q.EA) v = lane < nb1 ? q.EA[erow * q.eld_a + lane] : (q.EA2 ? q.EA2[erow * q.eld_a2 + lane - nb1] : 0);
-            } else if (has_r && q.ER && lane >= 32 && lane < 36) {
-                const int cb = tn_ * 4 + wc * 2 + (lane & 1);
-                if (cb < q.eld_r) {
-                    if (lane < 34) v = q.ER[erow * q.eld_r + cb];
-                    else if (q.AR) v = __builtin_bit_cast(int, q.AR[erow * q.eld_r + cb]);
-                }
-            }
-        }
-        return v;
+    // ---- tile exponents (p2.h) - SCALAR here.  gemm_p2 fetches a tile's exponents with one vector load (lane i: K block i) and
+    // reads them with v_readlane; in this kernel that register was one too many beside the four epilogues (hipcc spilled it, or
+    // put an s_waitcnt vmcnt(0) for it in front of every K step's readlane - in the middle of the counted load / store pipeline).
+    // The exponents are wave-uniform and small (P2_EMIN .. P2_EMAX: a signed byte): a tile's <= 8 K-block exponents are fetched
+    // ONCE per tile by scalar loads (asm statements that carry their own s_waitcnt lgkmcnt: nothing of the vector memory
+    // counter, nothing pending that hipcc could copy or spill early), packed into one 64-bit scalar, and a K block's exponent
+    // is a shift + sign extension - the K loop contains no memory operation for the side-band.  The scalar cache is not coherent
+    // with the epilogues' vector stores: it is invalidated where a tile reads exponents the tile before it stored (hard
+    // hand-off; step 4 of a soft tile, whose K blocks >= dep_kt / 2 are fetched again there - the producer's stores retired at
+    // step 2, everybody's by step 3's barrier).
+    typedef int p2c_i4 __attribute__((ext_vector_type(4)));
+    typedef int p2c_i2 __attribute__((ext_vector_type(2)));
+    auto sload4 = [](const int* p) {
+        p2c_i4 r;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(p) : "memory");
+        return r;
     };
+    auto sload2 = [](const int* p) {
+        p2c_i2 r;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(p) : "memory");
+        return r;
+    };
+    auto pack4 = [](p2c_i4 v) { return (unsigned)((v[0] & 255) | (v[1] & 255) << 8 | (v[2] & 255) << 16 | (v[3] & 255) << 24); };
+    // packed exponents of tile f's A operand for this wave's 64-row block (K blocks 0 - 3 | 4 - 7); the launcher admits only
+    // segment shapes of 4 | 4, 8 and 4 blocks
+    auto fetch_ew = [&](int f, bool low, bool high, unsigned long long old) {
+        const int rbi = f / tpr, r = f - rbi * tpr, ti = cp.t_info[r], s = ti & 255;
+        const int erow = ((int)blockIdx.x + rbi * (int)gridDim.x) * 4 + wr;
+        const GemmP2Params& q = cp.st[s];
+        if (!q.EA) return 0ull;
+        const int nb1 = (q.K1 / P2_BK) >> 1, nb = (q.K / P2_BK + 1) >> 1;
+        unsigned lo = (unsigned)old, hi = (unsigned)(old >> 32);
+        if (low) lo = pack4(sload4(q.EA + erow * q.eld_a));
+        if (high) {
+            hi = 0;
+            if (nb1 == 8) hi = pack4(sload4(q.EA + erow * q.eld_a + 4));
+            else if (nb > nb1 && q.EA2) hi = pack4(sload4(q.EA2 + erow * q.eld_a2));
+        }
+        return (unsigned long long)hi << 32 | lo;
+    };
+    auto e_of = [](unsigned long long ew, int kb) { return (int)(signed char)(ew >> (8 * kb)); };
 
     p2_f32x16 acc[4][2];
     int lf = 0, lkt = 0;                        // load position: (flat tile, K step)
     bool ld_valid = true, ld_blocked = false;   // blocked: the next tile is hard-dependent - its loads wait for this tile's epilogue
     auto advance = [&]() {
-        if (lkt + 1 < nk_l) { ++lkt; return; }
+        if (__builtin_expect(lkt + 1 < nk_l, 1)) { ++lkt; return; }
         if (lf + 1 >= total) { ld_valid = false; return; }
         if (is_hard(lf + 1)) { ld_blocked = true; return; }
         ++lf;
@@ -155,12 +186,10 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
         setup(lf);
     };
     setup(0);
-    issue(0, 0, 0u);
+    issue(0, 0, lane_rc());
     advance();
-    int ev = fetch_e(0), ev_next = 0;
-    // (every exponent fetch is waited for where the wait is free and BEFORE the K loop is entered again: a fetch still pending at
-    // the loop's readlane would make hipcc put an s_waitcnt vmcnt(0) in front of it - in every K step)
-    asm volatile("" : "+v"(ev));
+    unsigned long long ew = fetch_ew(0, true, true, 0), ew_next = 0;  // packed exponents of the current / the next tile
+    int er_c[2] = {0, 0}, ar_c[2] = {0, 0};  // residual blocks of this wave's two 64-column chunks: exponents / max |x| bits
     const bool issue_first = wave >= 4;  // the two waves of a SIMD take opposite orders (gemm_p2.hip)
     int e_run = 0, cur_kt = 0;
     int since = 8;       // K steps since the last epilogue
@@ -169,17 +198,23 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
     // per-tile state of the compute position (wave-uniform)
     bool has_e = false, soft = false, prefetch_next = false;
     int f = 0;
+    int n_st = 0;  // (DBG & 16: per K step stamps of workgroup 0 / 101, waves 0 and 5)
     auto step = [&](auto FIRST) {
+        long long t0 = 0, t1 = 0, t2 = 0;
+        if (DBG & 16) t0 = __builtin_amdgcn_s_memtime();
         if (since == 0 && ahead) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
         else if (since <= 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (has_e) {
-            if (soft && cur_kt == 4) {  // (a soft tile never prefetches: the launcher checks - ev_next is free for its second fetch)
-                asm volatile("" : "+v"(ev_next));
-                ev = ev_next;
+        if (DBG & 16) t1 = __builtin_amdgcn_s_memtime();
+        if (has_e && (cur_kt & 1) == 0) {  // a new K block
+            // (everything that runs once per tile is marked unlikely: the K step's own path from the barrier to its first MFMA is
+            // matrix-pipe idle time, and a cold block hipcc leaves inside it costs a taken branch + an instruction fetch)
+            if (__builtin_expect(soft && cur_kt == 4, 0)) {
+                __builtin_amdgcn_s_dcache_inv();
+                ew = fetch_ew(f, false, true, ew);
             }
-            const int e_step = __builtin_amdgcn_readlane(ev, cur_kt >> 1);
+            const int e_step = e_of(ew, cur_kt >> 1);
             if (!decltype(FIRST)::value && __builtin_expect(e_step != e_run, 0)) {
                 asm volatile("s_nop 15");  // (the previous step's asm MFMAs -> the VALU below: hipcc does not pad an asm's results)
                 const int d = e_run - e_step;
@@ -192,29 +227,44 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
                         for (int r = 0; r < 16; ++r) acc[j][i][r] *= fs;
             }
             e_run = e_step;
-            // the NEXT tile's exponents: loaded beside the operand loads of K step 2, picked up at the head of step 3 (gemm_p2.hip)
-            if (prefetch_next) {
-                if (cur_kt == 2) ev_next = fetch_e(f + 1);
-                if (cur_kt == 3) asm volatile("" : "+v"(ev_next));
+            if (__builtin_expect(cur_kt == 2, 0)) {  // once per tile, beside the operand loads of K step 2
+                if (prefetch_next) ew_next = fetch_ew(f + 1, true, true, 0);
+                const int rr_ = f % tpr, ti_ = cp.t_info[rr_], s_ = ti_ & 255;
+                const GemmP2Params& q_ = cp.st[s_];
+                if ((cp.kind[s_] & 4) && q_.ER) {  // the residual blocks this wave adds in the tile's epilogue (old data: any time)
+                    const int erow = ((int)blockIdx.x + (f / tpr) * (int)gridDim.x) * 4 + wr;
+                    const int cb = ((ti_ >> 8) & 255) * 4 + wc * 2;  // (two adjacent 64-column blocks: one 8-byte load each)
+                    const p2c_i2 e2 = sload2(q_.ER + erow * q_.eld_r + cb);
+                    er_c[0] = e2[0]; er_c[1] = e2[1];
+                    if (q_.AR) {
+                        const p2c_i2 a2 = sload2(reinterpret_cast<const int*>(q_.AR) + erow * q_.eld_r + cb);
+                        ar_c[0] = a2[0]; ar_c[1] = a2[1];
+                    }
+                }
             }
-            // soft dependency: the exponents of the K blocks the tile in front stored.  Its stores retired at step 2, everybody's
-            // by step 3's barrier: the tile's exponents are fetched AGAIN at the end of step 3 and picked up at the head of step 4,
-            // right behind that step's vmcnt(0)
-            if (soft && cur_kt == 3) ev_next = fetch_e(f);
         }
         ++cur_kt;
         const bool ldv = ld_valid && !ld_blocked && !(since == 0 && ahead);
-        if (issue_first && ldv) issue(buf ^ 1, lkt, 0u);
+        if (issue_first && ldv) issue(buf ^ 1, lkt, rc_t);
+        if (DBG & 16) t2 = __builtin_amdgcn_s_memtime();
         gp_kstep<decltype(FIRST)::value>(smem_p2c, buf, wr, wc, l31, lh, acc);
         if (!issue_first && ldv) {
-            unsigned dep = 0;
-            asm("" : "+v"(dep) : "v"(acc[3][1]));  // scheduling-only: keeps the loads behind the MFMAs
-            issue(buf ^ 1, lkt, dep);
+            unsigned rc = rc_t;
+            asm("" : "+v"(rc) : "v"(acc[3][1]));  // scheduling-only: keeps the loads behind the MFMAs
+            issue(buf ^ 1, lkt, rc);
         }
         if (ldv) advance();
         if (since == 0) ahead = false;
         ++since;
         buf ^= 1;
+        if (DBG & 16) {
+            const GemmP2Params& q0 = cp.st[0];
+            if (q0.dbg && gp_lane_now() == 0 && (blockIdx.x == 0 || blockIdx.x == 101) && (wave == 0 || wave == 5) && n_st < 80) {
+                long long* o = q0.dbg + (((blockIdx.x ? 1 : 0) * 2 + (wave ? 1 : 0)) * 80 + n_st) * 4;
+                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = __builtin_amdgcn_s_memtime();
+            }
+            ++n_st;
+        }
     };
     for (f = 0; f < total; ++f) {
         const int rbi = f / tpr, r = f - rbi * tpr, ti = cp.t_info[r], s = ti & 255;
@@ -225,6 +275,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
             const int ln = gp_lane_now();
             l31 = ln & 31;
             lh = ln >> 5;
+            rc_t = lane_rc();
         }
         has_e = q.EA != nullptr || ((cp.kind[s] & 4) && q.ER != nullptr);
         soft = f > 0 && (ti & (1 << 17)) != 0;
@@ -237,14 +288,20 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
         if (ld_valid && !ld_blocked) {
             // the buffer of the step just computed is free once every wave is through it: the loads of the step after next
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            unsigned dep = 0;
-            asm("" : "+v"(dep) : "v"(acc[3][1]));
-            issue(buf ^ 1, lkt, dep);
+            unsigned rc = lane_rc();
+            asm("" : "+v"(rc) : "v"(acc[3][1]));
+            issue(buf ^ 1, lkt, rc);
             advance();
             ahead = true;
         }
         cur_kt = 0;
         gp_acc_fence(acc);
+        // the epilogue's view of the side-band: lanes 32 - 35 of one register (gp_epilogue reads them with v_readlane)
+        int ev = 0;
+        if ((cp.kind[s] & 4) && q.ER) {
+            asm("v_writelane_b32 %0, %1, 32\n\tv_writelane_b32 %0, %2, 33\n\tv_writelane_b32 %0, %3, 34\n\tv_writelane_b32 %0, %4, 35"
+                : "+v"(ev) : "s"(er_c[0]), "s"(er_c[1]), "s"(ar_c[0]), "s"(ar_c[1]));
+        }
         if (!(DBG & 4)) {
             switch (cp.kind[s]) {
                 case P2_OUT_PLANES: gp_epilogue<P2_OUT_PLANES, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
@@ -256,7 +313,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
             asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));
         }
         if (DBG & 8) ts2 = __builtin_amdgcn_s_memtime();
-        ev = ev_next;
+        ew = ew_next;
         since = 0;
         if (ld_blocked) {
             // hard hand-off: every wave's stores of this tile have retired, then everybody's have; the consumer starts like a first tile
@@ -266,10 +323,10 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
             ++lf;
             lkt = 0;
             setup(lf);
-            ev = fetch_e(lf);
-            issue(buf, 0, 0u);
+            __builtin_amdgcn_s_dcache_inv();
+            ew = fetch_ew(lf, true, true, 0);
+            issue(buf, 0, lane_rc());
             advance();
-            asm volatile("" : "+v"(ev));
             since = 8;
             ahead = false;
         }
@@ -292,16 +349,22 @@ int launch_gemm_p2_chain(e2emv_ctx* ctx, const GemmP2Args* a, const int* dep_kt,
         if (a[i].K < 4 * P2_BK) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2 chain: K = %d (the store / load overlap needs >= 4 K steps)", a[i].K);
         if (a[i].out == P2_OUT_F32 && a[i].Rp) return set_err(ctx, E2EMV_ESHAPE, "gemm_p2 chain: fp32 output with a residual is not a chain stage");
         if (dep_kt[i] != 0 && dep_kt[i] < 4) return set_err(ctx, E2EMV_EINVAL, "gemm_p2 chain: dep_kt %d (0, >= 4 or independent)", dep_kt[i]);
-        // a softly dependent stage is one tile, followed by a hard one (the kernel's second exponent fetch borrows the register of
-        // the next tile's prefetch, which a hard successor does not use)
-        if (dep_kt[i] >= 4 && dep_kt[i] != P2C_INDEP && (a[i].N != P2_BN || i + 1 >= n || dep_kt[i + 1] != 0))
-            return set_err(ctx, E2EMV_EINVAL, "gemm_p2 chain: a softly dependent stage must be one tile wide and be followed by a hard-dependent one");
+        // a softly dependent stage is one tile, followed by a hard one; the first exponent that depends is requested at step
+        // dep_kt - 2, behind the scalar-cache invalidate of step 4
+        if (dep_kt[i] >= 4 && dep_kt[i] != P2C_INDEP && (a[i].N != P2_BN || i + 1 >= n || dep_kt[i + 1] != 0 || dep_kt[i] < 8 || (dep_kt[i] & 1)))
+            return set_err(ctx, E2EMV_EINVAL, "gemm_p2 chain: a softly dependent stage must be one tile wide, depend from an even K step >= 8 on and be followed by a hard-dependent one");
         if (i == 0 && dep_kt[i] != P2C_INDEP) return set_err(ctx, E2EMV_EINVAL, "gemm_p2 chain: the first stage cannot depend on a tile before it");
         // a soft dependency may only reach back over the tile right in front: the tiles before that one must have retired their
         // stores, which the K loop of one tile (>= 4 steps) guarantees
         if ((cp.st[i].EA != nullptr) != (cp.st[0].EA != nullptr)) return set_err(ctx, E2EMV_EINVAL, "gemm_p2 chain: tile exponents on all stages or on none");
+        // the scalar side-band of the kernel: K segments of 4 | 4, 8 or 4 exponent blocks, residual blocks in adjacent pairs
+        if (a[i].EA) {
+            const int nb1 = (a[i].A2 ? a[i].K1 : a[i].K) / 64, nb = a[i].K / 64;
+            if (!((nb1 == 4 && (nb == 4 || nb == 8)) || (nb1 == 8 && nb == 8)) || (a[i].ER && (a[i].ldr / 64) % 2))
+                return set_err(ctx, E2EMV_ESHAPE, "gemm_p2 chain: stage %d: tile exponents need K segments of 256 | 256, 512 or 256 columns (K=%d K1=%d)", i, a[i].K, a[i].K1);
+        }
         // whole tiles only, one row stride for both K segments (the one-register loader of the kernel)
-        if (a[i].M % P2_BM || a[i].N % P2_BN || (a[i].A2 && a[i].lda2 != a[i].lda))
+        if (a[i].M % P2_BM || a[i].N % P2_BN || (a[i].A2 && a[i].lda2 != a[i].lda) || a[i].lda * 4 >= (1 << 24) || (int64_t)a[i].K * 4 >= (1 << 24))
             return set_err(ctx, E2EMV_ESHAPE, "gemm_p2 chain: stage %d needs M, N multiples of 256 and lda2 == lda (M=%d N=%d)", i, a[i].M, a[i].N);
         cp.kind[i] = a[i].out | (a[i].Rp ? 4 : 0);
         cp.dep_kt[i] = dep_kt[i];
@@ -321,15 +384,19 @@ int launch_gemm_p2_chain(e2emv_ctx* ctx, const GemmP2Args* a, const int* dep_kt,
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("E2EMV_P2C_DBG"); dbg = e ? atoi(e) : 0; }
     static long long* d_buf = nullptr;
-    const size_t nb = sizeof(long long) * 2 * 8 * 12 * 4;
+    const size_t nb = sizeof(long long) * 4 * 80 * 4;  // (>= 2 * 8 * 12 * 4)
     switch (dbg) {
         case 4: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<4>); break;
         case 8: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<8>); break;
         case 512: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<512>); break;
         case 516: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<516>); break;
+        case 1024: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<1024>); break;
+        case 1028: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<1028>); break;
+        case 2048: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<2048>); break;
+        case 16: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<16>); break;
         default: break;
     }
-    if (dbg == 8) {
+    if (dbg == 8 || dbg == 16) {
         if (!d_buf) E2EMV_HIP(ctx, hipMalloc((void**)&d_buf, nb));
         E2EMV_HIP(ctx, hipMemsetAsync(d_buf, 0, nb, s));
         for (int i = 0; i < n; ++i) cp.st[i].dbg = d_buf;
@@ -340,6 +407,21 @@ int launch_gemm_p2_chain(e2emv_ctx* ctx, const GemmP2Args* a, const int* dep_kt,
     E2EMV_HIP(ctx, hipLaunchKernel(fn, dim3(grid), dim3(512), args, P2_LDSB, s));
     E2EMV_CHECK_LAUNCH(ctx, "gemm_p2_chain_kernel");
 #ifdef E2EMV_STAMPS
+    if (dbg == 16) {
+        static int printed16 = 0;
+        if (printed16++ < 2) {
+            E2EMV_HIP(ctx, hipStreamSynchronize(s));
+            std::vector<long long> h(4 * 80 * 4);
+            E2EMV_HIP(ctx, hipMemcpy(h.data(), d_buf, nb, hipMemcpyDeviceToHost));
+            for (int q = 0; q < 4; ++q) {
+                fprintf(stderr, "gemm_p2_chain wg %d wave %d: per K step  wait+barrier | exponents+issue | compute(+issue) | total   (ticks)\n", (q >> 1) ? 101 : 0, (q & 1) ? 5 : 0);
+                const long long* o = &h[(size_t)q * 80 * 4];
+                for (int i = 0; i < 80 && o[4 * i]; ++i)
+                    fprintf(stderr, "  %2d: %5lld %5lld %5lld | %5lld   (gap to next %lld)\n", i, o[4 * i + 1] - o[4 * i], o[4 * i + 2] - o[4 * i + 1], o[4 * i + 3] - o[4 * i + 2],
+                            o[4 * i + 3] - o[4 * i], i + 1 < 80 && o[4 * i + 4] ? o[4 * i + 4] - o[4 * i + 3] : 0);
+            }
+        }
+    }
     if (dbg == 8) {
         static int printed = 0;
         if (printed++ < 3) {

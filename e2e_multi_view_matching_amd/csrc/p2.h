@@ -71,6 +71,11 @@ __device__ __forceinline__ p2_f32x2 p2_join_plain(unsigned hi, unsigned lo) {
 __device__ __forceinline__ void p2_glds16(__amdgpu_buffer_rsrc_t rsrc, char* dst, unsigned voffset, unsigned soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 0);
 }
+// the same with the non-temporal hint (aux = 2: nt): a stream ONE CU reads - it should not push the weight tiles every CU
+// re-reads out of the XCD's L2
+__device__ __forceinline__ void p2_glds16_nt(__amdgpu_buffer_rsrc_t rsrc, char* dst, unsigned voffset, unsigned soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 2);
+}
 
 // ---- range side-band: tile exponents -------------------------------------------------------------------------------------
 // fp16 planes have fp16's exponent range.  Every plane tensor therefore carries one int32 exponent e per block of 64 rows x

@@ -578,6 +578,7 @@ static inline int skr_rw(int64_t ldS) {
 }
 static inline int skr_rows(int64_t ldS) { return 8 * skr_rw(ldS); }
 constexpr unsigned SKR_SPIN_LIMIT = 1u << 21;
+constexpr unsigned SKR_GAVE_UP_NAN = 0x7fc0dead;  // potentials of a problem whose inter-workgroup wait gave up
 
 struct SkResParams {
     const float* S;     // [B][M][ldS]
@@ -970,7 +971,9 @@ __global__ __launch_bounds__(512, (KT <= 4 && RW == 4) ? 4 : 2) void sinkhorn_re
         // from workgroup 0 the dustbin-row potential and v = log b.  A scaling that left fp32's range (zero, infinite,
         // NaN) or a give-up in the exchange is counted in the sticky error word; its NaN / inf reaches the outputs.
         {
-            const float qnan = __uint_as_float(0x7fc00000u);
+            // (a give-up marks ITS problem with a NaN of its own payload: the rescue pass books the problem as a timeout - contention,
+            // says nothing about the model - only when it finds that mark; a scaling that left fp32's range yields inf / the default NaN)
+            const float qnan = __uint_as_float(SKR_GAVE_UP_NAN);
             float* ub = p.u + (int64_t)b * (M + 1);
             bool bad = false;
 #pragma unroll
@@ -1009,10 +1012,11 @@ __global__ __launch_bounds__(1024) void sinkhorn_rescue(SkParams p, int iters, u
     const int M = p.M, N = p.N;
     float* ub = p.u + (int64_t)b * (M + 1);
     float* vb = p.v + (int64_t)b * p.ldV;
-    bool bad = false;
-    for (int i = tid; i <= M; i += 1024) bad = bad || !(fabsf(ub[i]) < INFINITY);
-    for (int j = tid; j <= N; j += 1024) bad = bad || !(fabsf(vb[j]) < INFINITY);
+    bool bad = false, gave_up = false;
+    for (int i = tid; i <= M; i += 1024) { const float x = ub[i]; bad = bad || !(fabsf(x) < INFINITY); gave_up = gave_up || __float_as_uint(x) == SKR_GAVE_UP_NAN; }
+    for (int j = tid; j <= N; j += 1024) { const float x = vb[j]; bad = bad || !(fabsf(x) < INFINITY); gave_up = gave_up || __float_as_uint(x) == SKR_GAVE_UP_NAN; }
     if (!__syncthreads_or(bad ? 1 : 0)) return;
+    const int timed_out = __syncthreads_or(gave_up ? 1 : 0);  // THIS problem's reason (the launch-global flag says nothing about it)
     float* su = lds;            // [M + 1]
     float* sv = lds + (M + 1);  // [N + 1]
     const float* Sb = p.S + (int64_t)b * M * p.ldS;
@@ -1055,8 +1059,8 @@ __global__ __launch_bounds__(1024) void sinkhorn_rescue(SkParams p, int iters, u
     }
     const int still = __syncthreads_or(bad ? 1 : 0);
     // [1] non-finite even in the log domain (non-finite scores: an error); otherwise rescued - [6] when a wait of the resident
-    // kernel gave up in this launch (contention: says nothing about the model), [3] when not (a scaling left fp32's range)
-    if (tid == 0) atomicAdd(flags + (still ? 1 : (flags[0] ? 6 : 3)), 1u);
+    // kernel gave up on THIS problem (contention: says nothing about the model), [3] when not (a scaling left fp32's range)
+    if (tid == 0) atomicAdd(flags + (still ? 1 : (timed_out ? 6 : 3)), 1u);
 }
 
 // streaming chain: the potentials of a problem with non-finite scores are non-finite - counted like the resident path's

@@ -44,7 +44,7 @@ if "--one" in sys.argv:
           f"{1e3 * at['ms'] / max(at['launches'], 1):7.1f} us   gemm_qkv {1e3 * pr['gemm_qkv']['ms'] / max(pr['gemm_qkv']['launches'], 1):6.1f} us", flush=True)
     sys.exit(0)
 
-for dbg in [0, 4, 512, 516, 8]:
+for dbg in ([int(a) for a in sys.argv[1:] if a.isdigit()] or [0, 4, 512, 516, 8]):
     env = dict(os.environ, E2EMV_LIBRARY=LIB, E2EMV_P2C_DBG=str(dbg))
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     out = "\n".join(l for l in r.stdout.splitlines() if "amdgpu.ids" not in l)
