@@ -430,11 +430,11 @@ int launch_gemm_p2_chain(e2emv_ctx* ctx, const GemmP2Args* a, const int* dep_kt,
             E2EMV_HIP(ctx, hipMemcpy(h.data(), d_buf, nb, hipMemcpyDeviceToHost));
             for (int wg = 0; wg < 2; ++wg)
                 for (int w = 0; w < 8; w += 5) {
-                    fprintf(stderr, "gemm_p2_chain wg %d wave %d: per tile  K loop | ahead-issue + epilogue | hand-off   (100 MHz ticks x 10 = ns)\n", wg ? 101 : 0, w);
+                    fprintf(stderr, "gemm_p2_chain wg %d wave %d: per tile  K loop | ahead-issue + epilogue | hand-off   (s_memtime ticks, ~0.54 ns each)\n", wg ? 101 : 0, w);
                     const long long* o = &h[((size_t)wg * 8 + w) * 12 * 4];
                     for (int f = 0; f < tiles && f < 12; ++f)
-                        fprintf(stderr, "  tile %d: %6lld | %6lld | %6lld   (start +%lld)\n", f, 10 * (o[4 * f + 1] - o[4 * f]), 10 * (o[4 * f + 2] - o[4 * f + 1]),
-                                10 * (o[4 * f + 3] - o[4 * f + 2]), 10 * (o[4 * f] - o[0]));
+                        fprintf(stderr, "  tile %d: %6lld | %6lld | %6lld   (start +%lld)\n", f, o[4 * f + 1] - o[4 * f], o[4 * f + 2] - o[4 * f + 1],
+                                o[4 * f + 3] - o[4 * f + 2], o[4 * f] - o[0]);
                 }
         }
     }
