@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
             // (everything that runs once per tile is marked unlikely: the K step's own path from the barrier to its first MFMA is
             // matrix-pipe idle time, and a cold block hipcc leaves inside it costs a taken branch + an instruction fetch)
             if (__builtin_expect(soft && cur_kt == 4, 0)) {
-                __builtin_amdgcn_s_dcache_inv();
+                asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
                 ew = fetch_ew(f, false, true, ew);
             }
             const int e_step = e_of(ew, cur_kt >> 1);
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
             ++lf;
             lkt = 0;
             setup(lf);
-            __builtin_amdgcn_s_dcache_inv();
+            asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
             ew = fetch_ew(lf, true, true, 0);
             issue(buf, 0, lane_rc());
             advance();
