@@ -112,6 +112,22 @@ bench)
   timeout 300 python bench.py --config c5 --cpu-pairs 0 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
   show $OUT/bench_c2.json $OUT/bench_c4.json $OUT/bench_c5.json
   ;;
+final)
+  # end-of-round evidence in ONE call on ONE box: kernel trace + three PMC passes of configs[1] (the traffic file the bench line
+  # reads is the one these passes just wrote), the three bench lines, kernel traces of configs[3] / the configs[4] share, and the
+  # at::native count of a trace with three times the steps
+  bash tools/gpu.sh prof c2 f16x2
+  cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
+  bash tools/gpu.sh bench
+  bash tools/gpu.sh kt c4 f16x2 > /dev/null
+  bash tools/gpu.sh kt c5 f16x2 > /dev/null
+  args="--steps 6 --warmup 1 --cpu-pairs 0 --no-alt --no-latency --no-profile"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_c2_steps6 -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_c2_steps6.log 2>&1)
+  db=$(find /tmp/kt_c2_steps6 -name '*.db' | head -1)
+  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r5_kernel_stats_c2_f16x2_steps6.md 2>&1
+  echo "at::native launches: steps 2 / steps 6"; grep "at::native" $OUT/r5_kernel_stats_c2_f16x2.md $OUT/r5_kernel_stats_c2_f16x2_steps6.md
+  grep "gemm_p2_chain\|attention_p2w" $OUT/r5_kernel_stats_c2_f16x2.md $OUT/r5_kernel_stats_c2_f16x2_steps6.md
+  ;;
 one)
   timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_one.json 2> $OUT/bench_one.err
   show $OUT/bench_one.json
