@@ -20,7 +20,7 @@
 //   * soft, dep_kt >= 4 (MLP1: K steps 0 - 7 read the hidden columns of MLP0's FIRST tile, whose stores retired - counted
 //     vmcnt(0) of K step 2 + the barrier of step 3 - long before; steps 8 - 15 read the second tile's, stored by the epilogue
 //     right in front): the loads still run ahead - the steps that depend are issued behind step 3's barrier by
-//     construction - and only the exponent side-band of the tile is fetched again at step 3;
+//     construction - and only the exponents of the K blocks that depend are fetched again, at step 4;
 //   * hard, dep_kt == 0 (q | k | v / final_proj read x_new from K step 0 on): no run-ahead; after the producer's epilogue
 //     the workgroup waits for its stores (vmcnt(0)), meets at a barrier and starts the consumer like a first tile.  This is
 //     the one exposed store drain per row block and launch (gemm_p2 exposes one per launch and tile round).
@@ -38,14 +38,15 @@ constexpr int P2C_INDEP = P2_CHAIN_INDEP;
 struct GemmP2ChainParams {
     GemmP2Params st[P2C_MAX_STAGES];
     int kind[P2C_MAX_STAGES];       // P2_OUT_* | 4 = with residual
-    int dep_kt[P2C_MAX_STAGES];     // see above; P2C_INDEP = the stage's operands come from earlier launches
+    int dep_kt[P2C_MAX_STAGES];     // see above; P2C_INDEP = the stage's operands come from earlier launches (the kernel reads t_info)
     int first[P2C_MAX_STAGES + 1];  // index of a stage's first tile among the tiles of a row block; [n_stages] = tiles per row block
     int n_stages, row_blocks;
     int t_info[P2C_MAX_TILES];      // per tile of a row block: stage | column tile << 8 | hard << 16 | soft << 17 (one scalar load)
 };
 
-// DBG (instantiated only in -DE2EMV_STAMPS builds, tools/p2c_stamps.py; results wrong but for 8): 4 no epilogue, 8 s_memtime stamps
-// per tile (K loop | epilogue | hand-off) of two workgroups, 512 no wait at the hard hand-off, 1024 activation loads non-temporal
+// DBG (instantiated only in -DE2EMV_STAMPS builds, tools/p2c_stamps.py; results wrong but for 8, 16, 1024): 4 no epilogue, 8 s_memtime
+// stamps per tile (K loop | epilogue | hand-off) of two workgroups, 16 stamps per K step, 512 no wait at the hard hand-off, 1024
+// activation loads non-temporal, 2048 odd column tiles walk K backwards
 template <int DBG>
 __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams cp_by_value) {
     extern __shared__ __attribute__((aligned(16))) char smem_p2c[];
