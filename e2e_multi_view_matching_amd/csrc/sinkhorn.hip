@@ -385,8 +385,11 @@ struct MatchParams {
     float* ms1[kMaxGroups];
 };
 
-// Mutual check (match block of SuperGlue.forward).  One workgroup per pair, indices in LDS.
-__global__ __launch_bounds__(256) void match_finalize(MatchParams p) {
+// Mutual check (match block of SuperGlue.forward).  One workgroup per pair, indices in LDS; 1024 threads: the kernel is a chain of
+// dependent loads per column (the chunk partials of the column arg-max) on as few workgroups as there are pairs - 256 threads
+// took 35 us for 32 pairs of 1024 keypoints.
+constexpr int MF_THREADS = 1024;
+__global__ __launch_bounds__(MF_THREADS) void match_finalize(MatchParams p) {
     extern __shared__ int sidx[];  // idx0 [M] | idx1 [N] | valid0 [M]
     int* i0 = sidx;
     int* i1 = sidx + p.M;
@@ -397,8 +400,8 @@ __global__ __launch_bounds__(256) void match_finalize(MatchParams p) {
     int64_t* const om1 = p.m1[grp];
     float* const oms0 = p.ms0[grp];
     float* const oms1 = p.ms1[grp];
-    for (int i = tid; i < p.M; i += 256) i0[i] = p.idx0[(int64_t)b * p.M + i];
-    for (int j = tid; j < p.N; j += 256) {
+    for (int i = tid; i < p.M; i += MF_THREADS) i0[i] = p.idx0[(int64_t)b * p.M + i];
+    for (int j = tid; j < p.N; j += MF_THREADS) {
         if (p.idx1_in) {
             i1[j] = p.idx1_in[(int64_t)b * p.N + j];
         } else {
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(256) void match_finalize(MatchParams p) {
         }
     }
     __syncthreads();
-    for (int i = tid; i < p.M; i += 256) {
+    for (int i = tid; i < p.M; i += MF_THREADS) {
         const int j = i0[i];
         const bool mutual = i1[j] == i;
         const float sc = mutual ? __expf(p.max0[(int64_t)b * p.M + i]) : 0.f;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256) void match_finalize(MatchParams p) {
         if (om0) om0[(int64_t)bl * p.M + i] = valid ? (int64_t)j : (int64_t)-1;
     }
     __syncthreads();
-    for (int j = tid; j < p.N; j += 256) {
+    for (int j = tid; j < p.N; j += MF_THREADS) {
         const int i = i1[j];
         const bool mutual = i0[i] == j;
         // mscores1 = where(mutual1, mscores0.gather(idx1), 0): mscores0[i] is exp(max0[i]) iff i is mutual
@@ -1309,7 +1312,7 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
         for (int g = 0; g < out.n_groups; ++g) {
             mp.m0[g] = out.m0[g]; mp.m1[g] = out.m1[g]; mp.ms0[g] = out.ms0[g]; mp.ms1[g] = out.ms1[g];
         }
-        hipLaunchKernelGGL(match_finalize, dim3(B), dim3(256), sizeof(int) * (2 * M + N), s, mp);
+        hipLaunchKernelGGL(match_finalize, dim3(B), dim3(MF_THREADS), sizeof(int) * (2 * M + N), s, mp);
         E2EMV_CHECK_LAUNCH(ctx, "match_finalize");
     }
     return E2EMV_OK;
@@ -1369,7 +1372,7 @@ extern "C" int e2emv_extract_matches(e2emv_ctx* ctx, int B, int M, int N, const 
     mp.max0 = max0; mp.idx0 = idx0; mp.idx1_in = idx1; mp.thr = match_threshold;
     mp.group_batch = B;
     mp.m0[0] = d_matches0; mp.m1[0] = d_matches1; mp.ms0[0] = d_mscores0; mp.ms1[0] = d_mscores1;
-    hipLaunchKernelGGL(match_finalize, dim3(B), dim3(256), sizeof(int) * (2 * M + N), s, mp);
+    hipLaunchKernelGGL(match_finalize, dim3(B), dim3(MF_THREADS), sizeof(int) * (2 * M + N), s, mp);
     prof_end(ctx, s);
     E2EMV_CHECK_LAUNCH(ctx, "extract_matches kernels");
     return E2EMV_OK;
