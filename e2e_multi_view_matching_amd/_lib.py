@@ -231,10 +231,11 @@ class Context:
         non-finite scores, 'sinkhorn_rescued': problems re-solved in the log domain behind the resident kernel (correct
         outputs), 'attention_slow_tiles': (wave, stream, key tile) softmaxes attention_p2w redid on its slow path - a row
         maximum outgrew the running one by more than ~2^9} since the last reset (host-synchronising)."""
-        v = (ctypes.c_uint64 * 5)()
-        self.call("e2emv_get_stats", v, 5, 1 if reset else 0)
+        v = (ctypes.c_uint64 * 6)()
+        self.call("e2emv_get_stats", v, 6, 1 if reset else 0)
         return {"rescaled_blocks": int(v[0]), "sinkhorn_bad": int(v[1]), "sinkhorn_rescued": int(v[2]), "attention_slow_tiles": int(v[3]),
-                "sinkhorn_timeouts": int(v[4])}  # (of the rescued: given up on a wait - contention -, not on range)
+                "sinkhorn_timeouts": int(v[4]),  # (of the rescued: given up on a wait - contention -, not on range)
+                "sinkhorn_rows128_calls": int(v[5])}  # (Sinkhorn calls on 128-row workgroups: fewer rounds for a large batch)
 
     def set_split_min_rows(self, min_rows=-1):
         """Calls with fewer keypoint rows than this run the fp32-MFMA kernels even in a split-operand mode

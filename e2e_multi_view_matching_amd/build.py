@@ -43,6 +43,35 @@ def build_library(force=False, verbose=False, defines=(), out=None):
     return LIB
 
 
+def check_register_window(asm_file, kernel, window):
+    """Every instance of `kernel` in the device assembly: outside its inline-asm statements the compiler touches no vector or
+    accumulation register >= `window` (those hold data placed there by number), and the wave is allocated 256 + 256 registers.
+    Returns the number of instances checked; raises RuntimeError otherwise."""
+    import re
+    txt = open(asm_file).read()
+    n = 0
+    for m in re.finditer(r"^(_Z\w*%s\w*):" % kernel, txt, re.M):
+        end = txt.index(".end_amdhsa_kernel", m.end())
+        body, desc = txt[m.end():end], txt[end - 4000:end]
+        if "amdhsa_next_free_vgpr 512" not in desc or "amdhsa_accum_offset 256" not in desc:
+            raise RuntimeError(f"{m.group(1)}: the wave is not allocated 256 + 256 registers")
+        inasm = False
+        for line in body.split("\n"):
+            if "#ASMSTART" in line:
+                inasm = True
+            elif "#ASMEND" in line:
+                inasm = False
+            elif not inasm:
+                code = line.split(";")[0]
+                regs = [int(x) for x in re.findall(r"\b[va](\d+)\b", code)] + [int(x) for x in re.findall(r"\b[va]\[\d+:(\d+)\]", code)]
+                if regs and max(regs) >= window:
+                    raise RuntimeError(f"{m.group(1)}: compiler-generated code touches a register outside its window: {line.strip()}")
+        n += 1
+    if n == 0:
+        raise RuntimeError(f"{kernel}: not found in {asm_file}")
+    return n
+
+
 def _build(hipcc, objdir, lib, extra, verbose):
     os.makedirs(objdir, exist_ok=True)
     procs = []
@@ -50,6 +79,11 @@ def _build(hipcc, objdir, lib, extra, verbose):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    # sinkhorn_resident128 keeps most of its data in registers it addresses by number, outside the window its
+    # amdgpu_num_vgpr attribute leaves to the compiler: the device assembly is checked for that (check_register_window)
+    asm_file = os.path.join(objdir, "sinkhorn.s")
+    asm_proc = subprocess.Popen([hipcc] + FLAGS + extra + ["--cuda-device-only", "-S", os.path.join(CSRC, "sinkhorn.hip"), "-o", asm_file],
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     objs = []
     for src, obj, p in procs:
         out, _ = p.communicate()
@@ -58,6 +92,10 @@ def _build(hipcc, objdir, lib, extra, verbose):
         if verbose and out.strip():
             print(out)
         objs.append(obj)
+    out, _ = asm_proc.communicate()
+    if asm_proc.returncode != 0:
+        raise RuntimeError(f"hipcc -S failed on sinkhorn.hip:\n{out}")
+    check_register_window(asm_file, "sinkhorn_resident128", 56)
     # the dynamic symbol table is the C ABI of include/e2emv.h and nothing else (hipcc gives kernel host stubs default
     # visibility whatever -fvisibility says: the version script takes them and every C++ internal out)
     vs = os.path.join(objdir, "e2emv.map")

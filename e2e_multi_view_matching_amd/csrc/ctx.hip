@@ -627,13 +627,14 @@ int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset) {
     if (ctx->d_flags) E2EMV_HIP(ctx, hipMemcpy(f, ctx->d_flags, sizeof(f), hipMemcpyDeviceToHost));
     ctx->stat_sinkhorn_bad += f[1];
     if (ctx->d_flags) note_rescues(ctx, f[3], f[6]);
-    const uint64_t v[5] = {(uint64_t)f[2], ctx->stat_sinkhorn_bad, ctx->stat_sinkhorn_rescued, (uint64_t)f[5], ctx->stat_sinkhorn_timeouts};
-    for (int i = 0; i < n; ++i) stats[i] = i < 5 ? v[i] : 0;
+    const uint64_t v[6] = {(uint64_t)f[2], ctx->stat_sinkhorn_bad, ctx->stat_sinkhorn_rescued, (uint64_t)f[5], ctx->stat_sinkhorn_timeouts, ctx->stat_sinkhorn_rows128};
+    for (int i = 0; i < n; ++i) stats[i] = i < 6 ? v[i] : 0;
     if (ctx->d_flags && f[1]) E2EMV_HIP(ctx, hipMemset(ctx->d_flags + 1, 0, sizeof(unsigned)));  // moved into the host-side total
     if (reset) {
         ctx->stat_sinkhorn_bad = 0;
         ctx->stat_sinkhorn_rescued = 0;
         ctx->stat_sinkhorn_timeouts = 0;
+        ctx->stat_sinkhorn_rows128 = 0;
         ctx->sk_range_strikes = 0;
         ctx->sk_stream_calls = 0;
         ctx->sinkhorn_stream = false;  // (a reset also returns the Sinkhorn to the resident kernel)

@@ -570,6 +570,23 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));  // the builtin is typed int: bit-cast, never convert
 }
 
+// Four wave-wide sums at once: lane l returns the sum of x[l & 3] over the wave.  The first two steps are butterflies that
+// halve the number of live vectors (a lane keeps the operand of its own class and sends the other), then one vector is reduced
+// over the four quads of a row (rotations by 4 and 8) and over the four rows (gfx950's row / half-wave swaps): 12 cross-lane
+// operations for four sums instead of 24, and the sums arrive in four LANES - what follows (a division per row) runs once.
+__device__ __forceinline__ float wave_sum4_dpp(float x0, float x1, float x2, float x3, int lane) {
+    const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
+    const float u01 = (o1 ? x1 : x0) + dpp_move<0xB1, 0xF>(0.f, o1 ? x0 : x1);  // quad_perm [1,0,3,2]
+    const float u23 = (o1 ? x3 : x2) + dpp_move<0xB1, 0xF>(0.f, o1 ? x2 : x3);
+    float t = (o2 ? u23 : u01) + dpp_move<0x4E, 0xF>(0.f, o2 ? u01 : u23);      // quad_perm [2,3,0,1]
+    t += dpp_move<0x124, 0xF>(0.f, t);                                           // row_ror:4
+    t += dpp_move<0x128, 0xF>(0.f, t);                                           // row_ror:8
+    auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    t = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+    auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
+
 // rows per workgroup: 8 waves x 4 rows up to 1024 columns, 8 x 2 rows up to 2048 (64 matrix values per lane either way)
 // rows per workgroup: 8 waves x RW rows.  RW = 4 (64 matrix values per lane at 1024 columns, two workgroups per CU) or RW = 8 at
 // 1024 columns (128 values per lane, one workgroup per CU: the same number of resident problems, HALF as many workgroups in a
@@ -1001,6 +1018,315 @@ __global__ __launch_bounds__(512, (KT <= 4 && RW == 4) ? 4 : 2) void sinkhorn_re
 }
 
 
+// ---- 128 rows per workgroup: ALL problems of a 32-pair batch resident at once (round 5) -----------------------------------------
+// sinkhorn_resident keeps 64 rows x 1024 columns per workgroup (one per CU) in registers: 16 problems of 1024 x 1024 fill the chip,
+// a batch of 32 runs as two rounds of 100 iterations, and an iteration is bound by the exchange, not by the arithmetic.  Here a
+// workgroup owns 128 rows - 8 workgroups per problem, 32 problems resident, ONE round - which needs 512 KB of couplings per CU,
+// the size of the register file.  What makes it fit:
+//   * FOUR waves per workgroup, one per SIMD: a wave then has 512 registers per lane (256 VGPRs + 256 AGPRs); 24 of its 32 rows live
+//     there (384 values per lane - hipcc parks what does not fit the VGPRs in the accumulator file, one v_accvgpr_read per use),
+//     8 rows in LDS (128 KB per workgroup);
+//   * ONE pass over the couplings per iteration: a_i depends on row i's sum alone (rows are whole inside a wave), so a row's
+//     column contribution K_ij a_i is accumulated right behind its row sum - no a[] array, no second sweep over K (the row
+//     kernel's two half-iterations read K twice: twice the accumulator-file reads and LDS traffic here);
+//   * the fold buffer holds the 4 waves' partial column sums (16 KB).
+// Exchange, epochs, give-up protocol, rescue: the row kernel's (pair mode), with the lane mappings of 256 threads.  An iteration
+// costs about twice the arithmetic per CU and the same two hops, for half as many rounds: chosen by the launcher when it saves
+// rounds (more than 16 problems of 513 ... 1024 columns).
+template <int... I, class F>
+__device__ __forceinline__ void sk_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void sk_static_for(F&& f) { sk_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+// rows of a wave: 12 in vector registers v64 .. v255, 12 in accumulation registers a64 .. a255, 8 in LDS
+constexpr int SK128_RV = 12, SK128_RA = 12, SK128_RL = 8, SK128_RR = SK128_RV + SK128_RA, SK128_R0 = 64;
+constexpr int sk128_base(int r) { return SK128_R0 + 16 * (r < SK128_RV ? r : r - SK128_RV); }
+#include "sinkhorn128_rows.h"
+template <bool FULL>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void sinkhorn_resident128(SkResParams p) {
+    constexpr int KT = 4, W = 1024, RW = SK128_RR + SK128_RL, ROWS = 4 * RW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* klds = lds;                       // [4 waves][RL rows][W]: the LDS-resident rows of K
+    float* fold = klds + 4 * SK128_RL * W;   // [4][W] partial column sums
+    float* vbuf = fold + 4 * W;              // [W + 4]: b of the current iteration (+ b_N at [W])
+    float* red = vbuf + W + 4;               // [32]
+    float* rks = red + 32;                   // [ROWS] r_i = exp(alpha - rowmax_i)
+    float* mrs = rks + ROWS;                 // [ROWS] rowmax_i
+    float* asv = mrs + ROWS;                 // [ROWS] a_i of the last iteration (for the potentials)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = blockIdx.x / p.G, w = blockIdx.x % p.G;
+    const int G = p.G, cs = p.cs, N = p.N, M = p.M;
+    const int row0 = w * ROWS + wave * RW;
+    u64* const bufA = p.bufA + (int64_t)grp * G * G * cs;
+    u64* const bufB = p.bufB + (int64_t)grp * G * cs;
+    u64* const bufU2 = p.bufU + (int64_t)grp * 2 * G;
+    bool dead = false;
+    const bool nap = !(p.flags & 1);
+    const float mu = 1.0f / (float)(M + N), muM = (float)N / (float)(M + N), nuN = (float)M / (float)(M + N);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(bufA, 0, G * G * cs * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(bufB, 0, G * cs * 8, 0x00020000);
+    float* const kl = klds + wave * SK128_RL * W + 4 * lane;  // this lane's first chunk of the wave's LDS rows (chunk k: + 256 k)
+    unsigned round = 0;
+    for (int b = grp; b < p.B; b += p.n_res, ++round) {
+        const unsigned ebase = round * (unsigned)p.iters;
+        const float* Sb = p.S + (int64_t)b * M * p.ldS;
+        // ---- load the wave's 32 rows, shift by the row maximum, exponentiate once; rows 24 - 31 go to LDS
+        // 24 of the wave's 32 rows live in registers the compiler does not allocate: amdgpu_num_vgpr(56) confines it to v0 - v55
+        // (and a0 - a55 as its spill space); v56 - v63 are the row pass's temporaries, v64 - v255 hold rows 0 - 11 and a64 - a255
+        // rows 12 - 23, as [16 r + 4 k + e].  hipcc's allocator cannot keep 384 values in place for a whole call (it spills
+        // exactly the long-lived ones: profiles/r5_sinkhorn_blocks.log), so these registers are written (v_mov / v_accvgpr_write,
+        // once per problem) and read (the row pass in sinkhorn128_rows.h, twice per iteration) by number.  The clobber sizes the
+        // wave's allocation at 256 + 256 registers; tests/test_host_and_abi.py disassembles the kernel and checks that nothing
+        // outside these statements touches a register above v55 / a55.
+        asm volatile("" ::: "v255", "a255");
+        sk_static_for<RW>([&](auto r_c) {
+            constexpr int r = decltype(r_c)::value;
+            const int row = FULL ? row0 + r : min(row0 + r, M - 1);
+            f32x4 zz[KT];
+            float mx = p.alpha;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const int c = 4 * (lane + 64 * k);
+                zz[k] = (FULL || c < p.ldS) ? *reinterpret_cast<const f32x4*>(Sb + (int64_t)row * p.ldS + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (FULL || c + e < N) mx = fmaxf(mx, zz[k][e]);
+            }
+            mx = wave_max_dpp(mx);
+            const bool rvalid = FULL || row0 + r < M;
+            if (lane == 0) {
+                mrs[wave * RW + r] = mx;
+                rks[wave * RW + r] = rvalid ? exp_accurate(p.alpha - mx) : 0.f;
+            }
+            sk_static_for<KT>([&](auto k_c) {
+                constexpr int k = decltype(k_c)::value;
+                const int c = 4 * (lane + 64 * k);
+                f32x4 kv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kv[e] = (rvalid && (FULL || c + e < N)) ? exp_accurate(zz[k][e] - mx) : 0.f;
+                if constexpr (r < SK128_RV) {
+                    const float k0 = kv[0], k1 = kv[1], k2 = kv[2], k3 = kv[3];
+                    asm volatile("v_mov_b32 v[%4], %0\n\tv_mov_b32 v[%4+1], %1\n\tv_mov_b32 v[%4+2], %2\n\tv_mov_b32 v[%4+3], %3"
+                                 :: "v"(k0), "v"(k1), "v"(k2), "v"(k3), "n"(sk128_base(r) + 4 * k));
+                } else if constexpr (r < SK128_RR) {
+                    const float k0 = kv[0], k1 = kv[1], k2 = kv[2], k3 = kv[3];
+                    asm volatile("v_accvgpr_write_b32 a[%4], %0\n\tv_accvgpr_write_b32 a[%4+1], %1\n\tv_accvgpr_write_b32 a[%4+2], %2\n\tv_accvgpr_write_b32 a[%4+3], %3"
+                                 :: "v"(k0), "v"(k1), "v"(k2), "v"(k3), "n"(sk128_base(r) + 4 * k));
+                } else {
+                    *reinterpret_cast<f32x4*>(kl + (r - SK128_RR) * W + 256 * k) = kv;
+                }
+            });
+            if (r & 1) __builtin_amdgcn_sched_barrier(0);  // two rows in flight
+        });
+        for (int c = tid; c < W + 4; c += 256) vbuf[c] = (c < N || c == W) ? 1.f : 0.f;
+        __syncthreads();
+        float bN = 1.f, aM = 0.f;
+
+        for (int it = 0; it < p.iters; ++it) {
+            const unsigned epoch = ebase + (unsigned)it + 1u;
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            u64* const bufU = bufU2 + (epoch & 1u) * (unsigned)G;
+            const bool last = it + 1 == p.iters;
+            // ---- ONE pass over the wave's 32 rows: row sum -> a_i -> the row's contribution to the column sums
+            f32x2 cl[KT], ch[KT];  // partial column sums of this lane's 16 columns (pairs 0 - 1 | 2 - 3 of each chunk)
+            float ra = 0.f;         // sum of r_i a_i over the wave's rows (dustbin column)
+            {
+                f32x2 blo[KT], bhi[KT];
+                f32x2 accb = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(vbuf + 4 * (lane + 64 * k));  // 0 beyond N
+                    blo[k] = f32x2{b4[0], b4[1]};
+                    bhi[k] = f32x2{b4[2], b4[3]};
+                    accb += blo[k] + bhi[k];
+                    cl[k] = f32x2{0.f, 0.f};
+                    ch[k] = f32x2{0.f, 0.f};
+                }
+                aM = muM / (wave_sum_dpp(accb[0] + accb[1]) + bN);
+                // register rows in groups of 4: row sums (asm) -> ONE 4-way reduction, the sums in lanes (l & 3) -> a_i of the four
+                // rows in one division -> read back as scalars -> column sums (asm).  The dustbin statistic sum_i r_i a_i is kept
+                // per lane class and folded at the end of the pass.
+                float ra4 = 0.f;
+                sk_static_for<SK128_RR / 4>([&](auto g_c) {
+                    constexpr int r0 = 4 * decltype(g_c)::value;
+                    constexpr int B0 = sk128_base(r0), B1 = sk128_base(r0 + 1), B2 = sk128_base(r0 + 2), B3 = sk128_base(r0 + 3);
+                    f32x2 acc[4];
+                    if constexpr (r0 < SK128_RV) {
+                        sk128_rs4v<B0, B1, B2, B3>(acc, blo, bhi);
+                    } else {
+                        sk128_rs2a<B0, B1>(acc[0], acc[1], blo, bhi);
+                        sk128_rs2a<B2, B3>(acc[2], acc[3], blo, bhi);
+                    }
+                    const float s_r = wave_sum4_dpp(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1], acc[2][0] + acc[2][1], acc[3][0] + acc[3][1], lane);
+                    const int rl = wave * RW + r0 + (lane & 3);
+                    const float rk = rks[rl];
+                    const float ar = (FULL || row0 + r0 + (lane & 3) < M) ? mu / fmaf(rk, bN, s_r) : 0.f;
+                    ra4 = fmaf(rk, ar, ra4);
+                    asm volatile("" : "+v"(ra4));  // (here: deferred to the end of the pass, every group's r_i and a_i went to scratch)
+                    if (last) asv[rl] = ar;       // for the potentials (16 lanes write the same value to the same word)
+                    f32x2 a2[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float aq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ar), q));
+                        a2[q] = f32x2{aq, aq};
+                    }
+                    if constexpr (r0 < SK128_RV) sk128_rc4v<B0, B1, B2, B3>(cl, ch, a2);
+                    else sk128_rc4a<B0, B1, B2, B3>(cl, ch, a2);
+                });
+                ra = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 1)))
+                     + (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 2)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 3)));
+                auto row_a = [&](float s_r, int r) __attribute__((always_inline)) {
+                    const float rk = rks[wave * RW + r];
+                    const float ar = (FULL || row0 + r < M) ? mu / fmaf(rk, bN, s_r) : 0.f;
+                    ra = fmaf(rk, ar, ra);
+                    asm volatile("" : "+v"(ra));
+                    return ar;
+                };
+                // LDS rows one at a time: read once into 16 registers (as one asm statement per row: plain loads are all hoisted to
+                // the front of the pass - 128 registers - and spilled from there)
+                const unsigned kl_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)kl;
+                sk_static_for<SK128_RL>([&](auto g_c) {
+                    constexpr int r = decltype(g_c)::value;
+                    f32x4 t0, t1, t2, t3;
+                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%5+1024\n\t"
+                                 "ds_read_b128 %2, %4 offset:%5+2048\n\tds_read_b128 %3, %4 offset:%5+3072\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(kl_a), "n"(r * W * 4));
+                    const f32x4 t[KT] = {t0, t1, t2, t3};
+                    f32x2 kr[KT][2];
+                    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) {
+                        kr[k][0] = f32x2{t[k][0], t[k][1]};
+                        kr[k][1] = f32x2{t[k][2], t[k][3]};
+                        acc = __builtin_elementwise_fma(kr[k][0], blo[k], acc);
+                        acc = __builtin_elementwise_fma(kr[k][1], bhi[k], acc);
+                    }
+                    const float ar = row_a(wave_sum_dpp(acc[0] + acc[1]), SK128_RR + r);
+                    if (last) asv[wave * RW + SK128_RR + r] = ar;
+                    const f32x2 a2 = {ar, ar};
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) {
+                        cl[k] = __builtin_elementwise_fma(kr[k][0], a2, cl[k]);
+                        ch[k] = __builtin_elementwise_fma(kr[k][1], a2, ch[k]);
+                    }
+                    // (here, not sunk to the end of the pass with the row kept in scratch until then)
+                    asm volatile("" : "+v"(cl[0]), "+v"(cl[1]), "+v"(cl[2]), "+v"(cl[3]), "+v"(ch[0]), "+v"(ch[1]), "+v"(ch[2]), "+v"(ch[3]));
+                });
+            }
+            // ---- the 4 waves' partial column sums -> LDS
+            {
+                float* lf = fold + wave * W + 4 * lane;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) *reinterpret_cast<f32x4*>(lf + 256 * k) = f32x4{cl[k][0], cl[k][1], ch[k][0], ch[k][1]};
+                if (lane == 0) red[wave] = ra;
+                __syncthreads();
+            }
+            // ---- publish the workgroup's partial column sums (stage A, 16-byte pairs: 4 adjacent columns per thread) and its dustbin sum
+            {
+                const int c = 4 * tq;
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(fold + c), t1 = *reinterpret_cast<const f32x4*>(fold + W + c);
+                const f32x4 t2 = *reinterpret_cast<const f32x4*>(fold + 2 * W + c), t3 = *reinterpret_cast<const f32x4*>(fold + 3 * W + c);
+                const f32x4 T = (t0 + t1) + (t2 + t3);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int cc = c + 2 * h, wc = cc / cs, jl = cc - wc * cs;
+                    if (FULL || cc < N) granule_store2(rsA, (unsigned)((wc * G + w) * cs + jl) * 8u, epoch, T[2 * h], T[2 * h + 1]);
+                }
+                if (tq == 0) {
+                    const float U = (red[0] + red[1]) + (red[2] + red[3]);
+                    granule_store(bufU + w, epoch, U);
+                }
+            }
+            // ---- stage A consume: my slice of columns over all producers -> b_j = mu / (sum + a_M), published as stage B
+            {
+                const int q = tq & 3, cg = tq >> 2;  // 4 lanes per column pair, each two producers: q, q + 4 (, + 8, + 12)
+                const unsigned base_b = (unsigned)(w * G * cs) * 8u;
+                for (int j0 = 0; j0 < cs; j0 += 128) {
+                    const int jl = j0 + 2 * cg, c = w * cs + jl;
+                    const bool act = jl < cs && c < N;
+                    float T0 = 0.f, T1 = 0.f;
+                    for (int g0 = 0; g0 < G; g0 += 8) {
+                        unsigned off[2];
+                        unsigned val[2][2];
+                        int n = 0;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const int g = g0 + q + 4 * i;
+                            off[i] = base_b;
+                            if (act && g < G) { off[i] = base_b + (unsigned)(g * cs + jl) * 8u; n = i + 1; }
+                        }
+                        granule_wait2<2>(rsA, off, n, epoch, val, p.timeout, dead, nap);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (i < n) { T0 += __uint_as_float(val[i][0]); T1 += __uint_as_float(val[i][1]); }
+                    }
+#pragma unroll
+                    for (int o = 2; o > 0; o >>= 1) { T0 += __shfl_xor(T0, o); T1 += __shfl_xor(T1, o); }
+                    if (act && q == 0) granule_store2(rsB, (unsigned)c * 8u, epoch, mu / (T0 + aM), mu / (T1 + aM));
+                }
+            }
+            // ---- b_N = nu_N / (sum_i r_i a_i + a_M) from the G workgroup sums (wave 0)
+            if (wave == 0) {
+                float U = 0.f;
+                for (int g0 = 0; g0 < G; g0 += 64) {
+                    const int g = g0 + lane;
+                    int off[1] = {g < G ? g : 0};
+                    unsigned val[1];
+                    granule_wait<1>(bufU, off, g < G ? 1 : 0, epoch, val, p.timeout, dead, nap);
+                    if (g < G) U += __uint_as_float(val[0]);
+                }
+                U = wave_sum_dpp(U);
+                if (lane == 0) vbuf[W] = nuN / (U + aM);
+            }
+            // ---- stage B consume: all of b into LDS (2 pairs per thread)
+            {
+                unsigned off[2];
+                unsigned val[2][2];
+                int n = 0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ca = 2 * tq + 512 * i;
+                    off[i] = 0u;
+                    if (ca < N) { off[i] = (unsigned)ca * 8u; n = i + 1; }
+                }
+                granule_wait2<2>(rsB, off, n, epoch, val, p.timeout, dead, nap);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ca = 2 * tq + 512 * i;
+                    *reinterpret_cast<f32x2*>(vbuf + ca) = f32x2{ca < N ? __uint_as_float(val[i][0]) : 0.f, ca + 1 < N ? __uint_as_float(val[i][1]) : 0.f};
+                }
+            }
+            if (__syncthreads_or(dead ? 1 : 0)) dead = true;
+            bN = vbuf[W];
+        }
+
+        // ---- potentials for the final sweep (as in sinkhorn_resident)
+        {
+            const float qnan = __uint_as_float(SKR_GAVE_UP_NAN);
+            float* ub = p.u + (int64_t)b * (M + 1);
+            bool bad = false;
+            if (tid < ROWS && w * ROWS + tid < M) {
+                const float ar = asv[tid];
+                bad = bad || !(ar > 0.f) || !(ar < INFINITY);
+                ub[w * ROWS + tid] = dead ? qnan : __logf(ar) - mrs[tid];
+            }
+            if (w == 0) {
+                float* vb = p.v + (int64_t)b * p.ldV;
+                for (int j = tid; j < p.ldV; j += 256) {
+                    const float bj = j < N ? vbuf[j] : (j == N ? bN : 1.f);
+                    bad = bad || !(bj > 0.f) || !(bj < INFINITY);
+                    vb[j] = dead ? qnan : __logf(bj);
+                }
+                bad = bad || !(aM > 0.f) || !(aM < INFINITY);
+                if (tid == 0) ub[M] = dead ? qnan : __logf(aM) - p.alpha;
+            }
+            if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicAdd(p.timeout + 4, 1u);
+        }
+    }
+}
+
+
 // ---- rescue pass behind the resident kernel -----------------------------------------------------------------------------
 // One workgroup per problem looks at the potentials the resident kernel left.  All finite (every call of an ordinary
 // network): return - the pass costs one launch of B idle workgroups.  Otherwise (a scaling left fp32's range in the
@@ -1086,9 +1412,9 @@ struct ResidentPlan {
     size_t bytesA, bytesB, bytesU;
 };
 static int round_up(int x, int m);
-static ResidentPlan resident_plan(int B, int M, int N, int slots) {
+static ResidentPlan resident_plan(int B, int M, int N, int slots, int rows_per_wg = 0) {
     ResidentPlan r;
-    const int rows = skr_rows(round_up(N, 4));
+    const int rows = rows_per_wg > 0 ? rows_per_wg : skr_rows(round_up(N, 4));
     r.G = (M + rows - 1) / rows;
     r.n_res = std::max(1, std::min(B, slots / std::max(r.G, 1)));
     r.cs = (N + r.G - 1) / r.G;
@@ -1124,7 +1450,7 @@ static int KT_of(int64_t ldS) {
     return kt <= 2 ? kt : (kt <= 4 ? 4 : 8);
 }
 
-static void hipLaunchKernelGGL_ptr(const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t s, SkResParams& par) {
+static void hipLaunchKernelGGL_ptr(const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t s, SkResParams& par) {  // (block: 512, or 256 for sinkhorn_resident128)
     void* args[] = {&par};
     (void)hipLaunchKernel(fn, grid, block, args, lds, s);
 }
@@ -1204,7 +1530,8 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
     }
     int wg_per_cu = 0;
     const void* kfn = nullptr;
-    const size_t res_lds = sizeof(float) * (size_t)(9 * KT_of(ldS) * 256 + 4 + 32);
+    bool rows128 = false;
+    size_t res_lds = sizeof(float) * (size_t)(9 * KT_of(ldS) * 256 + 4 + 32);
     if (resident) {
         const bool full = N == ldS && N == KT_of(ldS) * 256;
         // granule pairs (16-byte exchange stores / loads): a thread must own an even number of columns and a consumer's column
@@ -1226,8 +1553,24 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
                 else kfn = full ? (const void*)sinkhorn_resident<8, true> : (const void*)sinkhorn_resident<8, false>;
                 break;
         }
+        // 128 rows per workgroup (sinkhorn_resident128): twice the problems resident, about twice the arithmetic per iteration, the same
+        // two hops - a round takes 1.6 times as long (measured: 0.85 against 0.53 ms per 100 iterations at 1024 x 1024), so it is
+        // taken when it saves more than 3 rounds in 8 (the 32 problems of configs[1]: one round instead of two)
+        // (E2EMV_SINKHORN=rows64: never; unset: when it saves rounds; =rows128: whenever the shape allows it - tests compare a
+        // problem alone with the same problem in a batch through the same kernel)
+        int knob128 = 1;
+        if (const char* e = getenv("E2EMV_SINKHORN")) knob128 = strcmp(e, "rows64") == 0 ? 0 : (strcmp(e, "rows128") == 0 ? 2 : 1);
+        if (KT_of(ldS) == 4 && knob128 != 0) {
+            const int G128 = (M + 127) / 128, cs128 = (N + G128 - 1) / G128;
+            const int res64 = std::max(1, ctx->num_cus / std::max(G0, 1)), res128 = std::max(1, ctx->num_cus / std::max(G128, 1));
+            if (cs128 % 2 == 0 && G128 <= 16 && (knob128 == 2 || 8 * ((B + res128 - 1) / res128) < 5 * ((B + res64 - 1) / res64))) {
+                kfn = (full && M % 128 == 0) ? (const void*)sinkhorn_resident128<true> : (const void*)sinkhorn_resident128<false>;  // (full rows AND columns)
+                rows128 = true;
+            }
+        }
         static std::map<std::pair<int, const void*>, int> occupancy;  // (device, kernel) -> resident workgroups per CU
         static std::mutex occupancy_mu;
+        if (rows128) res_lds = sizeof(float) * (size_t)(4 * SK128_RL * 1024 + 4 * 1024 + 1024 + 4 + 32 + 3 * 128);
         {
             std::lock_guard<std::mutex> lk(occupancy_mu);
             auto it = occupancy.find({ctx->device, kfn});
@@ -1236,7 +1579,7 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
                 if (res_lds > 48 * 1024 && ensure_dynamic_lds(ctx, kfn, res_lds) != E2EMV_OK) {
                     (void)hipGetLastError();  // a device with less LDS: the streaming chain below serves the call
                     nb = 0;
-                } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 512, res_lds) != hipSuccess) {
+                } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, rows128 ? 256 : 512, res_lds) != hipSuccess) {
                     (void)hipGetLastError();
                     nb = 0;
                 }
@@ -1244,12 +1587,13 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
             }
             wg_per_cu = it->second;
         }
-        const int G = (M + skr_rows(ldS) - 1) / skr_rows(ldS);
+        const int rows_wg = rows128 ? 128 : skr_rows(ldS);
+        const int G = (M + rows_wg - 1) / rows_wg;
         if (wg_per_cu < 1 || G > wg_per_cu * ctx->num_cus) resident = false;
     }
     if (resident) {
         if (int rc_f = ensure_flags(ctx)) return rc_f;
-        const ResidentPlan rp = resident_plan(B, M, N, wg_per_cu * ctx->num_cus);
+        const ResidentPlan rp = resident_plan(B, M, N, wg_per_cu * ctx->num_cus, rows128 ? 128 : 0);
         SkResParams rpar{};
         rpar.S = S; rpar.ldS = ldS; rpar.M = M; rpar.N = N; rpar.B = B; rpar.iters = iters;
         rpar.alpha = alpha; rpar.norm = p.norm;
@@ -1269,7 +1613,8 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
         // every polled word starts from 0 in every launch (epochs count from 1)
         E2EMV_HIP(ctx, hipMemsetAsync(w, 0, rp.bytesA + rp.bytesB + rp.bytesU, s));
         E2EMV_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, 4, s));
-        hipLaunchKernelGGL_ptr(kfn, dim3((unsigned)(rp.n_res * rp.G)), dim3(512), res_lds, s, rpar);
+        hipLaunchKernelGGL_ptr(kfn, dim3((unsigned)(rp.n_res * rp.G)), dim3(rows128 ? 256 : 512), res_lds, s, rpar);
+        if (rows128) ++ctx->stat_sinkhorn_rows128;
         E2EMV_CHECK_LAUNCH(ctx, "sinkhorn_resident");
         // problems the exponential-domain kernel could not finish are re-solved in the log domain before anything reads u, v
         hipLaunchKernelGGL(sinkhorn_rescue, dim3(B), dim3(1024), sizeof(float) * (size_t)(M + N + 2), s, p, iters, ctx->d_flags);

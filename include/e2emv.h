@@ -380,7 +380,8 @@ int e2emv_get_descriptors(e2emv_ctx* ctx, float* d_out, int64_t capacity_floats,
  * inter-workgroup wait gave up under contention) and the rescue pass behind it re-solved in the log domain inside the same
  * call: their outputs are correct, nothing is raised.  The host tells the two causes apart: the SECOND observation (here or
  * in e2emv_sync) of calls with range rescues moves the context to the log-domain launch chain - after 16 calls on it the
- * resident kernel gets another try -, rescues behind a timeout (stats[4] counts those) never do; stats[3] = (wave, stream, 64-key tile) softmaxes that
+ * resident kernel gets another try -, rescues behind a timeout (stats[4] counts those) never do; stats[5] = Sinkhorn calls served by the 128-rows-per-workgroup
+ * kernel (a batch of 513 .. 1024-column problems that it brings through in fewer rounds); stats[3] = (wave, stream, 64-key tile) softmaxes that
  * attention_p2w redid on its slow path (a performance counter: results are the same).  Host-synchronising. */
 int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset);
 

@@ -22,6 +22,14 @@ def _stream_mode(on):
         os.environ.pop("E2EMV_SINKHORN", None)
 
 
+def _rows_mode(mode):
+    """None: the library's choice; "rows64" / "rows128": the 64-row kernel only / the 128-row kernel whenever the shape allows it."""
+    if mode:
+        os.environ["E2EMV_SINKHORN"] = mode
+    else:
+        os.environ.pop("E2EMV_SINKHORN", None)
+
+
 @pytest.mark.parametrize("B,M,N,iters", [(2, 128, 128, 100), (1, 100, 77, 20), (2, 33, 250, 5), (3, 1024, 1024, 100),
                                          (1, 1, 1, 3), (2, 5, 1000, 10), (2, 1000, 5, 10), (1, 513, 511, 30), (40, 256, 256, 50),
                                          (70, 300, 260, 7), (2, 2048, 2048, 30), (1, 1500, 2000, 10), (6, 2048, 2048, 12),
@@ -56,9 +64,58 @@ def test_more_problems_than_resident_capacity_and_batch_independence(gpu):
     workgroups (epochs keep counting) and every problem must come out exactly as when it runs alone."""
     import e2e_multi_view_matching_amd as E
     s = _scores(37, 1024, 1024, 5).to(gpu)
-    full = E.log_optimal_transport(s, 1.0, 25)
-    for b in (0, 15, 16, 31, 32, 36):
-        assert torch.equal(E.log_optimal_transport(s[b:b + 1].contiguous(), 1.0, 25)[0], full[b]), b
+    for mode in ("rows64", "rows128"):  # (the same kernel for the batch and for the problem alone: three rounds / two)
+        try:
+            _rows_mode(mode)
+            full = E.log_optimal_transport(s, 1.0, 25)
+            for b in (0, 15, 16, 31, 32, 36):
+                assert torch.equal(E.log_optimal_transport(s[b:b + 1].contiguous(), 1.0, 25)[0], full[b]), (mode, b)
+        finally:
+            _rows_mode(None)
+
+
+@pytest.mark.parametrize("B,M,N,iters,picked", [
+    (32, 1024, 1024, 100, True),   # BASELINE configs[1]'s Sinkhorn: one round instead of two
+    (65, 1024, 1024, 10, True),    # three rounds instead of five, the last with one problem
+    (20, 1024, 1008, 6, True),     # columns short of 1024 (masked chunk tails), 126-column slices
+    (18, 1000, 1024, 8, True),     # rows short of 8 x 128: a partial last workgroup
+    (24, 900, 1020, 12, True),     # both
+    (30, 640, 1020, 9, True),      # 5 workgroups per problem, 204-column slices
+    (52, 640, 1020, 4, False),     # two rounds instead of three do not pay (a round of 128-row workgroups takes 1.6 times as long)
+    (40, 640, 1024, 9, False),     # 205-column slices are odd (the exchange moves column pairs): the 64-row kernel
+    (16, 1024, 1024, 5, False),    # fits one round of 64-row workgroups already: not taken
+])
+def test_128_rows_per_workgroup(gpu, B, M, N, iters, picked):
+    """sinkhorn_resident128: a workgroup of 4 waves holds 128 rows of K = exp(S - rowmax) - 24 rows per wave in registers it
+    addresses by number (12 in v64 .. v255, 12 in a64 .. a255), 8 in LDS - so that twice as many problems are resident and a
+    large batch needs half the rounds.  Against the oracle (a sample of the problems), against the 64-row kernel (another
+    summation order of the same algorithm), bit-identical re-runs, and the library's choice reported by the statistics."""
+    import e2e_multi_view_matching_amd as E
+    from e2e_multi_view_matching_amd import _lib
+    from oracle.sinkhorn import log_optimal_transport
+    s = _scores(B, M, N, 3 * B + M + N)
+    sample = sorted({0, B // 2, B - 1})
+    ref = log_optimal_transport(s[sample], 1.0, iters)
+    sg = s.to(gpu)
+    ctx = _lib.context(gpu)
+    try:
+        _rows_mode(None)
+        ctx.stats(reset=True)
+        a = E.log_optimal_transport(sg, 1.0, iters)
+        a2 = E.log_optimal_transport(sg, 1.0, iters)
+        st = ctx.stats()
+        _rows_mode("rows64")
+        b = E.log_optimal_transport(sg, 1.0, iters)
+        assert ctx.stats()["sinkhorn_rows128_calls"] == st["sinkhorn_rows128_calls"]
+    finally:
+        _rows_mode(None)
+    assert st["sinkhorn_rows128_calls"] == (2 if picked else 0), st
+    assert st["sinkhorn_rescued"] == 0 and st["sinkhorn_timeouts"] == 0 and st["sinkhorn_bad"] == 0
+    assert bool(torch.isfinite(a).all())
+    assert torch.equal(a, a2)
+    assert float((a[sample].cpu() - ref).abs().max()) < 1e-4, float((a[sample].cpu() - ref).abs().max())
+    assert float((a - b).abs().max()) < 2e-5, float((a - b).abs().max())
+    assert torch.equal(a[:, :-1, :-1].argmax(2), b[:, :-1, :-1].argmax(2))
 
 
 def test_matches_from_the_resident_path_equal_the_streaming_chain(gpu):

@@ -103,6 +103,29 @@ ab)
   E2EMV_F16X2_KERNELS=r2 timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_r2k.json 2> $OUT/bench_r2k.err
   show $OUT/bench_p2.json $OUT/bench_r2k.json
   ;;
+sk128)
+  # sinkhorn_resident128: its tests, then ms per call (100 iterations incl. the final sweep) against the 64-row kernel, alternating
+  timeout 900 python -m pytest tests/test_gpu_sinkhorn_resident.py -x -q 2>&1 | tail -8 | tee $OUT/sk128_tests.log
+  timeout 300 python - <<'PY' 2>&1 | tee $OUT/sk128_time.log
+import os, time, torch
+import e2e_multi_view_matching_amd as E
+def t(s, it=100, reps=20):
+    for _ in range(3): E.log_optimal_transport(s, 1.0, it)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): E.log_optimal_transport(s, 1.0, it)
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
+for B, M, N in ((32, 1024, 1024), (80, 1024, 1024), (20, 1024, 1024), (48, 1024, 1024), (32, 896, 1020), (64, 640, 1020)):
+    s = torch.randn(B, M, N, device="cuda") * 3
+    r = []
+    for rep in range(2):
+        for mode in ("rows64", None):
+            if mode: os.environ["E2EMV_SINKHORN"] = mode
+            else: os.environ.pop("E2EMV_SINKHORN", None)
+            r.append(t(s))
+    os.environ.pop("E2EMV_SINKHORN", None)
+    print(f"{B} x {M} x {N}: rows64 {r[0]:.3f} / {r[2]:.3f} ms   library's choice {r[1]:.3f} / {r[3]:.3f} ms")
+PY
+  ;;
 tests)
   timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/tests.log
   ;;
