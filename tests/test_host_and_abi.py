@@ -42,6 +42,26 @@ def test_no_measurement_binaries_next_to_the_product():
     assert [f for f in os.listdir(pkg) if f.endswith(".so")] == ["libe2emv.so"]
 
 
+def test_sinkhorn128_keeps_the_compiler_inside_its_register_window(lib_built):
+    """sinkhorn_resident128 holds 24 of a wave's 32 rows in registers it addresses by number (v64 .. v255, a64 .. a255; v56 .. v63
+    are its temporaries); amdgpu_num_vgpr(56) confines hipcc to v0 .. v55 / a0 .. a55.  The device assembly the build wrote is the
+    proof: no compiler-generated instruction of either instance touches a register outside that window, and the wave is allocated
+    all 512 registers.  (build.py runs the same check on every build.)"""
+    from e2e_multi_view_matching_amd import build
+    asm = os.path.join(ROOT, "e2e_multi_view_matching_amd", "build", "sinkhorn.s")
+    if not os.path.exists(asm) or os.path.getmtime(asm) < os.path.getmtime(os.path.join(build.CSRC, "sinkhorn.hip")):
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + build.FLAGS + ["--cuda-device-only", "-S", os.path.join(build.CSRC, "sinkhorn.hip"), "-o", asm],
+                       check=True, capture_output=True)
+    assert build.check_register_window(asm, "sinkhorn_resident128", 56) == 2  # <true> (full tiles) and <false> (ragged)
+    txt = open(asm).read()
+    body = txt[txt.index("sinkhorn_resident128ILb1E"):]
+    body = body[:body.index(".end_amdhsa_kernel")]
+    mine = [ln for ln in body.splitlines() if re.search(r"\b(v_accvgpr_(read|write)_b32|v_mov_b32|v_pk_(fma|mul)_f32).*[va]\[(0x[0-9a-f]+|\d+)[+\]]", ln)]
+    assert len(mine) == 384 + 2 * (12 * 8 + 12 * 16)  # the statements that DO address them: 384 writes; per pass 8 packed operations per vector row, 16 reads per accumulation row
+    with pytest.raises(RuntimeError, match="outside its window"):
+        build.check_register_window(asm, "sinkhorn_resident128", 40)
+
+
 def test_struct_layouts_match_the_header():
     from e2e_multi_view_matching_amd import _lib
     assert ctypes.sizeof(_lib.ModelDesc) == 4 * (3 + 8 + 1 + 64 + 1)
