@@ -819,13 +819,19 @@ __global__ __launch_bounds__(512, (KT <= 4 && RW == 4) ? 4 : 2) void sinkhorn_re
                         acc[r] = __builtin_elementwise_fma(K[r][k][1], bhi, acc[r]);
                     }
                 }
-                float srow[RW + 1];
+                // four row sums per reduction, arriving in lanes (l & 3): ONE division gives the a_i of four rows, read back as scalars
+                static_assert(RW % 4 == 0, "rows of a wave in groups of four");
 #pragma unroll
-                for (int r = 0; r < RW; ++r) srow[r] = wave_sum_dpp(acc[r][0] + acc[r][1]);
-                srow[RW] = wave_sum_dpp(accb[0] + accb[1]);
+                for (int g = 0; g < RW / 4; ++g) {
+                    const float s4 = wave_sum4_dpp(acc[4 * g][0] + acc[4 * g][1], acc[4 * g + 1][0] + acc[4 * g + 1][1],
+                                                   acc[4 * g + 2][0] + acc[4 * g + 2][1], acc[4 * g + 3][0] + acc[4 * g + 3][1], lane);
+                    const int q = lane & 3;
+                    const float rk = q == 0 ? rK[4 * g] : (q == 1 ? rK[4 * g + 1] : (q == 2 ? rK[4 * g + 2] : rK[4 * g + 3]));
+                    const float a4 = (row0 + 4 * g + q < M) ? mu / fmaf(rk, bN, s4) : 0.f;
 #pragma unroll
-                for (int r = 0; r < RW; ++r) a[r] = (row0 + r < M) ? mu / fmaf(rK[r], bN, srow[r]) : 0.f;
-                aM = muM / (srow[RW] + bN);
+                    for (int qq = 0; qq < 4; ++qq) a[4 * g + qq] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a4), qq));
+                }
+                aM = muM / (wave_sum_dpp(accb[0] + accb[1]) + bN);
             }
             // ---- column half-iteration, this wave's part: sum over its 4 rows of K_ij a_i -> LDS
             {
