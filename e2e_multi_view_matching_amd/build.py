@@ -96,6 +96,7 @@ def _build(hipcc, objdir, lib, extra, verbose):
     if asm_proc.returncode != 0:
         raise RuntimeError(f"hipcc -S failed on sinkhorn.hip:\n{out}")
     check_register_window(asm_file, "sinkhorn_resident128", 56)
+    check_register_window(asm_file, "sinkhorn_resident2k", 56)
     # the dynamic symbol table is the C ABI of include/e2emv.h and nothing else (hipcc gives kernel host stubs default
     # visibility whatever -fvisibility says: the version script takes them and every C++ internal out)
     vs = os.path.join(objdir, "e2emv.map")

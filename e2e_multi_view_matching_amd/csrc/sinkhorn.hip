@@ -1134,6 +1134,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
             asm volatile("" : "+v"(tq));
             u64* const bufU = bufU2 + (epoch & 1u) * (unsigned)G;
             const bool last = it + 1 == p.iters;
+            unsigned long long* const dbg = (p.dbg && grp == 0 && round == 0 && it < 16 && tid == 0) ? p.dbg + ((int64_t)it * G + w) * 8 : nullptr;
+            if (dbg) dbg[0] = __builtin_amdgcn_s_memrealtime();
             // ---- ONE pass over the wave's 32 rows: row sum -> a_i -> the row's contribution to the column sums
             f32x2 cl[KT], ch[KT];  // partial column sums of this lane's 16 columns (pairs 0 - 1 | 2 - 3 of each chunk)
             float ra = 0.f;         // sum of r_i a_i over the wave's rows (dustbin column)
@@ -1226,6 +1228,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
 #pragma unroll
                 for (int k = 0; k < KT; ++k) *reinterpret_cast<f32x4*>(lf + 256 * k) = f32x4{cl[k][0], cl[k][1], ch[k][0], ch[k][1]};
                 if (lane == 0) red[wave] = ra;
+                if (dbg) dbg[1] = __builtin_amdgcn_s_memrealtime();
                 __syncthreads();
             }
             // ---- publish the workgroup's partial column sums (stage A, 16-byte pairs: 4 adjacent columns per thread) and its dustbin sum
@@ -1244,6 +1247,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                     granule_store(bufU + w, epoch, U);
                 }
             }
+            if (dbg) dbg[2] = __builtin_amdgcn_s_memrealtime();
             // ---- stage A consume: my slice of columns over all producers -> b_j = mu / (sum + a_M), published as stage B
             {
                 const int q = tq & 3, cg = tq >> 2;  // 4 lanes per column pair, each two producers: q, q + 4 (, + 8, + 12)
@@ -1272,6 +1276,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                     if (act && q == 0) granule_store2(rsB, (unsigned)c * 8u, epoch, mu / (T0 + aM), mu / (T1 + aM));
                 }
             }
+            if (dbg) dbg[3] = __builtin_amdgcn_s_memrealtime();
             // ---- b_N = nu_N / (sum_i r_i a_i + a_M) from the G workgroup sums (wave 0)
             if (wave == 0) {
                 float U = 0.f;
@@ -1285,6 +1290,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                 U = wave_sum_dpp(U);
                 if (lane == 0) vbuf[W] = nuN / (U + aM);
             }
+            if (dbg) dbg[4] = __builtin_amdgcn_s_memrealtime();
             // ---- stage B consume: all of b into LDS (2 pairs per thread)
             {
                 unsigned off[2];
@@ -1303,7 +1309,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                     *reinterpret_cast<f32x2*>(vbuf + ca) = f32x2{ca < N ? __uint_as_float(val[i][0]) : 0.f, ca + 1 < N ? __uint_as_float(val[i][1]) : 0.f};
                 }
             }
+            if (dbg) dbg[5] = __builtin_amdgcn_s_memrealtime();
             if (__syncthreads_or(dead ? 1 : 0)) dead = true;
+            if (dbg) dbg[6] = __builtin_amdgcn_s_memrealtime();
             bN = vbuf[W];
         }
 
@@ -1332,6 +1340,332 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
     }
 }
 
+
+// ---- the same construction for 1025 .. 2048 columns: 64 rows per workgroup ---------------------------------------------------
+// A row of K is 32 registers per lane here ([32 r + 16 h + 4 k + e]: h = the column half, chunk 4 h + k covers columns
+// 4 (lane + 64 (4 h + k)) .. + 3).  A wave holds 16 rows: 6 in v64 .. v255, 6 in a64 .. a255, 4 in LDS (128 KB for the
+// workgroup), so a problem of 2048 rows is 32 workgroups (64 with the 32-row workgroups of sinkhorn_resident<8>) and eight
+// problems are resident instead of four.  The compiler's 56 registers cannot hold b (32) and the column partials (32) at once:
+//   * row sums: per column half - b of the half (16 registers), the rows in pairs (sk_rs2v / sk128_rs2a, LDS rows through 16
+//     registers), each row's partial sum added into ONE register per row;
+//   * four 4-way reductions, a_i of four rows per division (as in sinkhorn_resident128);
+//   * column sums: per half 16 registers of partials, both halves kept (b is dead by then) until the fold;
+//   * the fold of the 4 waves goes through 16 KB (LDS is full): waves 2 and 3 write, waves 0 and 1 add theirs and write
+//     back, then all threads publish fold[0] + fold[1].
+constexpr int SK2K_RV = 6, SK2K_RA = 6, SK2K_RL = 4, SK2K_RR = SK2K_RV + SK2K_RA, SK2K_RW = SK2K_RR + SK2K_RL;
+constexpr int sk2k_base(int r, int h) { return 64 + 32 * (r < SK2K_RV ? r : r - SK2K_RV) + 16 * h; }
+template <bool FULL>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void sinkhorn_resident2k(SkResParams p) {
+    constexpr int W = 2048, RW = SK2K_RW, ROWS = 4 * RW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* klds = lds;                       // [4 waves][RL rows][W]: the LDS-resident rows of K
+    float* fold = klds + 4 * SK2K_RL * W;    // [2][W] partial column sums
+    float* vbuf = fold + 2 * W;              // [W + 4]: b of the current iteration (+ b_N at [W])
+    float* red = vbuf + W + 4;               // [32]
+    float* rks = red + 32;                   // [ROWS] r_i = exp(alpha - rowmax_i)
+    float* mrs = rks + ROWS;                 // [ROWS] rowmax_i
+    float* asv = mrs + ROWS;                 // [ROWS] a_i of the last iteration (for the potentials)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = blockIdx.x / p.G, w = blockIdx.x % p.G;
+    const int G = p.G, cs = p.cs, N = p.N, M = p.M;
+    const int row0 = w * ROWS + wave * RW;
+    u64* const bufA = p.bufA + (int64_t)grp * G * G * cs;
+    u64* const bufB = p.bufB + (int64_t)grp * G * cs;
+    u64* const bufU2 = p.bufU + (int64_t)grp * 2 * G;
+    bool dead = false;
+    const bool nap = !(p.flags & 1);
+    const float mu = 1.0f / (float)(M + N), muM = (float)N / (float)(M + N), nuN = (float)M / (float)(M + N);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(bufA, 0, G * G * cs * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(bufB, 0, G * cs * 8, 0x00020000);
+    float* const kl = klds + wave * SK2K_RL * W + 4 * lane;  // this lane's first chunk of the wave's LDS rows (chunk c: + 256 c)
+    unsigned round = 0;
+    for (int b = grp; b < p.B; b += p.n_res, ++round) {
+        const unsigned ebase = round * (unsigned)p.iters;
+        const float* Sb = p.S + (int64_t)b * M * p.ldS;
+        asm volatile("" ::: "v255", "a255");  // (the wave is allocated 256 + 256 registers: see sinkhorn_resident128)
+        // ---- load the wave's 16 rows, shift by the row maximum, exponentiate once
+        sk_static_for<RW>([&](auto r_c) {
+            constexpr int r = decltype(r_c)::value;
+            const int row = FULL ? row0 + r : min(row0 + r, M - 1);
+            f32x4 zz[8];
+            float mx = p.alpha;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const int c = 4 * (lane + 64 * c8);
+                zz[c8] = (FULL || c < p.ldS) ? *reinterpret_cast<const f32x4*>(Sb + (int64_t)row * p.ldS + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (FULL || c + e < N) mx = fmaxf(mx, zz[c8][e]);
+            }
+            mx = wave_max_dpp(mx);
+            const bool rvalid = FULL || row0 + r < M;
+            if (lane == 0) {
+                mrs[wave * RW + r] = mx;
+                rks[wave * RW + r] = rvalid ? exp_accurate(p.alpha - mx) : 0.f;
+            }
+            sk_static_for<8>([&](auto c_c) {
+                constexpr int c8 = decltype(c_c)::value, h = c8 >> 2, k = c8 & 3;
+                const int c = 4 * (lane + 64 * c8);
+                f32x4 kv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kv[e] = (rvalid && (FULL || c + e < N)) ? exp_accurate(zz[c8][e] - mx) : 0.f;
+                if constexpr (r < SK2K_RV) {
+                    const float k0 = kv[0], k1 = kv[1], k2 = kv[2], k3 = kv[3];
+                    asm volatile("v_mov_b32 v[%4], %0\n\tv_mov_b32 v[%4+1], %1\n\tv_mov_b32 v[%4+2], %2\n\tv_mov_b32 v[%4+3], %3"
+                                 :: "v"(k0), "v"(k1), "v"(k2), "v"(k3), "n"(sk2k_base(r, h) + 4 * k));
+                } else if constexpr (r < SK2K_RR) {
+                    const float k0 = kv[0], k1 = kv[1], k2 = kv[2], k3 = kv[3];
+                    asm volatile("v_accvgpr_write_b32 a[%4], %0\n\tv_accvgpr_write_b32 a[%4+1], %1\n\tv_accvgpr_write_b32 a[%4+2], %2\n\tv_accvgpr_write_b32 a[%4+3], %3"
+                                 :: "v"(k0), "v"(k1), "v"(k2), "v"(k3), "n"(sk2k_base(r, h) + 4 * k));
+                } else {
+                    *reinterpret_cast<f32x4*>(kl + (r - SK2K_RR) * W + 256 * c8) = kv;
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);  // one row in flight
+        });
+        for (int c = tid; c < W + 4; c += 256) vbuf[c] = (c < N || c == W) ? 1.f : 0.f;
+        __syncthreads();
+        float bN = 1.f, aM = 0.f;
+        const unsigned kl_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)kl;
+
+        for (int it = 0; it < p.iters; ++it) {
+            const unsigned epoch = ebase + (unsigned)it + 1u;
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            u64* const bufU = bufU2 + (epoch & 1u) * (unsigned)G;
+            const bool last = it + 1 == p.iters;
+            unsigned long long* const dbg = (p.dbg && grp == 0 && round == 0 && it < 16 && tid == 0) ? p.dbg + ((int64_t)it * G + w) * 8 : nullptr;
+            if (dbg) dbg[0] = __builtin_amdgcn_s_memrealtime();
+            // ---- row sums, per column half: one register per row
+            float accp[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) accp[r] = 0.f;
+            f32x2 accb = {0.f, 0.f};
+            sk_static_for<2>([&](auto h_c) {
+                constexpr int h = decltype(h_c)::value;
+                f32x2 blo[4], bhi[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(vbuf + 4 * (lane + 64 * (4 * h + k)));  // 0 beyond N
+                    blo[k] = f32x2{b4[0], b4[1]};
+                    bhi[k] = f32x2{b4[2], b4[3]};
+                    accb += blo[k] + bhi[k];
+                }
+                sk_static_for<SK2K_RV / 2>([&](auto p_c) {
+                    constexpr int r0 = 2 * decltype(p_c)::value;
+                    f32x2 acc[4];
+                    sk_rs2v<sk2k_base(r0, h), sk2k_base(r0 + 1, h)>(acc, blo, bhi);
+                    accp[r0] += (acc[0][0] + acc[0][1]) + (acc[2][0] + acc[2][1]);
+                    accp[r0 + 1] += (acc[1][0] + acc[1][1]) + (acc[3][0] + acc[3][1]);
+                    asm volatile("" : "+v"(accp[r0]), "+v"(accp[r0 + 1]));
+                });
+                sk_static_for<SK2K_RA / 2>([&](auto p_c) {
+                    constexpr int r0 = SK2K_RV + 2 * decltype(p_c)::value;
+                    f32x2 a0, a1;
+                    sk128_rs2a<sk2k_base(r0, h), sk2k_base(r0 + 1, h)>(a0, a1, blo, bhi);
+                    accp[r0] += a0[0] + a0[1];
+                    accp[r0 + 1] += a1[0] + a1[1];
+                    asm volatile("" : "+v"(accp[r0]), "+v"(accp[r0 + 1]));
+                });
+                sk_static_for<SK2K_RL>([&](auto j_c) {
+                    constexpr int j = decltype(j_c)::value;
+                    f32x4 t0, t1, t2, t3;
+                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%5+1024\n\t"
+                                 "ds_read_b128 %2, %4 offset:%5+2048\n\tds_read_b128 %3, %4 offset:%5+3072\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(kl_a), "n"((j * W + 1024 * h) * 4));
+                    const f32x4 t[4] = {t0, t1, t2, t3};
+                    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        acc = __builtin_elementwise_fma(f32x2{t[k][0], t[k][1]}, blo[k], acc);
+                        acc = __builtin_elementwise_fma(f32x2{t[k][2], t[k][3]}, bhi[k], acc);
+                    }
+                    accp[SK2K_RR + j] += acc[0] + acc[1];
+                    asm volatile("" : "+v"(accp[SK2K_RR + j]));
+                });
+            });
+            aM = muM / (wave_sum_dpp(accb[0] + accb[1]) + bN);
+            // ---- a_i: four rows per reduction and division; the scalars a_i for the column sums
+            float as[RW];
+            float ra4 = 0.f;
+#pragma unroll
+            for (int g = 0; g < RW / 4; ++g) {
+                const float s_r = wave_sum4_dpp(accp[4 * g], accp[4 * g + 1], accp[4 * g + 2], accp[4 * g + 3], lane);
+                const int rl = wave * RW + 4 * g + (lane & 3);
+                const float rk = rks[rl];
+                const float ar = (FULL || row0 + 4 * g + (lane & 3) < M) ? mu / fmaf(rk, bN, s_r) : 0.f;
+                ra4 = fmaf(rk, ar, ra4);
+                if (last) asv[rl] = ar;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) as[4 * g + q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ar), q));
+            }
+            const float ra = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 1)))
+                             + (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 2)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 3)));
+            // ---- column sums, per half; both halves stay in registers until the fold
+            f32x2 cl[2][4], ch[2][4];
+            sk_static_for<2>([&](auto h_c) {
+                constexpr int h = decltype(h_c)::value;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { cl[h][k] = f32x2{0.f, 0.f}; ch[h][k] = f32x2{0.f, 0.f}; }
+                sk_static_for<SK2K_RV / 2>([&](auto p_c) {
+                    constexpr int r0 = 2 * decltype(p_c)::value;
+                    sk_rc2v<sk2k_base(r0, h), sk2k_base(r0 + 1, h)>(cl[h], ch[h], f32x2{as[r0], as[r0]}, f32x2{as[r0 + 1], as[r0 + 1]});
+                });
+                sk_static_for<SK2K_RA / 2>([&](auto p_c) {
+                    constexpr int r0 = SK2K_RV + 2 * decltype(p_c)::value;
+                    sk_rc2a<sk2k_base(r0, h), sk2k_base(r0 + 1, h)>(cl[h], ch[h], f32x2{as[r0], as[r0]}, f32x2{as[r0 + 1], as[r0 + 1]});
+                });
+                sk_static_for<SK2K_RL>([&](auto j_c) {
+                    constexpr int j = decltype(j_c)::value;
+                    f32x4 t0, t1, t2, t3;
+                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%5+1024\n\t"
+                                 "ds_read_b128 %2, %4 offset:%5+2048\n\tds_read_b128 %3, %4 offset:%5+3072\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(kl_a), "n"((j * W + 1024 * h) * 4));
+                    const f32x4 t[4] = {t0, t1, t2, t3};
+                    const f32x2 a2 = {as[SK2K_RR + j], as[SK2K_RR + j]};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        cl[h][k] = __builtin_elementwise_fma(f32x2{t[k][0], t[k][1]}, a2, cl[h][k]);
+                        ch[h][k] = __builtin_elementwise_fma(f32x2{t[k][2], t[k][3]}, a2, ch[h][k]);
+                    }
+                    asm volatile("" : "+v"(cl[h][0]), "+v"(cl[h][1]), "+v"(cl[h][2]), "+v"(cl[h][3]), "+v"(ch[h][0]), "+v"(ch[h][1]), "+v"(ch[h][2]), "+v"(ch[h][3]));
+                });
+            });
+            // ---- fold of the 4 waves through 16 KB: waves 2, 3 write; waves 0, 1 add theirs and write back
+            {
+                float* lf = fold + (wave & 1) * W + 4 * lane;
+                if (wave >= 2) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(lf + 256 * (4 * h + k)) = f32x4{cl[h][k][0], cl[h][k][1], ch[h][k][0], ch[h][k][1]};
+                }
+                if (lane == 0) red[wave] = ra;
+                if (dbg) dbg[1] = __builtin_amdgcn_s_memrealtime();
+                __syncthreads();
+                if (wave < 2) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const f32x4 o = *reinterpret_cast<const f32x4*>(lf + 256 * (4 * h + k));
+                            *reinterpret_cast<f32x4*>(lf + 256 * (4 * h + k)) = f32x4{cl[h][k][0] + o[0], cl[h][k][1] + o[1], ch[h][k][0] + o[2], ch[h][k][1] + o[3]};
+                        }
+                }
+                __syncthreads();
+            }
+            // ---- publish the workgroup's partial column sums (stage A, 16-byte pairs: 8 adjacent columns per thread) and its dustbin sum
+            {
+                const int c = 8 * tq;
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    const f32x4 T = *reinterpret_cast<const f32x4*>(fold + c + 4 * q4) + *reinterpret_cast<const f32x4*>(fold + W + c + 4 * q4);
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int cc = c + 4 * q4 + 2 * hh, wc = cc / cs, jl = cc - wc * cs;
+                        if (FULL || cc < N) granule_store2(rsA, (unsigned)((wc * G + w) * cs + jl) * 8u, epoch, T[2 * hh], T[2 * hh + 1]);
+                    }
+                }
+                if (tq == 0) {
+                    const float U = (red[0] + red[1]) + (red[2] + red[3]);
+                    granule_store(bufU + w, epoch, U);
+                }
+            }
+            if (dbg) dbg[2] = __builtin_amdgcn_s_memrealtime();
+            // ---- stage A consume: my slice of columns over all producers -> b_j = mu / (sum + a_M), published as stage B
+            {
+                // 8 lanes per column pair, each two producers per wait (four per wait - all 32 producers in one round trip - was
+                // slower: 4.1 against 2.9 us for this stage, the polls themselves load the memory system)
+                const int q = tq & 7, cg = tq >> 3;
+                const unsigned base_b = (unsigned)(w * G * cs) * 8u;
+                for (int j0 = 0; j0 < cs; j0 += 64) {
+                    const int jl = j0 + 2 * cg, c = w * cs + jl;
+                    const bool act = jl < cs && c < N;
+                    float T0 = 0.f, T1 = 0.f;
+                    for (int g0 = 0; g0 < G; g0 += 16) {
+                        unsigned off[2];
+                        unsigned val[2][2];
+                        int n = 0;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const int g = g0 + q + 8 * i;
+                            off[i] = base_b;
+                            if (act && g < G) { off[i] = base_b + (unsigned)(g * cs + jl) * 8u; n = i + 1; }
+                        }
+                        granule_wait2<2>(rsA, off, n, epoch, val, p.timeout, dead, nap);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (i < n) { T0 += __uint_as_float(val[i][0]); T1 += __uint_as_float(val[i][1]); }
+                    }
+#pragma unroll
+                    for (int o = 4; o > 0; o >>= 1) { T0 += __shfl_xor(T0, o); T1 += __shfl_xor(T1, o); }
+                    if (act && q == 0) granule_store2(rsB, (unsigned)c * 8u, epoch, mu / (T0 + aM), mu / (T1 + aM));
+                }
+            }
+            if (dbg) dbg[3] = __builtin_amdgcn_s_memrealtime();
+            // ---- b_N = nu_N / (sum_i r_i a_i + a_M) from the G workgroup sums (wave 0)
+            if (wave == 0) {
+                float U = 0.f;
+                for (int g0 = 0; g0 < G; g0 += 64) {
+                    const int g = g0 + lane;
+                    int off[1] = {g < G ? g : 0};
+                    unsigned val[1];
+                    granule_wait<1>(bufU, off, g < G ? 1 : 0, epoch, val, p.timeout, dead, nap);
+                    if (g < G) U += __uint_as_float(val[0]);
+                }
+                U = wave_sum_dpp(U);
+                if (lane == 0) vbuf[W] = nuN / (U + aM);
+            }
+            if (dbg) dbg[4] = __builtin_amdgcn_s_memrealtime();
+            // ---- stage B consume: all of b into LDS (4 pairs per thread, one wait)
+            {
+                unsigned off[4];
+                unsigned val[4][2];
+                int n = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ca = 2 * tq + 512 * i;
+                    off[i] = 0u;
+                    if (ca < N) { off[i] = (unsigned)ca * 8u; n = i + 1; }
+                }
+                granule_wait2<4>(rsB, off, n, epoch, val, p.timeout, dead, nap);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ca = 2 * tq + 512 * i;
+                    *reinterpret_cast<f32x2*>(vbuf + ca) = f32x2{ca < N ? __uint_as_float(val[i][0]) : 0.f, ca + 1 < N ? __uint_as_float(val[i][1]) : 0.f};
+                }
+            }
+            if (dbg) dbg[5] = __builtin_amdgcn_s_memrealtime();
+            if (__syncthreads_or(dead ? 1 : 0)) dead = true;
+            if (dbg) dbg[6] = __builtin_amdgcn_s_memrealtime();
+            bN = vbuf[W];
+        }
+
+        // ---- potentials for the final sweep (as in sinkhorn_resident)
+        {
+            const float qnan = __uint_as_float(SKR_GAVE_UP_NAN);
+            float* ub = p.u + (int64_t)b * (M + 1);
+            bool bad = false;
+            if (tid < ROWS && w * ROWS + tid < M) {
+                const float ar = asv[tid];
+                bad = bad || !(ar > 0.f) || !(ar < INFINITY);
+                ub[w * ROWS + tid] = dead ? qnan : __logf(ar) - mrs[tid];
+            }
+            if (w == 0) {
+                float* vb = p.v + (int64_t)b * p.ldV;
+                for (int j = tid; j < p.ldV; j += 256) {
+                    const float bj = j < N ? vbuf[j] : (j == N ? bN : 1.f);
+                    bad = bad || !(bj > 0.f) || !(bj < INFINITY);
+                    vb[j] = dead ? qnan : __logf(bj);
+                }
+                bad = bad || !(aM > 0.f) || !(aM < INFINITY);
+                if (tid == 0) ub[M] = dead ? qnan : __logf(aM) - p.alpha;
+            }
+            if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicAdd(p.timeout + 4, 1u);
+        }
+    }
+}
 
 // ---- rescue pass behind the resident kernel -----------------------------------------------------------------------------
 // One workgroup per problem looks at the potentials the resident kernel left.  All finite (every call of an ordinary
@@ -1536,7 +1870,7 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
     }
     int wg_per_cu = 0;
     const void* kfn = nullptr;
-    bool rows128 = false;
+    int rows_hr = 0;  // 128 / 64: the kernels with K in registers addressed by number (sinkhorn_resident128 / sinkhorn_resident2k)
     size_t res_lds = sizeof(float) * (size_t)(9 * KT_of(ldS) * 256 + 4 + 32);
     if (resident) {
         const bool full = N == ldS && N == KT_of(ldS) * 256;
@@ -1560,8 +1894,8 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
                 break;
         }
         // 128 rows per workgroup (sinkhorn_resident128): twice the problems resident, about twice the arithmetic per iteration, the same
-        // two hops - a round takes 1.6 times as long (measured: 0.85 against 0.53 ms per 100 iterations at 1024 x 1024), so it is
-        // taken when it saves more than 3 rounds in 8 (the 32 problems of configs[1]: one round instead of two)
+        // two hops - a round takes 1.6 - 1.75 times as long (measured: 0.83 - 0.94 against 0.51 - 0.53 ms per 100 iterations at 1024 x 1024,
+        // by box), so it is taken when it saves more than 3 rounds in 7 (the 32 problems of configs[1]: one round instead of two)
         // (E2EMV_SINKHORN=rows64: never; unset: when it saves rounds; =rows128: whenever the shape allows it - tests compare a
         // problem alone with the same problem in a batch through the same kernel)
         int knob128 = 1;
@@ -1569,14 +1903,25 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
         if (KT_of(ldS) == 4 && knob128 != 0) {
             const int G128 = (M + 127) / 128, cs128 = (N + G128 - 1) / G128;
             const int res64 = std::max(1, ctx->num_cus / std::max(G0, 1)), res128 = std::max(1, ctx->num_cus / std::max(G128, 1));
-            if (cs128 % 2 == 0 && G128 <= 16 && (knob128 == 2 || 8 * ((B + res128 - 1) / res128) < 5 * ((B + res64 - 1) / res64))) {
+            if (cs128 % 2 == 0 && G128 <= 16 && (knob128 == 2 || 7 * ((B + res128 - 1) / res128) < 4 * ((B + res64 - 1) / res64))) {
                 kfn = (full && M % 128 == 0) ? (const void*)sinkhorn_resident128<true> : (const void*)sinkhorn_resident128<false>;  // (full rows AND columns)
-                rows128 = true;
+                rows_hr = 128;
+            }
+        }
+        // 1025 .. 2048 columns: 64 rows per workgroup (sinkhorn_resident2k) against the 32 of sinkhorn_resident<8>, eight problems
+        // resident instead of four
+        if (KT_of(ldS) == 8 && knob128 != 0) {
+            const int G2k = (M + 63) / 64, cs2k = (N + G2k - 1) / G2k;
+            const int res32 = std::max(1, ctx->num_cus / std::max(G0, 1)), res64 = std::max(1, ctx->num_cus / std::max(G2k, 1));
+            if (cs2k % 2 == 0 && G2k <= 64 && (knob128 == 2 || 8 * ((B + res64 - 1) / res64) < 5 * ((B + res32 - 1) / res32))) {
+                kfn = (full && M % 64 == 0) ? (const void*)sinkhorn_resident2k<true> : (const void*)sinkhorn_resident2k<false>;
+                rows_hr = 64;
             }
         }
         static std::map<std::pair<int, const void*>, int> occupancy;  // (device, kernel) -> resident workgroups per CU
         static std::mutex occupancy_mu;
-        if (rows128) res_lds = sizeof(float) * (size_t)(4 * SK128_RL * 1024 + 4 * 1024 + 1024 + 4 + 32 + 3 * 128);
+        if (rows_hr == 128) res_lds = sizeof(float) * (size_t)(4 * SK128_RL * 1024 + 4 * 1024 + 1024 + 4 + 32 + 3 * 128);
+        if (rows_hr == 64) res_lds = sizeof(float) * (size_t)(4 * SK2K_RL * 2048 + 2 * 2048 + 2048 + 4 + 32 + 3 * 64);
         {
             std::lock_guard<std::mutex> lk(occupancy_mu);
             auto it = occupancy.find({ctx->device, kfn});
@@ -1585,7 +1930,7 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
                 if (res_lds > 48 * 1024 && ensure_dynamic_lds(ctx, kfn, res_lds) != E2EMV_OK) {
                     (void)hipGetLastError();  // a device with less LDS: the streaming chain below serves the call
                     nb = 0;
-                } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, rows128 ? 256 : 512, res_lds) != hipSuccess) {
+                } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, rows_hr ? 256 : 512, res_lds) != hipSuccess) {
                     (void)hipGetLastError();
                     nb = 0;
                 }
@@ -1593,13 +1938,13 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
             }
             wg_per_cu = it->second;
         }
-        const int rows_wg = rows128 ? 128 : skr_rows(ldS);
+        const int rows_wg = rows_hr ? rows_hr : skr_rows(ldS);
         const int G = (M + rows_wg - 1) / rows_wg;
         if (wg_per_cu < 1 || G > wg_per_cu * ctx->num_cus) resident = false;
     }
     if (resident) {
         if (int rc_f = ensure_flags(ctx)) return rc_f;
-        const ResidentPlan rp = resident_plan(B, M, N, wg_per_cu * ctx->num_cus, rows128 ? 128 : 0);
+        const ResidentPlan rp = resident_plan(B, M, N, wg_per_cu * ctx->num_cus, rows_hr);
         SkResParams rpar{};
         rpar.S = S; rpar.ldS = ldS; rpar.M = M; rpar.N = N; rpar.B = B; rpar.iters = iters;
         rpar.alpha = alpha; rpar.norm = p.norm;
@@ -1619,8 +1964,8 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
         // every polled word starts from 0 in every launch (epochs count from 1)
         E2EMV_HIP(ctx, hipMemsetAsync(w, 0, rp.bytesA + rp.bytesB + rp.bytesU, s));
         E2EMV_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, 4, s));
-        hipLaunchKernelGGL_ptr(kfn, dim3((unsigned)(rp.n_res * rp.G)), dim3(rows128 ? 256 : 512), res_lds, s, rpar);
-        if (rows128) ++ctx->stat_sinkhorn_rows128;
+        hipLaunchKernelGGL_ptr(kfn, dim3((unsigned)(rp.n_res * rp.G)), dim3(rows_hr ? 256 : 512), res_lds, s, rpar);
+        if (rows_hr) ++ctx->stat_sinkhorn_rows128;
         E2EMV_CHECK_LAUNCH(ctx, "sinkhorn_resident");
         // problems the exponential-domain kernel could not finish are re-solved in the log domain before anything reads u, v
         hipLaunchKernelGGL(sinkhorn_rescue, dim3(B), dim3(1024), sizeof(float) * (size_t)(M + N + 2), s, p, iters, ctx->d_flags);

@@ -114,16 +114,16 @@ def t(s, it=100, reps=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): E.log_optimal_transport(s, 1.0, it)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
-for B, M, N in ((32, 1024, 1024), (80, 1024, 1024), (20, 1024, 1024), (48, 1024, 1024), (32, 896, 1020), (64, 640, 1020)):
+for B, M, N in ((32, 1024, 1024), (80, 1024, 1024), (48, 1024, 1024), (80, 2048, 2048), (16, 2048, 2048), (8, 2048, 2048), (12, 2048, 2048)):
     s = torch.randn(B, M, N, device="cuda") * 3
     r = []
     for rep in range(2):
-        for mode in ("rows64", None):
+        for mode in ("rows64", "rows128"):
             if mode: os.environ["E2EMV_SINKHORN"] = mode
             else: os.environ.pop("E2EMV_SINKHORN", None)
             r.append(t(s))
     os.environ.pop("E2EMV_SINKHORN", None)
-    print(f"{B} x {M} x {N}: rows64 {r[0]:.3f} / {r[2]:.3f} ms   library's choice {r[1]:.3f} / {r[3]:.3f} ms")
+    print(f"{B} x {M} x {N}: rows64 {r[0]:.3f} / {r[2]:.3f} ms   rows128 / 2k {r[1]:.3f} / {r[3]:.3f} ms")
 PY
   ;;
 tests)

@@ -49,6 +49,13 @@ def run(B, N, iters, flags, path):
 
 
 if __name__ == "__main__":
+    if "--rows128" in sys.argv:  # the 128-row kernel (taken by itself for 32 problems) against the 64-row one
+        for mode in ("rows64", "rows128"):
+            os.environ["E2EMV_SINKHORN"] = mode
+            for B, N in ((1, 1024), (32, 1024), (1, 2048), (8, 2048)):
+                print(mode, end=": ")
+                run(B, N, 100, 0, "/tmp/skr.txt")
+        sys.exit(0)
     for flags in (0, 1):
         for B in (1, 16, 32):
             run(B, 1024, 100, flags, "/tmp/skr.txt")
