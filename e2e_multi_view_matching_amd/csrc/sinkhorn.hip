@@ -574,17 +574,23 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // halve the number of live vectors (a lane keeps the operand of its own class and sends the other), then one vector is reduced
 // over the four quads of a row (rotations by 4 and 8) and over the four rows (gfx950's row / half-wave swaps): 12 cross-lane
 // operations for four sums instead of 24, and the sums arrive in four LANES - what follows (a division per row) runs once.
-__device__ __forceinline__ float wave_sum4_dpp(float x0, float x1, float x2, float x3, int lane) {
+// (in two parts: the butterflies leave ONE register per four rows - what a pass over many rows keeps until all row sums exist)
+__device__ __forceinline__ float wave_sum4_quads(float x0, float x1, float x2, float x3, int lane) {
     const bool o1 = (lane & 1) != 0, o2 = (lane & 2) != 0;
     const float u01 = (o1 ? x1 : x0) + dpp_move<0xB1, 0xF>(0.f, o1 ? x0 : x1);  // quad_perm [1,0,3,2]
     const float u23 = (o1 ? x3 : x2) + dpp_move<0xB1, 0xF>(0.f, o1 ? x2 : x3);
-    float t = (o2 ? u23 : u01) + dpp_move<0x4E, 0xF>(0.f, o2 ? u01 : u23);      // quad_perm [2,3,0,1]
+    return (o2 ? u23 : u01) + dpp_move<0x4E, 0xF>(0.f, o2 ? u01 : u23);         // quad_perm [2,3,0,1]: lane l = x[l & 3] over its quad
+}
+__device__ __forceinline__ float wave_sum4_rows(float t) {
     t += dpp_move<0x124, 0xF>(0.f, t);                                           // row_ror:4
     t += dpp_move<0x128, 0xF>(0.f, t);                                           // row_ror:8
     auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
     t = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
     auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
     return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
+__device__ __forceinline__ float wave_sum4_dpp(float x0, float x1, float x2, float x3, int lane) {
+    return wave_sum4_rows(wave_sum4_quads(x0, x1, x2, x3, lane));
 }
 
 // rows per workgroup: 8 waves x 4 rows up to 1024 columns, 8 x 2 rows up to 2048 (64 matrix values per lane either way)
@@ -1047,6 +1053,15 @@ __device__ __forceinline__ void sk_static_for(F&& f) { sk_static_for_impl(std::m
 constexpr int SK128_RV = 12, SK128_RA = 12, SK128_RL = 8, SK128_RR = SK128_RV + SK128_RA, SK128_R0 = 64;
 constexpr int sk128_base(int r) { return SK128_R0 + 16 * (r < SK128_RV ? r : r - SK128_RV); }
 #include "sinkhorn128_rows.h"
+// per-phase timestamps (tools/skr_timing.py): only in the measurement build - in these two kernels a 64-bit pointer kept over the
+// iteration costs registers the compiler's window does not have (it went to scratch and was reloaded at every stamp)
+#ifdef E2EMV_STAMPS
+#define SK_STAMP_PTR() unsigned long long* const dbg = (p.dbg && grp == 0 && round == 0 && it < 16 && tid == 0) ? p.dbg + ((int64_t)it * G + w) * 8 : nullptr
+#define SK_STAMP(i) do { if (dbg) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SK_STAMP_PTR() do {} while (0)
+#define SK_STAMP(i) do {} while (0)
+#endif
 template <bool FULL>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void sinkhorn_resident128(SkResParams p) {
     constexpr int KT = 4, W = 1024, RW = SK128_RR + SK128_RL, ROWS = 4 * RW;
@@ -1134,91 +1149,112 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
             asm volatile("" : "+v"(tq));
             u64* const bufU = bufU2 + (epoch & 1u) * (unsigned)G;
             const bool last = it + 1 == p.iters;
-            unsigned long long* const dbg = (p.dbg && grp == 0 && round == 0 && it < 16 && tid == 0) ? p.dbg + ((int64_t)it * G + w) * 8 : nullptr;
-            if (dbg) dbg[0] = __builtin_amdgcn_s_memrealtime();
-            // ---- ONE pass over the wave's 32 rows: row sum -> a_i -> the row's contribution to the column sums
+            SK_STAMP_PTR();
+            SK_STAMP(0);
+            // ---- the wave's 32 rows in three phases, so that no latency-bound chain stands between two streams of multiply-adds:
+            //   (1) row sums of all rows (asm), four rows folded into one register by two butterflies;
+            //   (2) the 8 reductions over quads and rows and the 8 divisions - independent chains, interleaved by the compiler;
+            //   (3) column sums of all rows (asm) with the a_i as scalars.  LDS rows are read in both (1) and (3).
             f32x2 cl[KT], ch[KT];  // partial column sums of this lane's 16 columns (pairs 0 - 1 | 2 - 3 of each chunk)
             float ra = 0.f;         // sum of r_i a_i over the wave's rows (dustbin column)
             {
-                f32x2 blo[KT], bhi[KT];
-                f32x2 accb = {0.f, 0.f};
+                const unsigned kl_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)kl;
+                float t4[RW / 4];   // group g: lane l holds the sum of row 4 g + (l & 3) over the lane's quad
+                {
+                    f32x2 blo[KT], bhi[KT];
+                    f32x2 accb = {0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < KT; ++k) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(vbuf + 4 * (lane + 64 * k));  // 0 beyond N
-                    blo[k] = f32x2{b4[0], b4[1]};
-                    bhi[k] = f32x2{b4[2], b4[3]};
-                    accb += blo[k] + bhi[k];
-                    cl[k] = f32x2{0.f, 0.f};
-                    ch[k] = f32x2{0.f, 0.f};
+                    for (int k = 0; k < KT; ++k) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(vbuf + 4 * (lane + 64 * k));  // 0 beyond N
+                        blo[k] = f32x2{b4[0], b4[1]};
+                        bhi[k] = f32x2{b4[2], b4[3]};
+                        accb += blo[k] + bhi[k];
+                    }
+                    aM = muM / (wave_sum_dpp(accb[0] + accb[1]) + bN);
+                    sk_static_for<SK128_RR / 4>([&](auto g_c) {
+                        constexpr int g = decltype(g_c)::value, r0 = 4 * g;
+                        constexpr int B0 = sk128_base(r0), B1 = sk128_base(r0 + 1), B2 = sk128_base(r0 + 2), B3 = sk128_base(r0 + 3);
+                        f32x2 acc[4];
+                        if constexpr (r0 < SK128_RV) {
+                            sk128_rs4v<B0, B1, B2, B3>(acc, blo, bhi);
+                        } else {
+                            sk128_rs2a<B0, B1>(acc[0], acc[1], blo, bhi);
+                            sk128_rs2a<B2, B3>(acc[2], acc[3], blo, bhi);
+                        }
+                        t4[g] = wave_sum4_quads(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1], acc[2][0] + acc[2][1], acc[3][0] + acc[3][1], lane);
+                        asm volatile("" : "+v"(t4[g]));
+                    });
+                    // LDS rows one at a time through 16 registers (one asm statement per row: plain loads are all hoisted to the front
+                    // of the pass - 128 registers - and spilled from there)
+                    sk_static_for<SK128_RL / 4>([&](auto g_c) {
+                        constexpr int g = decltype(g_c)::value;
+                        float x[4];
+                        sk_static_for<4>([&](auto j_c) {
+                            constexpr int j = decltype(j_c)::value, r = 4 * g + j;
+                            f32x4 t0, t1, t2, t3;
+                            asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%5+1024\n\t"
+                                         "ds_read_b128 %2, %4 offset:%5+2048\n\tds_read_b128 %3, %4 offset:%5+3072\n\ts_waitcnt lgkmcnt(0)"
+                                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(kl_a), "n"(r * W * 4));
+                            const f32x4 t[KT] = {t0, t1, t2, t3};
+                            f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                            for (int k = 0; k < KT; ++k) {
+                                acc = __builtin_elementwise_fma(f32x2{t[k][0], t[k][1]}, blo[k], acc);
+                                acc = __builtin_elementwise_fma(f32x2{t[k][2], t[k][3]}, bhi[k], acc);
+                            }
+                            x[j] = acc[0] + acc[1];
+                            asm volatile("" : "+v"(x[j]));
+                        });
+                        t4[SK128_RR / 4 + g] = wave_sum4_quads(x[0], x[1], x[2], x[3], lane);
+                    });
                 }
-                aM = muM / (wave_sum_dpp(accb[0] + accb[1]) + bN);
-                // register rows in groups of 4: row sums (asm) -> ONE 4-way reduction, the sums in lanes (l & 3) -> a_i of the four
-                // rows in one division -> read back as scalars -> column sums (asm).  The dustbin statistic sum_i r_i a_i is kept
-                // per lane class and folded at the end of the pass.
+                // (2) a_i of four rows per division; the scalars for phase 3; the dustbin statistic sum_i r_i a_i per lane class
+                float as[RW];
                 float ra4 = 0.f;
+                int l3 = lane & 3;
+                asm volatile("" : "+v"(l3));  // (per iteration: the 8 LDS addresses below are otherwise hoisted out of the loop and spilled)
+#pragma unroll
+                for (int g = 0; g < RW / 4; ++g) {
+                    const float s_r = wave_sum4_rows(t4[g]);
+                    const int rl = wave * RW + 4 * g + l3;
+                    const float rk = rks[rl];
+                    const float ar = (FULL || row0 + 4 * g + l3 < M) ? mu / fmaf(rk, bN, s_r) : 0.f;
+                    ra4 = fmaf(rk, ar, ra4);
+                    if (last) asv[rl] = ar;  // for the potentials (16 lanes write the same value to the same word)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) as[4 * g + q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ar), q));
+                }
+                ra = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 1)))
+                     + (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 2)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 3)));
+                // (3)
+#pragma unroll
+                for (int k = 0; k < KT; ++k) { cl[k] = f32x2{0.f, 0.f}; ch[k] = f32x2{0.f, 0.f}; }
                 sk_static_for<SK128_RR / 4>([&](auto g_c) {
                     constexpr int r0 = 4 * decltype(g_c)::value;
                     constexpr int B0 = sk128_base(r0), B1 = sk128_base(r0 + 1), B2 = sk128_base(r0 + 2), B3 = sk128_base(r0 + 3);
-                    f32x2 acc[4];
-                    if constexpr (r0 < SK128_RV) {
-                        sk128_rs4v<B0, B1, B2, B3>(acc, blo, bhi);
-                    } else {
-                        sk128_rs2a<B0, B1>(acc[0], acc[1], blo, bhi);
-                        sk128_rs2a<B2, B3>(acc[2], acc[3], blo, bhi);
-                    }
-                    const float s_r = wave_sum4_dpp(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1], acc[2][0] + acc[2][1], acc[3][0] + acc[3][1], lane);
-                    const int rl = wave * RW + r0 + (lane & 3);
-                    const float rk = rks[rl];
-                    const float ar = (FULL || row0 + r0 + (lane & 3) < M) ? mu / fmaf(rk, bN, s_r) : 0.f;
-                    ra4 = fmaf(rk, ar, ra4);
-                    asm volatile("" : "+v"(ra4));  // (here: deferred to the end of the pass, every group's r_i and a_i went to scratch)
-                    if (last) asv[rl] = ar;       // for the potentials (16 lanes write the same value to the same word)
-                    f32x2 a2[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float aq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ar), q));
-                        a2[q] = f32x2{aq, aq};
-                    }
+                    const f32x2 a2[4] = {f32x2{as[r0], as[r0]}, f32x2{as[r0 + 1], as[r0 + 1]}, f32x2{as[r0 + 2], as[r0 + 2]}, f32x2{as[r0 + 3], as[r0 + 3]}};
                     if constexpr (r0 < SK128_RV) sk128_rc4v<B0, B1, B2, B3>(cl, ch, a2);
                     else sk128_rc4a<B0, B1, B2, B3>(cl, ch, a2);
                 });
-                ra = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 1)))
-                     + (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 2)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ra4), 3)));
-                auto row_a = [&](float s_r, int r) __attribute__((always_inline)) {
-                    const float rk = rks[wave * RW + r];
-                    const float ar = (FULL || row0 + r < M) ? mu / fmaf(rk, bN, s_r) : 0.f;
-                    ra = fmaf(rk, ar, ra);
-                    asm volatile("" : "+v"(ra));
-                    return ar;
-                };
-                // LDS rows one at a time: read once into 16 registers (as one asm statement per row: plain loads are all hoisted to
-                // the front of the pass - 128 registers - and spilled from there)
-                const unsigned kl_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)kl;
-                sk_static_for<SK128_RL>([&](auto g_c) {
-                    constexpr int r = decltype(g_c)::value;
-                    f32x4 t0, t1, t2, t3;
-                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%5+1024\n\t"
-                                 "ds_read_b128 %2, %4 offset:%5+2048\n\tds_read_b128 %3, %4 offset:%5+3072\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(kl_a), "n"(r * W * 4));
-                    const f32x4 t[KT] = {t0, t1, t2, t3};
-                    f32x2 kr[KT][2];
-                    f32x2 acc = {0.f, 0.f};
+                sk_static_for<SK128_RL / 2>([&](auto g_c) {  // LDS rows again, two per statement (32 registers: b is dead by now)
+                    constexpr int r = 2 * decltype(g_c)::value;
+                    f32x4 t0, t1, t2, t3, t4_, t5, t6, t7;
+                    asm volatile("ds_read_b128 %0, %8 offset:%9\n\tds_read_b128 %1, %8 offset:%9+1024\n\t"
+                                 "ds_read_b128 %2, %8 offset:%9+2048\n\tds_read_b128 %3, %8 offset:%9+3072\n\t"
+                                 "ds_read_b128 %4, %8 offset:%9+4096\n\tds_read_b128 %5, %8 offset:%9+4096+1024\n\t"
+                                 "ds_read_b128 %6, %8 offset:%9+4096+2048\n\tds_read_b128 %7, %8 offset:%9+4096+3072\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4_), "=&v"(t5), "=&v"(t6), "=&v"(t7) : "v"(kl_a), "n"(r * W * 4));
+                    const f32x4 t[2][KT] = {{t0, t1, t2, t3}, {t4_, t5, t6, t7}};
 #pragma unroll
-                    for (int k = 0; k < KT; ++k) {
-                        kr[k][0] = f32x2{t[k][0], t[k][1]};
-                        kr[k][1] = f32x2{t[k][2], t[k][3]};
-                        acc = __builtin_elementwise_fma(kr[k][0], blo[k], acc);
-                        acc = __builtin_elementwise_fma(kr[k][1], bhi[k], acc);
-                    }
-                    const float ar = row_a(wave_sum_dpp(acc[0] + acc[1]), SK128_RR + r);
-                    if (last) asv[wave * RW + SK128_RR + r] = ar;
-                    const f32x2 a2 = {ar, ar};
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x2 a2 = {as[SK128_RR + r + j], as[SK128_RR + r + j]};
 #pragma unroll
-                    for (int k = 0; k < KT; ++k) {
-                        cl[k] = __builtin_elementwise_fma(kr[k][0], a2, cl[k]);
-                        ch[k] = __builtin_elementwise_fma(kr[k][1], a2, ch[k]);
+                        for (int k = 0; k < KT; ++k) {
+                            cl[k] = __builtin_elementwise_fma(f32x2{t[j][k][0], t[j][k][1]}, a2, cl[k]);
+                            ch[k] = __builtin_elementwise_fma(f32x2{t[j][k][2], t[j][k][3]}, a2, ch[k]);
+                        }
                     }
-                    // (here, not sunk to the end of the pass with the row kept in scratch until then)
+                    // (here, not sunk to the end of the pass with the rows kept in scratch until then)
                     asm volatile("" : "+v"(cl[0]), "+v"(cl[1]), "+v"(cl[2]), "+v"(cl[3]), "+v"(ch[0]), "+v"(ch[1]), "+v"(ch[2]), "+v"(ch[3]));
                 });
             }
@@ -1228,7 +1264,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
 #pragma unroll
                 for (int k = 0; k < KT; ++k) *reinterpret_cast<f32x4*>(lf + 256 * k) = f32x4{cl[k][0], cl[k][1], ch[k][0], ch[k][1]};
                 if (lane == 0) red[wave] = ra;
-                if (dbg) dbg[1] = __builtin_amdgcn_s_memrealtime();
+                SK_STAMP(1);
                 __syncthreads();
             }
             // ---- publish the workgroup's partial column sums (stage A, 16-byte pairs: 4 adjacent columns per thread) and its dustbin sum
@@ -1247,7 +1283,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                     granule_store(bufU + w, epoch, U);
                 }
             }
-            if (dbg) dbg[2] = __builtin_amdgcn_s_memrealtime();
+            SK_STAMP(2);
             // ---- stage A consume: my slice of columns over all producers -> b_j = mu / (sum + a_M), published as stage B
             {
                 const int q = tq & 3, cg = tq >> 2;  // 4 lanes per column pair, each two producers: q, q + 4 (, + 8, + 12)
@@ -1276,7 +1312,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                     if (act && q == 0) granule_store2(rsB, (unsigned)c * 8u, epoch, mu / (T0 + aM), mu / (T1 + aM));
                 }
             }
-            if (dbg) dbg[3] = __builtin_amdgcn_s_memrealtime();
+            SK_STAMP(3);
             // ---- b_N = nu_N / (sum_i r_i a_i + a_M) from the G workgroup sums (wave 0)
             if (wave == 0) {
                 float U = 0.f;
@@ -1290,7 +1326,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                 U = wave_sum_dpp(U);
                 if (lane == 0) vbuf[W] = nuN / (U + aM);
             }
-            if (dbg) dbg[4] = __builtin_amdgcn_s_memrealtime();
+            SK_STAMP(4);
             // ---- stage B consume: all of b into LDS (2 pairs per thread)
             {
                 unsigned off[2];
@@ -1309,9 +1345,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                     *reinterpret_cast<f32x2*>(vbuf + ca) = f32x2{ca < N ? __uint_as_float(val[i][0]) : 0.f, ca + 1 < N ? __uint_as_float(val[i][1]) : 0.f};
                 }
             }
-            if (dbg) dbg[5] = __builtin_amdgcn_s_memrealtime();
+            SK_STAMP(5);
             if (__syncthreads_or(dead ? 1 : 0)) dead = true;
-            if (dbg) dbg[6] = __builtin_amdgcn_s_memrealtime();
+            SK_STAMP(6);
             bN = vbuf[W];
         }
 
@@ -1435,8 +1471,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
             asm volatile("" : "+v"(tq));
             u64* const bufU = bufU2 + (epoch & 1u) * (unsigned)G;
             const bool last = it + 1 == p.iters;
-            unsigned long long* const dbg = (p.dbg && grp == 0 && round == 0 && it < 16 && tid == 0) ? p.dbg + ((int64_t)it * G + w) * 8 : nullptr;
-            if (dbg) dbg[0] = __builtin_amdgcn_s_memrealtime();
+            SK_STAMP_PTR();
+            SK_STAMP(0);
             // ---- row sums, per column half: one register per row
             float accp[RW];
 #pragma unroll
@@ -1542,7 +1578,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                         for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(lf + 256 * (4 * h + k)) = f32x4{cl[h][k][0], cl[h][k][1], ch[h][k][0], ch[h][k][1]};
                 }
                 if (lane == 0) red[wave] = ra;
-                if (dbg) dbg[1] = __builtin_amdgcn_s_memrealtime();
+                SK_STAMP(1);
                 __syncthreads();
                 if (wave < 2) {
 #pragma unroll
@@ -1572,7 +1608,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                     granule_store(bufU + w, epoch, U);
                 }
             }
-            if (dbg) dbg[2] = __builtin_amdgcn_s_memrealtime();
+            SK_STAMP(2);
             // ---- stage A consume: my slice of columns over all producers -> b_j = mu / (sum + a_M), published as stage B
             {
                 // 8 lanes per column pair, each two producers per wait (four per wait - all 32 producers in one round trip - was
@@ -1603,7 +1639,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                     if (act && q == 0) granule_store2(rsB, (unsigned)c * 8u, epoch, mu / (T0 + aM), mu / (T1 + aM));
                 }
             }
-            if (dbg) dbg[3] = __builtin_amdgcn_s_memrealtime();
+            SK_STAMP(3);
             // ---- b_N = nu_N / (sum_i r_i a_i + a_M) from the G workgroup sums (wave 0)
             if (wave == 0) {
                 float U = 0.f;
@@ -1617,7 +1653,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                 U = wave_sum_dpp(U);
                 if (lane == 0) vbuf[W] = nuN / (U + aM);
             }
-            if (dbg) dbg[4] = __builtin_amdgcn_s_memrealtime();
+            SK_STAMP(4);
             // ---- stage B consume: all of b into LDS (4 pairs per thread, one wait)
             {
                 unsigned off[4];
@@ -1636,9 +1672,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                     *reinterpret_cast<f32x2*>(vbuf + ca) = f32x2{ca < N ? __uint_as_float(val[i][0]) : 0.f, ca + 1 < N ? __uint_as_float(val[i][1]) : 0.f};
                 }
             }
-            if (dbg) dbg[5] = __builtin_amdgcn_s_memrealtime();
+            SK_STAMP(5);
             if (__syncthreads_or(dead ? 1 : 0)) dead = true;
-            if (dbg) dbg[6] = __builtin_amdgcn_s_memrealtime();
+            SK_STAMP(6);
             bN = vbuf[W];
         }
 
