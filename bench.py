@@ -698,19 +698,28 @@ def run(args):
             wg_per_cu = 1 if (rows_wg == 64 or N > 1024) else 2
             resident = max(1, min(problems, (wg_per_cu * 256) // max((N + rows_wg - 1) // rows_wg, 1)))
             rounds = -(-problems // resident)
+            # the kernels with the couplings in registers addressed by number (sinkhorn_resident128 / sinkhorn_resident2k): twice the
+            # rows per workgroup, twice the problems resident - taken by the launcher when the saved rounds pay for the longer round
+            big, num, den = (128, 7, 4) if 512 < N <= 1024 else ((64, 8, 5) if 1024 < N <= 2048 else (0, 1, 1))
+            if big:
+                g_big = (N + big - 1) // big
+                res_big = max(1, min(problems, 256 // g_big))
+                if ((N + g_big - 1) // g_big) % 2 == 0 and num * -(-problems // res_big) < den * rounds:
+                    rows_wg, resident, rounds = big, res_big, -(-problems // res_big)
             hop_us = 0.8  # an idle one-to-one granule hand-off on this chip (MI355X_MICROARCH.md price list): the physical floor of a hop
             exch_ms = rounds * args.sinkhorn_iters * 2 * hop_us * 1e-3
             fma_ms = rounds * args.sinkhorn_iters * 2 * (resident * N * N / 2) / (256 * 64 * 2.0e9) * 1e3  # packed fp32 FMA: 2 elements / lane / clk
             physical = problems * 2 * N * N * 4 + problems * (N + 1) ** 2 * 4
             out["sinkhorn_bound"] = {"bound": "inter-workgroup exchange latency (resident kernel)", "ms_per_call": round(ms_call, 3),
-                                     "iterations": args.sinkhorn_iters, "problems": problems, "resident_problems": resident, "rounds": rounds,
+                                     "iterations": args.sinkhorn_iters, "problems": problems, "rows_per_workgroup": rows_wg, "resident_problems": resident, "rounds": rounds,
                                      "us_per_iteration": round(ms_call * 1e3 / (rounds * max(args.sinkhorn_iters, 1)), 2),
                                      "exchange_floor_ms": round(exch_ms, 3), "arithmetic_floor_ms": round(fma_ms, 3),
                                      "frac": round((exch_ms + fma_ms) / ms_call, 4),
                                      "physical_hbm_gbs": round(physical / (ms_call * 1e-3) / 1e9, 1),
-                                     "note": "frac = (2 idle granule hops of 0.8 us per iteration + packed-FMA time) / measured; one problem alone on "
-                                             "the chip runs 5.05 us per iteration (profiles/README.md); the SURVEY 8(d) byte model (2 sweeps of the "
-                                             "couplings per iteration from HBM) does not describe a kernel that keeps them in registers"}
+                                     "note": "frac = (2 idle granule hops of 0.8 us per iteration + fp32 FMA time at 64 elements / clk / CU) / measured; one "
+                                             "problem alone on the chip runs 4.6 us per iteration on 64-row workgroups (profiles/README.md); the SURVEY "
+                                             "8(d) byte model (2 sweeps of the couplings per iteration from HBM) does not describe a kernel that keeps "
+                                             "them in registers"}
     for alt, alt_prof in alts:
         if alt_prof:
             alt["roofline"], alt["roofline_second"], alt["families"] = roofline_of(alt_prof, alt["mode"])
