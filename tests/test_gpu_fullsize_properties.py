@@ -117,7 +117,10 @@ def test_pose_from_matches_recovers_ground_truth_and_is_scale_invariant(full):
 
 
 def test_sinkhorn_idempotent_rerun_and_batch_independence(gpu):
-    """Same input twice -> bit-identical output; a pair's result does not depend on its batch neighbours."""
+    """Same input twice -> bit-identical output; a pair's result does not depend on its batch neighbours.  The library serves a
+    batch of 32 on 128-row workgroups and a batch of 2 on 64-row ones (another summation order of the same algorithm): bit for bit
+    with the kernel pinned (E2EMV_SINKHORN=rows64 / rows128), within the two orders' distance with the library's own choice."""
+    import os
     import e2e_multi_view_matching_amd as E
     g = torch.Generator().manual_seed(4)
     s = (torch.randn(32, 1024, 1024, generator=g) * 4).to(gpu)
@@ -125,7 +128,15 @@ def test_sinkhorn_idempotent_rerun_and_batch_independence(gpu):
     b = E.log_optimal_transport(s, 1.0, 100)
     assert torch.equal(a, b)
     c = E.log_optimal_transport(s[5:7].contiguous(), 1.0, 100)
-    assert torch.equal(c, a[5:7])
+    assert float((c - a[5:7]).abs().max()) < 2e-5
+    assert torch.equal(c[:, :-1, :-1].argmax(2), a[5:7, :-1, :-1].argmax(2))
+    try:
+        for mode in ("rows64", "rows128"):
+            os.environ["E2EMV_SINKHORN"] = mode
+            a = E.log_optimal_transport(s, 1.0, 100)
+            assert torch.equal(E.log_optimal_transport(s[5:7].contiguous(), 1.0, 100), a[5:7]), mode
+    finally:
+        os.environ.pop("E2EMV_SINKHORN", None)
 
 
 def test_multi_frame_self_consistency(gpu):
