@@ -148,6 +148,10 @@ final)
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_c2_steps6 -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_c2_steps6.log 2>&1)
   db=$(find /tmp/kt_c2_steps6 -name '*.db' | head -1)
   [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r5_kernel_stats_c2_f16x2_steps6.md 2>&1
+  # the Sinkhorn kernels against each other (product library), then their per-phase timestamps (measurement build)
+  bash tools/gpu.sh sk128 > /dev/null 2>&1
+  timeout 400 python tools/skr_timing.py --rows128 2>&1 | grep -v amdgpu.ids > $OUT/skr_rows128.log
+  { echo "# ms per call of 100 iterations incl. the final sweep, one box, alternating (tools/gpu.sh sk128; rows64 = E2EMV_SINKHORN=rows64: the 64-row"; echo "# (32-row at 2048 columns) workgroups only, rows128 / 2k = the kernels with the couplings in registers addressed by number wherever the shape allows)"; grep " x " $OUT/sk128_time.log; echo; echo "# tests/test_gpu_sinkhorn_resident.py on the same box:"; tail -1 $OUT/sk128_tests.log; echo; echo "# per-phase timestamps (tools/skr_timing.py --rows128, measurement build tools/libe2emv_stamps.bin; workgroup 0's thread 0, iterations 2 - 13):"; cat $OUT/skr_rows128.log; } > $OUT/r5_sinkhorn_rows128.log
   echo "at::native launches: steps 2 / steps 6"; grep "at::native" $OUT/r5_kernel_stats_c2_f16x2.md $OUT/r5_kernel_stats_c2_f16x2_steps6.md
   grep "gemm_p2_chain\|attention_p2w" $OUT/r5_kernel_stats_c2_f16x2.md $OUT/r5_kernel_stats_c2_f16x2_steps6.md
   ;;
