@@ -696,22 +696,35 @@ def run(args):
             problems = B * P
             rows_wg = 64 if 512 < N <= 1024 else 32                      # rows of a problem per workgroup (sinkhorn.hip: skr_rows)
             wg_per_cu = 1 if (rows_wg == 64 or N > 1024) else 2
-            resident = max(1, min(problems, (wg_per_cu * 256) // max((N + rows_wg - 1) // rows_wg, 1)))
-            rounds = -(-problems // resident)
-            # the kernels with the couplings in registers addressed by number (sinkhorn_resident128 / sinkhorn_resident2k): twice the
-            # rows per workgroup, twice the problems resident - taken by the launcher when the saved rounds pay for the longer round
-            big, num, den = (128, 7, 4) if 512 < N <= 1024 else ((64, 8, 5) if 1024 < N <= 2048 else (0, 1, 1))
+            res_base = max(1, (wg_per_cu * 256) // max((N + rows_wg - 1) // rows_wg, 1))
+            # the launcher's plan (sinkhorn.hip, launch_sinkhorn): the kernels with the couplings in registers addressed by number
+            # (sinkhorn_resident128 / sinkhorn_resident2k: twice the rows per workgroup, twice the problems resident) take their full
+            # rounds, the remainder goes to the compiler-allocated kernel unless that needs two rounds or more
+            big = 128 if 512 < N <= 1024 else (64 if 1024 < N <= 2048 else 0)
+            segments = []  # (rows per workgroup, resident problems, rounds)
+            n_big = 0
             if big:
                 g_big = (N + big - 1) // big
-                res_big = max(1, min(problems, 256 // g_big))
-                if ((N + g_big - 1) // g_big) % 2 == 0 and num * -(-problems // res_big) < den * rounds:
-                    rows_wg, resident, rounds = big, res_big, -(-problems // res_big)
+                res_big = max(1, 256 // g_big)
+                if ((N + g_big - 1) // g_big) % 2 == 0:
+                    n_big = (problems // res_big) * res_big
+                    rem = problems - n_big
+                    if rem > 0 and 8 * -(-rem // res_base) > 13:
+                        n_big = problems
+                    if n_big:
+                        segments.append((big, min(n_big, res_big), -(-n_big // res_big)))
+            if n_big < problems:
+                segments.append((rows_wg, min(problems - n_big, res_base), -(-(problems - n_big) // res_base)))
+            rounds = sum(sg[2] for sg in segments)
+            resident = max(sg[1] for sg in segments)
             hop_us = 0.8  # an idle one-to-one granule hand-off on this chip (MI355X_MICROARCH.md price list): the physical floor of a hop
             exch_ms = rounds * args.sinkhorn_iters * 2 * hop_us * 1e-3
-            fma_ms = rounds * args.sinkhorn_iters * 2 * (resident * N * N / 2) / (256 * 64 * 2.0e9) * 1e3  # packed fp32 FMA: 2 elements / lane / clk
+            fma_ms = sum(sg[2] * args.sinkhorn_iters * 2 * (sg[1] * N * N / 2) / (256 * 64 * 2.0e9) * 1e3 for sg in segments)  # fp32 FMA: 64 elements / clk / CU
             physical = problems * 2 * N * N * 4 + problems * (N + 1) ** 2 * 4
             out["sinkhorn_bound"] = {"bound": "inter-workgroup exchange latency (resident kernel)", "ms_per_call": round(ms_call, 3),
-                                     "iterations": args.sinkhorn_iters, "problems": problems, "rows_per_workgroup": rows_wg, "resident_problems": resident, "rounds": rounds,
+                                     "iterations": args.sinkhorn_iters, "problems": problems,
+                                     "segments": [{"rows_per_workgroup": a, "resident_problems": b_, "rounds": c} for a, b_, c in segments],
+                                     "resident_problems": resident, "rounds": rounds,
                                      "us_per_iteration": round(ms_call * 1e3 / (rounds * max(args.sinkhorn_iters, 1)), 2),
                                      "exchange_floor_ms": round(exch_ms, 3), "arithmetic_floor_ms": round(fma_ms, 3),
                                      "frac": round((exch_ms + fma_ms) / ms_call, 4),

@@ -18,6 +18,15 @@
 // Row loads are 16 B per lane, 1 KiB contiguous per wave instruction.
 // The final sweep writes logZ = couplings + u + v + log(M+N) densely ([M+1][N+1], the API
 // layout) and fuses the row/column arg-max needed by the match block, so Z is never re-read.
+//
+// That launch chain (round 1) is the fallback today.  The default path is a RESIDENT kernel: all iterations in one launch, in the
+// exponential domain, K = exp(S - rowmax) kept on chip for the whole call, the workgroups of a problem exchanging column sums
+// through tagged granules:
+//   sinkhorn_resident<KT, ...>   8 waves, 32 / 64 rows per workgroup, K in 64 / 128 compiler-allocated registers per lane
+//   sinkhorn_resident128         4 waves, 128 rows x <= 1024 columns: 24 of a wave's 32 rows in registers the kernel addresses
+//                                by number (v64 - v255, a64 - a255; the compiler confined to 56), 8 in LDS - 32 problems resident
+//   sinkhorn_resident2k          the same for <= 2048 columns, 64 rows per workgroup - 8 problems resident instead of 4
+// followed by sinkhorn_rescue (problems that left fp32's range or gave up on a wait: re-solved in the log domain) and the final sweep.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -1904,16 +1913,22 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
         if (++ctx->sk_stream_calls > 16) { ctx->sinkhorn_stream = false; ctx->sk_stream_calls = 0; ctx->sk_range_strikes = 1; }
         else resident = false;
     }
-    int wg_per_cu = 0;
-    const void* kfn = nullptr;
-    int rows_hr = 0;  // 128 / 64: the kernels with K in registers addressed by number (sinkhorn_resident128 / sinkhorn_resident2k)
-    size_t res_lds = sizeof(float) * (size_t)(9 * KT_of(ldS) * 256 + 4 + 32);
+    // A call is served by one or two resident launches (segments of the batch): the kernels with K in registers addressed by number
+    // (sinkhorn_resident128 at 513 .. 1024 columns, sinkhorn_resident2k at 1025 .. 2048: twice the rows per workgroup, twice the
+    // problems resident, a round 1.6 - 1.75 times as long - measured 0.83 - 0.94 against 0.51 - 0.53 ms per 100 iterations at
+    // 1024 x 1024, 1.21 against 0.80 at 2048 x 2048) take every FULL round of theirs, the remainder goes to whichever is cheaper:
+    // rounds of the compiler-allocated kernel, or one more round of the big one.  80 problems of 1024 x 1024 = 64 + 16.
+    // E2EMV_SINKHORN=rows64: never the big kernels; =rows128: the big kernel for the whole batch whenever the shape allows it
+    // (tests compare a problem alone with the same problem in a batch through the same kernel).
+    struct SkKernel { const void* fn = nullptr; int rows = 0, threads = 512, wg_per_cu = 0; size_t lds = 0; bool big = false; };
+    SkKernel kbase, kbig;
     if (resident) {
         const bool full = N == ldS && N == KT_of(ldS) * 256;
         // granule pairs (16-byte exchange stores / loads): a thread must own an even number of columns and a consumer's column
         // slice must be even
         const int G0 = (M + skr_rows(ldS) - 1) / skr_rows(ldS);
         const bool pairs = KT_of(ldS) >= 4 && ((N + G0 - 1) / G0) % 2 == 0 && dbg_knob("E2EMV_SKR_PAIR", 1) != 0;
+        const void* kfn = nullptr;
         switch (KT_of(ldS)) {
             case 1: kfn = full ? (const void*)sinkhorn_resident<1, true> : (const void*)sinkhorn_resident<1, false>; break;
             case 2: kfn = full ? (const void*)sinkhorn_resident<2, true> : (const void*)sinkhorn_resident<2, false>; break;
@@ -1929,99 +1944,113 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
                 else kfn = full ? (const void*)sinkhorn_resident<8, true> : (const void*)sinkhorn_resident<8, false>;
                 break;
         }
-        // 128 rows per workgroup (sinkhorn_resident128): twice the problems resident, about twice the arithmetic per iteration, the same
-        // two hops - a round takes 1.6 - 1.75 times as long (measured: 0.83 - 0.94 against 0.51 - 0.53 ms per 100 iterations at 1024 x 1024,
-        // by box), so it is taken when it saves more than 3 rounds in 7 (the 32 problems of configs[1]: one round instead of two)
-        // (E2EMV_SINKHORN=rows64: never; unset: when it saves rounds; =rows128: whenever the shape allows it - tests compare a
-        // problem alone with the same problem in a batch through the same kernel)
-        int knob128 = 1;
-        if (const char* e = getenv("E2EMV_SINKHORN")) knob128 = strcmp(e, "rows64") == 0 ? 0 : (strcmp(e, "rows128") == 0 ? 2 : 1);
-        if (KT_of(ldS) == 4 && knob128 != 0) {
+        kbase.fn = kfn; kbase.rows = skr_rows(ldS); kbase.threads = 512;
+        kbase.lds = sizeof(float) * (size_t)(9 * KT_of(ldS) * 256 + 4 + 32);
+        if (KT_of(ldS) == 4) {
             const int G128 = (M + 127) / 128, cs128 = (N + G128 - 1) / G128;
-            const int res64 = std::max(1, ctx->num_cus / std::max(G0, 1)), res128 = std::max(1, ctx->num_cus / std::max(G128, 1));
-            if (cs128 % 2 == 0 && G128 <= 16 && (knob128 == 2 || 7 * ((B + res128 - 1) / res128) < 4 * ((B + res64 - 1) / res64))) {
-                kfn = (full && M % 128 == 0) ? (const void*)sinkhorn_resident128<true> : (const void*)sinkhorn_resident128<false>;  // (full rows AND columns)
-                rows_hr = 128;
+            if (cs128 % 2 == 0 && G128 <= 16) {
+                kbig.fn = (full && M % 128 == 0) ? (const void*)sinkhorn_resident128<true> : (const void*)sinkhorn_resident128<false>;  // (full rows AND columns)
+                kbig.rows = 128;
+                kbig.lds = sizeof(float) * (size_t)(4 * SK128_RL * 1024 + 4 * 1024 + 1024 + 4 + 32 + 3 * 128);
             }
-        }
-        // 1025 .. 2048 columns: 64 rows per workgroup (sinkhorn_resident2k) against the 32 of sinkhorn_resident<8>, eight problems
-        // resident instead of four
-        if (KT_of(ldS) == 8 && knob128 != 0) {
+        } else if (KT_of(ldS) == 8) {
             const int G2k = (M + 63) / 64, cs2k = (N + G2k - 1) / G2k;
-            const int res32 = std::max(1, ctx->num_cus / std::max(G0, 1)), res64 = std::max(1, ctx->num_cus / std::max(G2k, 1));
-            if (cs2k % 2 == 0 && G2k <= 64 && (knob128 == 2 || 8 * ((B + res64 - 1) / res64) < 5 * ((B + res32 - 1) / res32))) {
-                kfn = (full && M % 64 == 0) ? (const void*)sinkhorn_resident2k<true> : (const void*)sinkhorn_resident2k<false>;
-                rows_hr = 64;
+            if (cs2k % 2 == 0 && G2k <= 64) {
+                kbig.fn = (full && M % 64 == 0) ? (const void*)sinkhorn_resident2k<true> : (const void*)sinkhorn_resident2k<false>;
+                kbig.rows = 64;
+                kbig.lds = sizeof(float) * (size_t)(4 * SK2K_RL * 2048 + 2 * 2048 + 2048 + 4 + 32 + 3 * 64);
             }
         }
+        kbig.threads = 256; kbig.big = true;
         static std::map<std::pair<int, const void*>, int> occupancy;  // (device, kernel) -> resident workgroups per CU
         static std::mutex occupancy_mu;
-        if (rows_hr == 128) res_lds = sizeof(float) * (size_t)(4 * SK128_RL * 1024 + 4 * 1024 + 1024 + 4 + 32 + 3 * 128);
-        if (rows_hr == 64) res_lds = sizeof(float) * (size_t)(4 * SK2K_RL * 2048 + 2 * 2048 + 2048 + 4 + 32 + 3 * 64);
-        {
+        for (SkKernel* k : {&kbase, &kbig}) {
+            if (!k->fn) continue;
             std::lock_guard<std::mutex> lk(occupancy_mu);
-            auto it = occupancy.find({ctx->device, kfn});
+            auto it = occupancy.find({ctx->device, k->fn});
             if (it == occupancy.end()) {
                 int nb = 0;
-                if (res_lds > 48 * 1024 && ensure_dynamic_lds(ctx, kfn, res_lds) != E2EMV_OK) {
+                if (k->lds > 48 * 1024 && ensure_dynamic_lds(ctx, k->fn, k->lds) != E2EMV_OK) {
                     (void)hipGetLastError();  // a device with less LDS: the streaming chain below serves the call
                     nb = 0;
-                } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, rows_hr ? 256 : 512, res_lds) != hipSuccess) {
+                } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k->fn, k->threads, k->lds) != hipSuccess) {
                     (void)hipGetLastError();
                     nb = 0;
                 }
-                it = occupancy.emplace(std::make_pair(ctx->device, kfn), std::min(nb, 2)).first;
+                it = occupancy.emplace(std::make_pair(ctx->device, k->fn), std::min(nb, 2)).first;
             }
-            wg_per_cu = it->second;
+            k->wg_per_cu = it->second;
+            const int G = (M + k->rows - 1) / k->rows;
+            if (k->wg_per_cu < 1 || G > k->wg_per_cu * ctx->num_cus) k->fn = nullptr;  // cannot hold a problem's workgroups at once
         }
-        const int rows_wg = rows_hr ? rows_hr : skr_rows(ldS);
-        const int G = (M + rows_wg - 1) / rows_wg;
-        if (wg_per_cu < 1 || G > wg_per_cu * ctx->num_cus) resident = false;
+        if (!kbase.fn) { if (kbig.fn) kbase = kbig; else resident = false; }
     }
     if (resident) {
         if (int rc_f = ensure_flags(ctx)) return rc_f;
-        const ResidentPlan rp = resident_plan(B, M, N, wg_per_cu * ctx->num_cus, rows_hr);
-        SkResParams rpar{};
-        rpar.S = S; rpar.ldS = ldS; rpar.M = M; rpar.N = N; rpar.B = B; rpar.iters = iters;
-        rpar.alpha = alpha; rpar.norm = p.norm;
-        rpar.G = rp.G; rpar.n_res = rp.n_res; rpar.cs = rp.cs;
-        char* gw = w;  // granule buffers follow the streaming path's arrays in the workspace
-        rpar.bufA = (u64*)gw; gw += rp.bytesA;
-        rpar.bufB = (u64*)gw; gw += rp.bytesB;
-        rpar.bufU = (u64*)gw; gw += rp.bytesU;
-        rpar.timeout = ctx->d_flags;
+        int knob = 1;
+        if (const char* e = getenv("E2EMV_SINKHORN")) knob = strcmp(e, "rows64") == 0 ? 0 : (strcmp(e, "rows128") == 0 ? 2 : 1);
+        struct Segment { int b0, n; const SkKernel* k; };
+        Segment seg[2];
+        int n_seg = 0;
+        auto res_of = [&](const SkKernel& k) { return std::max(1, (k.wg_per_cu * ctx->num_cus) / std::max((M + k.rows - 1) / k.rows, 1)); };
+        if (!kbig.fn || !kbase.fn || kbase.big || knob == 0) {
+            seg[n_seg++] = {0, B, &kbase};
+        } else if (knob == 2) {
+            seg[n_seg++] = {0, B, &kbig};
+        } else {
+            const int res_big = res_of(kbig), res_base = res_of(kbase);
+            int n_big = (B / res_big) * res_big;   // every full round of the big kernel (it holds twice the problems at < 2 x the time)
+            const int rem = B - n_big;
+            if (rem > 0 && 8 * ((rem + res_base - 1) / res_base) > 13) n_big = B;  // the remainder too: one round of 1.6 against two or more of 1
+            if (n_big > 0) seg[n_seg++] = {0, n_big, &kbig};
+            if (n_big < B) seg[n_seg++] = {n_big, B - n_big, &kbase};
+        }
         const char* dbg_path = dbg_env("E2EMV_SKR_DEBUG");
-        unsigned long long* d_dbg = nullptr;
-        const size_t dbg_bytes = (size_t)16 * rp.G * 8 * sizeof(unsigned long long);
-        if (dbg_path && hipMalloc((void**)&d_dbg, dbg_bytes) == hipSuccess) (void)hipMemsetAsync(d_dbg, 0, dbg_bytes, s);
-        rpar.dbg = d_dbg;
-        rpar.flags = dbg_knob("E2EMV_SKR_FLAGS", rpar.flags);
-        rpar.u = p.u; rpar.v = p.v; rpar.ldV = p.ldV;
-        // every polled word starts from 0 in every launch (epochs count from 1)
-        E2EMV_HIP(ctx, hipMemsetAsync(w, 0, rp.bytesA + rp.bytesB + rp.bytesU, s));
-        E2EMV_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, 4, s));
-        hipLaunchKernelGGL_ptr(kfn, dim3((unsigned)(rp.n_res * rp.G)), dim3(rows_hr ? 256 : 512), res_lds, s, rpar);
-        if (rows_hr) ++ctx->stat_sinkhorn_rows128;
-        E2EMV_CHECK_LAUNCH(ctx, "sinkhorn_resident");
+        for (int si = 0; si < n_seg; ++si) {
+            const SkKernel& k = *seg[si].k;
+            const int b0 = seg[si].b0, nb = seg[si].n;
+            const ResidentPlan rp = resident_plan(nb, M, N, k.wg_per_cu * ctx->num_cus, k.rows);
+            SkResParams rpar{};
+            rpar.S = S + (int64_t)b0 * M * ldS; rpar.ldS = ldS; rpar.M = M; rpar.N = N; rpar.B = nb; rpar.iters = iters;
+            rpar.alpha = alpha; rpar.norm = p.norm;
+            rpar.G = rp.G; rpar.n_res = rp.n_res; rpar.cs = rp.cs;
+            char* gw = w;  // granule buffers follow the streaming path's arrays in the workspace (segments run one after the other)
+            rpar.bufA = (u64*)gw; gw += rp.bytesA;
+            rpar.bufB = (u64*)gw; gw += rp.bytesB;
+            rpar.bufU = (u64*)gw; gw += rp.bytesU;
+            rpar.timeout = ctx->d_flags;
+            unsigned long long* d_dbg = nullptr;
+            const size_t dbg_bytes = (size_t)16 * rp.G * 8 * sizeof(unsigned long long);
+            if (dbg_path && si == 0 && hipMalloc((void**)&d_dbg, dbg_bytes) == hipSuccess) (void)hipMemsetAsync(d_dbg, 0, dbg_bytes, s);
+            rpar.dbg = d_dbg;
+            rpar.flags = dbg_knob("E2EMV_SKR_FLAGS", rpar.flags);
+            rpar.u = p.u + (int64_t)b0 * (M + 1); rpar.v = p.v + (int64_t)b0 * p.ldV; rpar.ldV = p.ldV;
+            // every polled word starts from 0 in every launch (epochs count from 1)
+            E2EMV_HIP(ctx, hipMemsetAsync(w, 0, rp.bytesA + rp.bytesB + rp.bytesU, s));
+            E2EMV_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, 4, s));
+            hipLaunchKernelGGL_ptr(k.fn, dim3((unsigned)(rp.n_res * rp.G)), dim3(k.threads), k.lds, s, rpar);
+            E2EMV_CHECK_LAUNCH(ctx, "sinkhorn_resident");
+            if (d_dbg) {  // development aid: per-phase timestamps of resident problem 0, appended as text
+                std::vector<unsigned long long> h(dbg_bytes / 8);
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(h.data(), d_dbg, dbg_bytes, hipMemcpyDeviceToHost);
+                (void)hipFree(d_dbg);
+                if (FILE* f = fopen(dbg_path, "a")) {
+                    fprintf(f, "# B=%d M=%d N=%d iters=%d G=%d n_res=%d flags=%d\n", nb, M, N, iters, rp.G, rp.n_res, rpar.flags);
+                    for (int it = 0; it < 16 && it < iters; ++it)
+                        for (int g = 0; g < rp.G; ++g) {
+                            fprintf(f, "%d %d", it, g);
+                            for (int kk = 0; kk < 7; ++kk) fprintf(f, " %llu", h[((size_t)it * rp.G + g) * 8 + kk]);
+                            fprintf(f, "\n");
+                        }
+                    fclose(f);
+                }
+            }
+        }
+        if (seg[0].k->big) ++ctx->stat_sinkhorn_rows128;
         // problems the exponential-domain kernel could not finish are re-solved in the log domain before anything reads u, v
         hipLaunchKernelGGL(sinkhorn_rescue, dim3(B), dim3(1024), sizeof(float) * (size_t)(M + N + 2), s, p, iters, ctx->d_flags);
         E2EMV_CHECK_LAUNCH(ctx, "sinkhorn_rescue");
-        if (d_dbg) {  // development aid: per-phase timestamps of resident problem 0, appended as text
-            std::vector<unsigned long long> h(dbg_bytes / 8);
-            (void)hipStreamSynchronize(s);
-            (void)hipMemcpy(h.data(), d_dbg, dbg_bytes, hipMemcpyDeviceToHost);
-            (void)hipFree(d_dbg);
-            if (FILE* f = fopen(dbg_path, "a")) {
-                fprintf(f, "# B=%d M=%d N=%d iters=%d G=%d n_res=%d flags=%d\n", B, M, N, iters, rp.G, rp.n_res, rpar.flags);
-                for (int it = 0; it < 16 && it < iters; ++it)
-                    for (int g = 0; g < rp.G; ++g) {
-                        fprintf(f, "%d %d", it, g);
-                        for (int k = 0; k < 7; ++k) fprintf(f, " %llu", h[((size_t)it * rp.G + g) * 8 + k]);
-                        fprintf(f, "\n");
-                    }
-                fclose(f);
-            }
-        }
     }
     if (!resident) {
         hipLaunchKernelGGL(sinkhorn_init, dim3(B), dim3(256), 0, s, p, B);

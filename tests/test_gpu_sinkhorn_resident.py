@@ -86,12 +86,13 @@ def test_more_problems_than_resident_capacity_and_batch_independence(gpu):
 @pytest.mark.parametrize("B,M,N,iters,picked", [
     (32, 1024, 1024, 100, True),   # BASELINE configs[1]'s Sinkhorn: one round instead of two
     (64, 1024, 1024, 10, True),    # two rounds instead of four
-    (65, 1024, 1024, 4, False),    # three instead of five do not pay (a round of 128-row workgroups takes 1.6 - 1.75 times as long)
+    (65, 1024, 1024, 4, True),     # two rounds of 128-row workgroups + one problem on 64-row ones (a second launch)
+    (80, 1024, 1024, 3, True),     # BASELINE configs[3]'s Sinkhorn: 64 + 16
     (20, 1024, 1008, 6, True),     # columns short of 1024 (masked chunk tails), 126-column slices
     (18, 1000, 1024, 8, True),     # rows short of 8 x 128: a partial last workgroup
     (24, 900, 1020, 12, True),     # both
     (30, 640, 1020, 9, True),      # 5 workgroups per problem, 204-column slices
-    (52, 640, 1020, 4, False),     # two rounds instead of three do not pay (a round of 128-row workgroups takes 1.6 times as long)
+    (52, 640, 1020, 4, True),      # 51 + 1
     (40, 640, 1024, 9, False),     # 205-column slices are odd (the exchange moves column pairs): the 64-row kernel
     (16, 1024, 1024, 5, False),    # fits one round of 64-row workgroups already: not taken
     # 1025 .. 2048 columns: sinkhorn_resident2k, 64 rows per workgroup (12 of a wave's 16 rows in registers by number)
@@ -100,6 +101,7 @@ def test_more_problems_than_resident_capacity_and_batch_independence(gpu):
     (16, 1536, 1824, 4, True),     # 24 workgroups per problem, 76-column slices
     (16, 1500, 1800, 4, False),    # 75-column slices are odd: the 32-row kernel
     (4, 2048, 2048, 4, False),     # one round either way
+    (12, 2048, 2048, 4, True),     # 8 + 4
 ])
 def test_128_rows_per_workgroup(gpu, B, M, N, iters, picked):
     """sinkhorn_resident128: a workgroup of 4 waves holds 128 rows of K = exp(S - rowmax) - 24 rows per wave in registers it

@@ -114,16 +114,16 @@ def t(s, it=100, reps=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): E.log_optimal_transport(s, 1.0, it)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
-for B, M, N in ((32, 1024, 1024), (80, 1024, 1024), (48, 1024, 1024), (80, 2048, 2048), (16, 2048, 2048), (8, 2048, 2048), (12, 2048, 2048)):
+for B, M, N in ((32, 1024, 1024), (80, 1024, 1024), (48, 1024, 1024), (40, 1024, 1024), (80, 2048, 2048), (12, 2048, 2048), (20, 2048, 2048)):
     s = torch.randn(B, M, N, device="cuda") * 3
     r = []
     for rep in range(2):
-        for mode in ("rows64", "rows128"):
+        for mode in ("rows64", "rows128", None):
             if mode: os.environ["E2EMV_SINKHORN"] = mode
             else: os.environ.pop("E2EMV_SINKHORN", None)
             r.append(t(s))
     os.environ.pop("E2EMV_SINKHORN", None)
-    print(f"{B} x {M} x {N}: rows64 {r[0]:.3f} / {r[2]:.3f} ms   rows128 / 2k {r[1]:.3f} / {r[3]:.3f} ms")
+    print(f"{B} x {M} x {N}: rows64 {r[0]:.3f} / {r[3]:.3f} ms   rows128 / 2k {r[1]:.3f} / {r[4]:.3f} ms   library's plan {r[2]:.3f} / {r[5]:.3f} ms")
 PY
   ;;
 tests)
@@ -151,7 +151,7 @@ final)
   # the Sinkhorn kernels against each other (product library), then their per-phase timestamps (measurement build)
   bash tools/gpu.sh sk128 > /dev/null 2>&1
   timeout 400 python tools/skr_timing.py --rows128 2>&1 | grep -v amdgpu.ids > $OUT/skr_rows128.log
-  { echo "# ms per call of 100 iterations incl. the final sweep, one box, alternating (tools/gpu.sh sk128; rows64 = E2EMV_SINKHORN=rows64: the 64-row"; echo "# (32-row at 2048 columns) workgroups only, rows128 / 2k = the kernels with the couplings in registers addressed by number wherever the shape allows)"; grep " x " $OUT/sk128_time.log; echo; echo "# tests/test_gpu_sinkhorn_resident.py on the same box:"; tail -1 $OUT/sk128_tests.log; echo; echo "# per-phase timestamps (tools/skr_timing.py --rows128, measurement build tools/libe2emv_stamps.bin; workgroup 0's thread 0, iterations 2 - 13):"; cat $OUT/skr_rows128.log; } > $OUT/r5_sinkhorn_rows128.log
+  { echo "# ms per call of 100 iterations incl. the final sweep, one box, alternating (tools/gpu.sh sk128; rows64 = E2EMV_SINKHORN=rows64: the 64-row"; echo "# (32-row at 2048 columns) workgroups only, rows128 / 2k = the kernels with the couplings in registers addressed by number for the whole batch,"; echo "# library's plan = their full rounds + the remainder on whichever is cheaper: what a call gets by default)"; grep " x " $OUT/sk128_time.log; echo; echo "# tests/test_gpu_sinkhorn_resident.py on the same box:"; tail -1 $OUT/sk128_tests.log; echo; echo "# per-phase timestamps (tools/skr_timing.py --rows128, measurement build tools/libe2emv_stamps.bin; workgroup 0's thread 0, iterations 2 - 13):"; cat $OUT/skr_rows128.log; } > $OUT/r5_sinkhorn_rows128.log
   echo "at::native launches: steps 2 / steps 6"; grep "at::native" $OUT/r5_kernel_stats_c2_f16x2.md $OUT/r5_kernel_stats_c2_f16x2_steps6.md
   grep "gemm_p2_chain\|attention_p2w" $OUT/r5_kernel_stats_c2_f16x2.md $OUT/r5_kernel_stats_c2_f16x2_steps6.md
   ;;
