@@ -1180,42 +1180,45 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                         accb += blo[k] + bhi[k];
                     }
                     aM = muM / (wave_sum_dpp(accb[0] + accb[1]) + bN);
+                    // every asm statement of the register rows also fetches ONE LDS row, consumed right behind it (the LDS latency
+                    // hides under the statement's multiply-adds): rows 0 - 2 with the vector-register groups, 3 - 7 with the first five
+                    // pair statements of the accumulation-register groups
+                    float x[SK128_RL];
+                    auto lds_row_sum = [&](const f32x4 (&t)[4], int j) __attribute__((always_inline)) {
+                        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                        for (int k = 0; k < KT; ++k) {
+                            acc = __builtin_elementwise_fma(f32x2{t[k][0], t[k][1]}, blo[k], acc);
+                            acc = __builtin_elementwise_fma(f32x2{t[k][2], t[k][3]}, bhi[k], acc);
+                        }
+                        x[j] = acc[0] + acc[1];
+                        asm volatile("" : "+v"(x[j]));
+                    };
                     sk_static_for<SK128_RR / 4>([&](auto g_c) {
                         constexpr int g = decltype(g_c)::value, r0 = 4 * g;
                         constexpr int B0 = sk128_base(r0), B1 = sk128_base(r0 + 1), B2 = sk128_base(r0 + 2), B3 = sk128_base(r0 + 3);
                         f32x2 acc[4];
+                        f32x4 t[4];
                         if constexpr (r0 < SK128_RV) {
-                            sk128_rs4v<B0, B1, B2, B3>(acc, blo, bhi);
+                            sk128_rs4v_l<B0, B1, B2, B3, g * W * 4>(acc, blo, bhi, t, kl_a);
+                            lds_row_sum(t, g);
                         } else {
-                            sk128_rs2a<B0, B1>(acc[0], acc[1], blo, bhi);
-                            sk128_rs2a<B2, B3>(acc[2], acc[3], blo, bhi);
+                            constexpr int j0 = SK128_RV / 4 + 2 * (g - SK128_RV / 4);  // LDS rows of this group's two pair statements
+                            sk128_rs2a_l<B0, B1, j0 * W * 4>(acc[0], acc[1], blo, bhi, t, kl_a);
+                            lds_row_sum(t, j0);
+                            if constexpr (j0 + 1 < SK128_RL) {
+                                sk128_rs2a_l<B2, B3, (j0 + 1) * W * 4>(acc[2], acc[3], blo, bhi, t, kl_a);
+                                lds_row_sum(t, j0 + 1);
+                            } else {
+                                sk128_rs2a<B2, B3>(acc[2], acc[3], blo, bhi);
+                            }
                         }
                         t4[g] = wave_sum4_quads(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1], acc[2][0] + acc[2][1], acc[3][0] + acc[3][1], lane);
                         asm volatile("" : "+v"(t4[g]));
                     });
-                    // LDS rows one at a time through 16 registers (one asm statement per row: plain loads are all hoisted to the front
-                    // of the pass - 128 registers - and spilled from there)
-                    sk_static_for<SK128_RL / 4>([&](auto g_c) {
-                        constexpr int g = decltype(g_c)::value;
-                        float x[4];
-                        sk_static_for<4>([&](auto j_c) {
-                            constexpr int j = decltype(j_c)::value, r = 4 * g + j;
-                            f32x4 t0, t1, t2, t3;
-                            asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%5+1024\n\t"
-                                         "ds_read_b128 %2, %4 offset:%5+2048\n\tds_read_b128 %3, %4 offset:%5+3072\n\ts_waitcnt lgkmcnt(0)"
-                                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(kl_a), "n"(r * W * 4));
-                            const f32x4 t[KT] = {t0, t1, t2, t3};
-                            f32x2 acc = {0.f, 0.f};
-#pragma unroll
-                            for (int k = 0; k < KT; ++k) {
-                                acc = __builtin_elementwise_fma(f32x2{t[k][0], t[k][1]}, blo[k], acc);
-                                acc = __builtin_elementwise_fma(f32x2{t[k][2], t[k][3]}, bhi[k], acc);
-                            }
-                            x[j] = acc[0] + acc[1];
-                            asm volatile("" : "+v"(x[j]));
-                        });
-                        t4[SK128_RR / 4 + g] = wave_sum4_quads(x[0], x[1], x[2], x[3], lane);
-                    });
+                    static_assert(SK128_RV / 4 + 2 * (SK128_RA / 4) - 1 >= SK128_RL, "an asm statement per LDS row");
+                    t4[SK128_RR / 4] = wave_sum4_quads(x[0], x[1], x[2], x[3], lane);
+                    t4[SK128_RR / 4 + 1] = wave_sum4_quads(x[4], x[5], x[6], x[7], lane);
                 }
                 // (2) a_i of four rows per division; the scalars for phase 3; the dustbin statistic sum_i r_i a_i per lane class
                 float as[RW];
@@ -1497,29 +1500,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                     bhi[k] = f32x2{b4[2], b4[3]};
                     accb += blo[k] + bhi[k];
                 }
-                sk_static_for<SK2K_RV / 2>([&](auto p_c) {
-                    constexpr int r0 = 2 * decltype(p_c)::value;
-                    f32x2 acc[4];
-                    sk_rs2v<sk2k_base(r0, h), sk2k_base(r0 + 1, h)>(acc, blo, bhi);
-                    accp[r0] += (acc[0][0] + acc[0][1]) + (acc[2][0] + acc[2][1]);
-                    accp[r0 + 1] += (acc[1][0] + acc[1][1]) + (acc[3][0] + acc[3][1]);
-                    asm volatile("" : "+v"(accp[r0]), "+v"(accp[r0 + 1]));
-                });
-                sk_static_for<SK2K_RA / 2>([&](auto p_c) {
-                    constexpr int r0 = SK2K_RV + 2 * decltype(p_c)::value;
-                    f32x2 a0, a1;
-                    sk128_rs2a<sk2k_base(r0, h), sk2k_base(r0 + 1, h)>(a0, a1, blo, bhi);
-                    accp[r0] += a0[0] + a0[1];
-                    accp[r0 + 1] += a1[0] + a1[1];
-                    asm volatile("" : "+v"(accp[r0]), "+v"(accp[r0 + 1]));
-                });
-                sk_static_for<SK2K_RL>([&](auto j_c) {
-                    constexpr int j = decltype(j_c)::value;
-                    f32x4 t0, t1, t2, t3;
-                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%5+1024\n\t"
-                                 "ds_read_b128 %2, %4 offset:%5+2048\n\tds_read_b128 %3, %4 offset:%5+3072\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(kl_a), "n"((j * W + 1024 * h) * 4));
-                    const f32x4 t[4] = {t0, t1, t2, t3};
+                // register rows in pairs; the first four pair statements also fetch one LDS row (half) each, consumed right behind them
+                auto lds_row_sum = [&](const f32x4 (&t)[4], int j) __attribute__((always_inline)) {
                     f32x2 acc = {0.f, 0.f};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -1528,6 +1510,30 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                     }
                     accp[SK2K_RR + j] += acc[0] + acc[1];
                     asm volatile("" : "+v"(accp[SK2K_RR + j]));
+                };
+                sk_static_for<SK2K_RV / 2>([&](auto p_c) {
+                    constexpr int pp = decltype(p_c)::value, r0 = 2 * pp;
+                    f32x2 acc[4];
+                    f32x4 t[4];
+                    sk_rs2v_l<sk2k_base(r0, h), sk2k_base(r0 + 1, h), (pp * W + 1024 * h) * 4>(acc, blo, bhi, t, kl_a);
+                    accp[r0] += (acc[0][0] + acc[0][1]) + (acc[2][0] + acc[2][1]);
+                    accp[r0 + 1] += (acc[1][0] + acc[1][1]) + (acc[3][0] + acc[3][1]);
+                    asm volatile("" : "+v"(accp[r0]), "+v"(accp[r0 + 1]));
+                    lds_row_sum(t, pp);
+                });
+                sk_static_for<SK2K_RA / 2>([&](auto p_c) {
+                    constexpr int pp = decltype(p_c)::value, r0 = SK2K_RV + 2 * pp;
+                    f32x2 a0, a1;
+                    if constexpr (SK2K_RV / 2 + pp < SK2K_RL) {
+                        f32x4 t[4];
+                        sk128_rs2a_l<sk2k_base(r0, h), sk2k_base(r0 + 1, h), ((SK2K_RV / 2 + pp) * W + 1024 * h) * 4>(a0, a1, blo, bhi, t, kl_a);
+                        lds_row_sum(t, SK2K_RV / 2 + pp);
+                    } else {
+                        sk128_rs2a<sk2k_base(r0, h), sk2k_base(r0 + 1, h)>(a0, a1, blo, bhi);
+                    }
+                    accp[r0] += a0[0] + a0[1];
+                    accp[r0 + 1] += a1[0] + a1[1];
+                    asm volatile("" : "+v"(accp[r0]), "+v"(accp[r0 + 1]));
                 });
             });
             aM = muM / (wave_sum_dpp(accb[0] + accb[1]) + bN);
@@ -1553,21 +1559,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                 constexpr int h = decltype(h_c)::value;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { cl[h][k] = f32x2{0.f, 0.f}; ch[h][k] = f32x2{0.f, 0.f}; }
-                sk_static_for<SK2K_RV / 2>([&](auto p_c) {
-                    constexpr int r0 = 2 * decltype(p_c)::value;
-                    sk_rc2v<sk2k_base(r0, h), sk2k_base(r0 + 1, h)>(cl[h], ch[h], f32x2{as[r0], as[r0]}, f32x2{as[r0 + 1], as[r0 + 1]});
-                });
-                sk_static_for<SK2K_RA / 2>([&](auto p_c) {
-                    constexpr int r0 = SK2K_RV + 2 * decltype(p_c)::value;
-                    sk_rc2a<sk2k_base(r0, h), sk2k_base(r0 + 1, h)>(cl[h], ch[h], f32x2{as[r0], as[r0]}, f32x2{as[r0 + 1], as[r0 + 1]});
-                });
-                sk_static_for<SK2K_RL>([&](auto j_c) {
-                    constexpr int j = decltype(j_c)::value;
-                    f32x4 t0, t1, t2, t3;
-                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%5+1024\n\t"
-                                 "ds_read_b128 %2, %4 offset:%5+2048\n\tds_read_b128 %3, %4 offset:%5+3072\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(kl_a), "n"((j * W + 1024 * h) * 4));
-                    const f32x4 t[4] = {t0, t1, t2, t3};
+                auto lds_row_cols = [&](const f32x4 (&t)[4], int j) __attribute__((always_inline)) {
                     const f32x2 a2 = {as[SK2K_RR + j], as[SK2K_RR + j]};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -1575,6 +1567,22 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(56))) void s
                         ch[h][k] = __builtin_elementwise_fma(f32x2{t[k][2], t[k][3]}, a2, ch[h][k]);
                     }
                     asm volatile("" : "+v"(cl[h][0]), "+v"(cl[h][1]), "+v"(cl[h][2]), "+v"(cl[h][3]), "+v"(ch[h][0]), "+v"(ch[h][1]), "+v"(ch[h][2]), "+v"(ch[h][3]));
+                };
+                sk_static_for<SK2K_RV / 2>([&](auto p_c) {
+                    constexpr int pp = decltype(p_c)::value, r0 = 2 * pp;
+                    f32x4 t[4];
+                    sk_rc2v_l<sk2k_base(r0, h), sk2k_base(r0 + 1, h), (pp * W + 1024 * h) * 4>(cl[h], ch[h], f32x2{as[r0], as[r0]}, f32x2{as[r0 + 1], as[r0 + 1]}, t, kl_a);
+                    lds_row_cols(t, pp);
+                });
+                sk_static_for<SK2K_RA / 2>([&](auto p_c) {
+                    constexpr int pp = decltype(p_c)::value, r0 = SK2K_RV + 2 * pp;
+                    if constexpr (SK2K_RV / 2 + pp < SK2K_RL) {
+                        f32x4 t[4];
+                        sk_rc2a_l<sk2k_base(r0, h), sk2k_base(r0 + 1, h), ((SK2K_RV / 2 + pp) * W + 1024 * h) * 4>(cl[h], ch[h], f32x2{as[r0], as[r0]}, f32x2{as[r0 + 1], as[r0 + 1]}, t, kl_a);
+                        lds_row_cols(t, SK2K_RV / 2 + pp);
+                    } else {
+                        sk_rc2a<sk2k_base(r0, h), sk2k_base(r0 + 1, h)>(cl[h], ch[h], f32x2{as[r0], as[r0]}, f32x2{as[r0 + 1], as[r0 + 1]});
+                    }
                 });
             });
             // ---- fold of the 4 waves through 16 KB: waves 2, 3 write; waves 0, 1 add theirs and write back
