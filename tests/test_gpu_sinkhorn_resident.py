@@ -159,12 +159,15 @@ def test_matches_from_the_resident_path_equal_the_streaming_chain(gpu):
     assert float((a["matches0_0_1"] >= 0).float().mean()) > 0.5
 
 
-def test_exchange_under_uneven_load(gpu):
+@pytest.mark.parametrize("B,N,iters", [(20, 512, 40), (32, 1024, 25), (40, 1024, 10), (9, 2048, 10)])
+def test_exchange_under_uneven_load(gpu, B, N, iters):
     """Hand-offs must not depend on timing or placement: run the resident kernel while a second stream streams 2 GB
-    copies (its workgroups occupy CUs and the memory queues unevenly), many times, and require the quiet result."""
+    copies (its workgroups occupy CUs and the memory queues unevenly), many times, and require the quiet result.
+    (512 columns: the compiler-allocated kernel; 32 x 1024 / 9 x 2048: the kernels with K in registers addressed by number -
+    their waves must find those registers untouched whatever else runs on the chip; 40 x 1024: two resident launches.)"""
     import e2e_multi_view_matching_amd as E
-    s = _scores(20, 512, 512, 11).to(gpu)
-    quiet = E.log_optimal_transport(s, 1.0, 40)
+    s = _scores(B, N, N, 11).to(gpu)
+    quiet = E.log_optimal_transport(s, 1.0, iters)
     side = torch.cuda.Stream(device=gpu)
     big = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=gpu)
     other = torch.empty_like(big)
@@ -173,7 +176,7 @@ def test_exchange_under_uneven_load(gpu):
             for _ in range(4):
                 other.copy_(big)
                 big.add_(1.0)
-        out = E.log_optimal_transport(s, 1.0, 40)
+        out = E.log_optimal_transport(s, 1.0, iters)
         assert torch.equal(out, quiet), rep
     torch.cuda.synchronize()
 
