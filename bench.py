@@ -535,6 +535,8 @@ def run(args):
     # ---- AUC leg (not timed): identity-like weights give real matches; errors gathered over ranks
     e_deg = wl.auc_errors()
     e_all = gather_pair_errors(e_deg, device=wl.coll_dev)  # the path's only data collective (RCCL over xGMI), B*P floats per rank
+    from e2e_multi_view_matching_amd import distributed as _dist_mod
+    metric_collective = _dist_mod.last_collective if world > 1 else "none (one rank)"
     auc = [100.0 * a for a in pose_auc(e_all, [5, 10, 20])]
 
     if rank != 0:
@@ -554,7 +556,7 @@ def run(args):
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": workload_string(args, world), "pairs_per_gpu": B * P, "global_pairs": pairs_per_step,
                    "weights": "random init (timed), identity-like for the AUC leg", "parallelism": f"tuple-sharded x{world}"},
-        "auc_5_10_20": [round(a, 3) for a in auc], "auc_pairs": int(len(e_all)),
+        "auc_5_10_20": [round(a, 3) for a in auc], "auc_pairs": int(len(e_all)), "metric_collective": metric_collective,
     }
     if hasattr(wl, "ctx"):
         st = wl.ctx.stats()
@@ -623,14 +625,28 @@ def run(args):
         # compulsory HBM bytes of the family per step (activations are 4 bytes per element in every mode: fp32, or a pair of
         # fp16 planes; the weights stay in L2): the floor the operand / result stream sets next to the matrix-core ceiling
         Mt, L = B * T * N, len(args.layers)
-        hbm = {"gemm": L * Mt * D * 4 * (1 + 3 + 2 + 2 + 2 + 1 + 1), "attention": L * Mt * D * 4 * (3 + 1)}[fam]
+        chained = bool(parts.get("gemm_chain"))
+        # One [rows x 256] activation = U bytes.  A launch per GEMM moves q|k|v 1 + 3, MLP0 2 + 2, MLP1 2 + 1 + 1 = 12 U per layer.  A
+        # CHAINED launch (MLP0 -> MLP1 -> the next layer's q|k|v inside one workgroup) has its own compulsory traffic: read [x | message]
+        # 2 U, write x_new 1 U, write q|k|v 3 U = 6 U (the hidden layer and the re-read of x_new are NOT compulsory: whatever of them
+        # reaches HBM shows up in `traffic` / `traffic_ratio`); the last layer's chain ends in final_proj: 2 + 1 + 1 = 4 U; the first
+        # q|k|v is a launch of its own: 4 U.
+        gemm_units = (4 + (L - 1) * 6 + 4) if chained else L * 12
+        hbm = {"gemm": Mt * D * 4 * gemm_units, "attention": L * Mt * D * 4 * (3 + 1)}[fam]
         floor_ms = hbm / (PEAK_HBM_GBS * 1e9) * 1e3
-        # Which roof binds: the layer GEMMs of the split-operand modes sit BELOW the ridge (f16x2: 84 flop per compulsory byte
-        # against 833 TFLOP/s / 6.3 TB/s = 132) - their bound is HBM, and the matrix-core fraction rides along as `mfma`;
-        # attention (and the fp32-MFMA GEMMs, 16x slower matrix pipe) are matrix-core bound.
-        hbm_bound = fam == "gemm" and mode_ != "f32"
+        # Which roof binds: a launch per GEMM in the split-operand modes sits BELOW the ridge (f16x2: 84 flop per compulsory byte
+        # against 833 TFLOP/s / 6.3 TB/s = 132) - HBM-bound, the matrix-core fraction rides along as `mfma`.  Chained, the same flops
+        # stand against half the bytes (≈190 flop / B): ABOVE the ridge, the bound is the matrix pipe.  Attention (and
+        # the fp32-MFMA GEMMs, 16x slower matrix pipe) are matrix-core bound.
+        hbm_bound = fam == "gemm" and mode_ != "f32" and not chained
         gbs = hbm / (ms / args.steps * 1e-3) / 1e9
-        common = {"kernel": kname, "mode": mode_, "traffic": traffic, "traffic_source": traffic_src}
+        # algorithmic (compulsory) bytes of ONE launch of the named kernel, the figure `traffic` is to be read against
+        alg_launch = {"gemm": Mt * D * 4 * (6 if chained else 4), "attention": Mt * D * 4 * 4}[fam]
+        common = {"kernel": kname, "mode": mode_, "traffic": traffic, "traffic_source": traffic_src,
+                  "algorithmic_bytes_per_launch": int(alg_launch),
+                  "traffic_ratio": (round(traffic / alg_launch, 3) if traffic else None),
+                  "clock": "HIP events on the launch stream inside the timed steps (the rocprofv3 kernel trace of the same command, "
+                           "profiles/r6_kernel_stats_*.md, reads 4 - 6 % longer per launch: it serialises the launches)"}
         if hbm_bound:
             main = dict(common, bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
                         frac_of_achievable=round(gbs / 6290.0, 4),
@@ -641,7 +657,8 @@ def run(args):
                 "limiter": ("compulsory HBM bytes of the family (activations in and out once, weights from L2) / HIP-event time against the 8 TB/s "
                             "spec peak (6.29 TB/s measured copy rate: frac_of_achievable); a launch is 1 - 3 output tiles per workgroup, so the "
                             "operand stream and the epilogue store burst alternate instead of overlapping (DESIGN.md 4d)") if hbm_bound else
-                           ("the matrix-core ceiling is the stated peak; see DESIGN.md 4d / 4f for what the kernel spends beside it"),
+                           ("the matrix-core ceiling is the stated peak (f16x2: 2500 / 3 products); see DESIGN.md 4d / 4f / 4g / 4i for what the kernel "
+                            "spends beside it (K step above its MFMA floor, epilogues with the matrix pipe idle)"),
                 "hbm_floor": {"bytes_per_step": int(hbm), "bytes_per_launch": int(hbm // max(n // args.steps, 1)),
                               "ms_per_step_at_peak_hbm": round(floor_ms, 3), "peak_gbs": PEAK_HBM_GBS,
                               "frac_of_family_time": round(floor_ms / (ms / args.steps), 4),
@@ -663,7 +680,7 @@ def run(args):
             # per launch: (compulsory bytes, algorithmic flops); the chain of the last layer ends in final_proj instead of q | k | v
             spec = {"gemm_qkv": ("gemm_p2_kernel<QKV>", 4 * U, 3 * fl_row), "gemm_mlp0": ("gemm_p2_kernel<PLANES>", 4 * U, 4 * fl_row),
                     "gemm_mlp1": ("gemm_p2_kernel<PLANES, residual>", 4 * U, 2 * fl_row),
-                    "gemm_chain": ("gemm_p2_chain_kernel (MLP0 -> MLP1 -> next q|k|v)", ((L - 1) * 12 + 8 + 2) * U / L, ((L - 1) * 9 + 6 + 1) * fl_row / L)}
+                    "gemm_chain": ("gemm_p2_chain_kernel (MLP0 -> MLP1 -> next q|k|v)", ((L - 1) * 6 + 4) * U / L, ((L - 1) * 9 + 6 + 1) * fl_row / L)}
             per = []
             for k, v in parts.items():
                 nm, by, fp = spec[k]
@@ -681,7 +698,8 @@ def run(args):
             main["per_kernel"] = per
             main["per_kernel_note"] = ("HIP events around each kernel instantiation's launches in the timed steps (the interval of a launch ends where "
                                        "the next family's begins: dispatch gaps included); bytes = compulsory activation traffic of the launch, flops = "
-                                       "algorithmic; a chained launch is priced with the bytes of the three launches it replaces")
+                                       "algorithmic; a chained launch is priced at its OWN compulsory 6 U (read [x | message] 2, write x_new 1, "
+                                       "write q|k|v 3; last layer 4 U) - 192 flop / B, above the 132 ridge: its roof is frac_mfma; us_per_launch = HIP events")
         return main, second, fams
 
     if prof:
@@ -694,27 +712,11 @@ def run(args):
             # profiles/README.md), not a byte rate; the arithmetic (one packed FMA per element per half-iteration) is the rest.
             ms_call = sk["ms"] / args.steps
             problems = B * P
-            rows_wg = 64 if 512 < N <= 1024 else 32                      # rows of a problem per workgroup (sinkhorn.hip: skr_rows)
-            wg_per_cu = 1 if (rows_wg == 64 or N > 1024) else 2
-            res_base = max(1, (wg_per_cu * 256) // max((N + rows_wg - 1) // rows_wg, 1))
-            # the launcher's plan (sinkhorn.hip, launch_sinkhorn): the kernels with the couplings in registers addressed by number
-            # (sinkhorn_resident128 / sinkhorn_resident2k: twice the rows per workgroup, twice the problems resident) take their full
-            # rounds, the remainder goes to the compiler-allocated kernel unless that needs two rounds or more
-            big = 128 if 512 < N <= 1024 else (64 if 1024 < N <= 2048 else 0)
-            segments = []  # (rows per workgroup, resident problems, rounds)
-            n_big = 0
-            if big:
-                g_big = (N + big - 1) // big
-                res_big = max(1, 256 // g_big)
-                if ((N + g_big - 1) // g_big) % 2 == 0:
-                    n_big = (problems // res_big) * res_big
-                    rem = problems - n_big
-                    if rem > 0 and 8 * -(-rem // res_base) > 13:
-                        n_big = problems
-                    if n_big:
-                        segments.append((big, min(n_big, res_big), -(-n_big // res_big)))
-            if n_big < problems:
-                segments.append((rows_wg, min(problems - n_big, res_base), -(-(problems - n_big) // res_base)))
+            # the launcher's own plan for this batch (e2emv_sinkhorn_plan: what launch_sinkhorn runs on this context and device -
+            # kernel kinds, residency, rounds; nothing re-derived here)
+            segments = [(sg["rows_per_workgroup"], sg["resident_problems"], sg["rounds"]) for sg in wl.ctx.sinkhorn_plan(problems, N, N, args.sinkhorn_iters)]
+            if not segments:  # the log-domain chain (iters == 0 / a demoted context): one "round" per call, no resident exchange
+                segments = [(0, problems, 1)]
             rounds = sum(sg[2] for sg in segments)
             resident = max(sg[1] for sg in segments)
             hop_us = 0.8  # an idle one-to-one granule hand-off on this chip (MI355X_MICROARCH.md price list): the physical floor of a hop
@@ -747,8 +749,6 @@ def run(args):
                                        "frac": r["frac"], "second": alt["roofline_second"]}
     if mode == "f32":
         out["value_f32"], out["ms_per_step_f32"] = out["value"], out["ms_per_step"]
-    out["torch_ops_in_step"] = ("none: the timed step launches only libe2emv kernels (rocprofv3 kernel traces of this command at two step "
-                                "counts hold the same number of at::native launches - they belong to the set-up; profiles/README.md)")
 
     # ---- CPU baseline: the oracle (torch CPU, same unfused op sequence as the reference) on a bounded sample
     if world == 1 and args.cpu_pairs > 0 and not stub:

@@ -123,6 +123,15 @@ SIGNATURES = {
     "e2emv_w8pt_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_pose_errors_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e2emv_get_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_uint64), c_int, c_int]),
+    "e2emv_set_sinkhorn_kernel": (c_int, [c_void_p, c_int]),
+    "e2emv_sinkhorn_plan": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), c_int]),
+    "e2emv_comm_unique_id": (c_int, [c_void_p, c_void_p]),
+    "e2emv_comm_init": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "e2emv_comm_init_file": (c_int, [c_void_p, c_char_p, c_int, c_int, ctypes.c_double, ctypes.POINTER(c_void_p)]),
+    "e2emv_comm_destroy": (c_int, [c_void_p, c_void_p]),
+    "e2emv_comm_rank": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "e2emv_metric_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "e2emv_metric_allreduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "e2emv_profile": (c_int, [c_void_p, c_int]),
     "e2emv_profile_read": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int64), c_int, c_int]),
     "e2emv_profile_name": (c_char_p, [c_int]),
@@ -194,7 +203,9 @@ class Context:
         self.train_owner = None       # (module, fingerprint) whose weights e2emv_train_commit folded last
         self.train_generation = 0     # bumped by every forward_train: the context keeps the tape of the LAST one only
         self.default_precision = self.precision()  # E2EMV_PRECISION at creation time (else f32)
-        self.f16x2_kernels = {"r2": 2, "r3": 3, "r4": 4}.get(os.environ.get("E2EMV_F16X2_KERNELS"), 5)
+        # (r2 / r3: superseded generations, selectable in a measurement build only - E2EMV_LIBRARY=tools/libe2emv_stamps.bin)
+        gens = {"r2": 2, "r3": 3, "r4": 4} if os.environ.get("E2EMV_LIBRARY") else {"r4": 4}
+        self.f16x2_kernels = gens.get(os.environ.get("E2EMV_F16X2_KERNELS"), 5)
         self.default_f16x2_kernels = self._env_f16x2_kernels = self.f16x2_kernels
         self.forced_precision = None               # set_precision(): explicit process-wide override for models with
         #                                            config["mfma_precision"] = None
@@ -237,6 +248,22 @@ class Context:
                 "sinkhorn_timeouts": int(v[4]),  # (of the rescued: given up on a wait - contention -, not on range)
                 "sinkhorn_rows128_calls": int(v[5])}  # (Sinkhorn calls on 128-row workgroups: fewer rounds for a large batch)
 
+    SINKHORN_KERNELS = {None: 0, "auto": 0, "rows64": 1, "rows128": 2, "stream": 3}
+
+    def set_sinkhorn_kernel(self, kernel=None):
+        """Pins the Sinkhorn kernel of every later call on this context: None / "auto" = by shape and batch size (default),
+        "rows64" / "rows128" = one resident kernel kind (a problem's result is then independent of its batch neighbours, bit
+        for bit), "stream" = the log-domain launch chain.  The E2EMV_SINKHORN variable only sets the value a context starts with."""
+        self.call("e2emv_set_sinkhorn_kernel", self.SINKHORN_KERNELS[kernel])
+        self.sinkhorn_kernel_pin = self.SINKHORN_KERNELS[kernel]
+
+    def sinkhorn_plan(self, B, M, N, iters):
+        """What the launcher would run for this batch now: [] = the log-domain chain, else one dict per resident launch."""
+        v = (c_int * 9)()
+        self.call("e2emv_sinkhorn_plan", int(B), int(M), int(N), int(iters), v, 9)
+        return [{"rows_per_workgroup": int(v[1 + 4 * i]), "problems": int(v[2 + 4 * i]), "resident_problems": int(v[3 + 4 * i]),
+                 "rounds": int(v[4 + 4 * i])} for i in range(int(v[0]))]
+
     def set_split_min_rows(self, min_rows=-1):
         """Calls with fewer keypoint rows than this run the fp32-MFMA kernels even in a split-operand mode
         (-1 = library default, 0 = never)."""
@@ -249,6 +276,7 @@ class Context:
         self.forced_precision = other.forced_precision
         self.default_precision = other.default_precision
         self.default_f16x2_kernels = other.default_f16x2_kernels
+        self.call("e2emv_set_sinkhorn_kernel", getattr(other, "sinkhorn_kernel_pin", 0))
         want = getattr(other, "split_min_rows", -1)
         if getattr(self, "split_min_rows", -1) != want:
             self.set_split_min_rows(want)

@@ -12,7 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libe2emv.so")
 SOURCES = ["ctx.hip", "gemm.hip", "attention.hip", "gemm3.hip", "gemm_x3.hip", "gemm_h2.hip", "gemm_p2.hip", "gemm_p2c.hip", "attention_p2.hip", "attention_p2w.hip", "p2_tools.hip", "attention3.hip", "split3_api.hip", "sinkhorn.hip", "pose.hip", "ba2view.hip", "gtmatch.hip",
-           "mvinit.hip", "mvba.hip", "superpoint.hip", "forward.hip", "train.hip"]
+           "mvinit.hip", "mvba.hip", "superpoint.hip", "forward.hip", "train.hip", "comm.hip"]
+# (superseded kernels are compiled under #ifdef E2EMV_STAMPS inside their files: gemm3.hip's all-planes GEMM, generations 2 / 3 of the
+# f16x2 selection - A/B arms of the measurement build, not in the product)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-ffp-contract=fast", "-Wno-unused-result"]
 
 
@@ -52,8 +54,12 @@ def check_register_window(asm_file, kernel, window):
     n = 0
     for m in re.finditer(r"^(_Z\w*%s\w*):" % kernel, txt, re.M):
         end = txt.index(".end_amdhsa_kernel", m.end())
-        body, desc = txt[m.end():end], txt[end - 4000:end]
-        if "amdhsa_next_free_vgpr 512" not in desc or "amdhsa_accum_offset 256" not in desc:
+        # the kernel descriptor: from its .amdhsa_kernel header (whatever its length) to .end_amdhsa_kernel
+        dstart = txt.rfind(".amdhsa_kernel " + m.group(1), m.end(), end)
+        if dstart < 0:
+            raise RuntimeError(f"{m.group(1)}: no .amdhsa_kernel header in front of .end_amdhsa_kernel")
+        body, desc = txt[m.end():dstart], txt[dstart:end]
+        if not re.search(r"\.amdhsa_next_free_vgpr\s+512\b", desc) or not re.search(r"\.amdhsa_accum_offset\s+256\b", desc):
             raise RuntimeError(f"{m.group(1)}: the wave is not allocated 256 + 256 registers")
         inasm = False
         for line in body.split("\n"):
@@ -74,16 +80,25 @@ def check_register_window(asm_file, kernel, window):
 
 def _build(hipcc, objdir, lib, extra, verbose):
     os.makedirs(objdir, exist_ok=True)
+    # gemm_p2c.hip hands tiles from one wave to another of the SAME workgroup through the CU's vector L1 (stores retired + barrier):
+    # threadgroup-split mode would put those waves on different CUs / L1s
+    if any("tgsplit" in f for f in FLAGS + list(extra)):
+        raise RuntimeError("libe2emv is built for CU mode: -mtgsplit breaks the in-workgroup hand-off of gemm_p2c.hip")
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
-        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    # sinkhorn_resident128 keeps most of its data in registers it addresses by number, outside the window its
-    # amdgpu_num_vgpr attribute leaves to the compiler: the device assembly is checked for that (check_register_window)
-    asm_file = os.path.join(objdir, "sinkhorn.s")
-    asm_proc = subprocess.Popen([hipcc] + FLAGS + extra + ["--cuda-device-only", "-S", os.path.join(CSRC, "sinkhorn.hip"), "-o", asm_file],
-                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        cwd = None
+        if src == "sinkhorn.hip":
+            # sinkhorn_resident128 / sinkhorn_resident2k keep most of their data in registers they address by number, outside the
+            # window their amdgpu_num_vgpr attribute leaves to the compiler.  The device assembly hipcc ASSEMBLES into this very
+            # object is kept (-save-temps: one compile, its own intermediate .s - not a second -S compile that could diverge) and
+            # checked below (check_register_window)
+            cwd = os.path.join(objdir, "sinkhorn_temps")
+            os.makedirs(cwd, exist_ok=True)
+            cmd.insert(1, "-save-temps=obj")
+            cmd[-1] = os.path.join(cwd, "sinkhorn.o")
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=cwd)))
     objs = []
     for src, obj, p in procs:
         out, _ = p.communicate()
@@ -92,9 +107,11 @@ def _build(hipcc, objdir, lib, extra, verbose):
         if verbose and out.strip():
             print(out)
         objs.append(obj)
-    out, _ = asm_proc.communicate()
-    if asm_proc.returncode != 0:
-        raise RuntimeError(f"hipcc -S failed on sinkhorn.hip:\n{out}")
+    import shutil
+    temps = os.path.join(objdir, "sinkhorn_temps")
+    shutil.copyfile(os.path.join(temps, "sinkhorn.o"), os.path.join(objdir, "sinkhorn.o"))  # the object that is linked
+    asm_file = os.path.join(objdir, "sinkhorn.s")
+    shutil.copyfile(os.path.join(temps, "sinkhorn-hip-amdgcn-amd-amdhsa-gfx950.s"), asm_file)  # the assembly it was made from
     check_register_window(asm_file, "sinkhorn_resident128", 56)
     check_register_window(asm_file, "sinkhorn_resident2k", 56)
     # the dynamic symbol table is the C ABI of include/e2emv.h and nothing else (hipcc gives kernel host stubs default

@@ -142,6 +142,7 @@ struct e2emv_ctx {
     int sk_stream_calls = 0;         // calls served by the chain since the demotion (16 -> the resident kernel is tried again)
     uint64_t stat_sinkhorn_timeouts = 0;
     uint64_t stat_sinkhorn_rows128 = 0;  // calls served by sinkhorn_resident128 (128 rows per workgroup)
+    int sinkhorn_kernel = 0;         // E2EMV_SINKHORN_* pin (e2emv_set_sinkhorn_kernel; initial value from the E2EMV_SINKHORN variable, read once at e2emv_create)
     bool sinkhorn_stream = false;    // set by the first such report: later calls run the log-domain launch chain
     char* d_dummy = nullptr;  // 4 KB scratch line: target of masked-out stores of kernels that must issue a fixed number of stores (gemm_p2.hip)
     // workspace arena

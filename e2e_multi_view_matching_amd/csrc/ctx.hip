@@ -169,10 +169,19 @@ int e2emv_create(e2emv_ctx** out, int device) {
     ctx->num_cus = p.multiProcessorCount;
     if (dbg_knob("E2EMV_NO_FUSE_MERGE", 0) == 1) ctx->fuse_merge = false;
     if (dbg_knob("E2EMV_B3_PLANES", 0) == 1) ctx->b3_planes = true;
-    if (const char* e = getenv("E2EMV_F16X2_KERNELS")) {  // earlier kernel generations of the f16x2 mode (A/B measurements)
+    if (const char* e = getenv("E2EMV_F16X2_KERNELS")) {  // r4: a launch per GEMM (the chain's A/B arm and the T = 5 path)
+#ifdef E2EMV_STAMPS
+        // the superseded generations are arms of the measurement build only (round 6: the product selects 5, 105 or 4)
         ctx->h2_legacy = strcmp(e, "r2") == 0;
         ctx->attn_wide = strcmp(e, "r3") != 0 && !ctx->h2_legacy;
-        if (strcmp(e, "r2") == 0 || strcmp(e, "r3") == 0 || strcmp(e, "r4") == 0) ctx->gemm_chain = 0;
+        if (strcmp(e, "r2") == 0 || strcmp(e, "r3") == 0) ctx->gemm_chain = 0;
+#endif
+        if (strcmp(e, "r4") == 0) ctx->gemm_chain = 0;
+    }
+
+    if (const char* e = getenv("E2EMV_SINKHORN")) {  // the Sinkhorn kernel pin (e2emv_set_sinkhorn_kernel): read here, once
+        ctx->sinkhorn_kernel = strcmp(e, "rows64") == 0 ? E2EMV_SINKHORN_ROWS64 : strcmp(e, "rows128") == 0 ? E2EMV_SINKHORN_ROWS128
+                               : strcmp(e, "stream") == 0 ? E2EMV_SINKHORN_STREAM : E2EMV_SINKHORN_AUTO;
     }
 
     // default arithmetic of the dense GNN contractions: the split-operand fp16 x 2 path (22-bit operands, fp32 accumulate;
@@ -651,6 +660,11 @@ int e2emv_set_f16x2_kernels(e2emv_ctx* ctx, int generation) {
     const bool always = generation == 105;  // generation 5 with the GEMM chain on every shape that allows it (tests, A/B runs)
     if (always) generation = 5;
     if (generation < 2 || generation > 5) return set_err(ctx, E2EMV_EINVAL, "f16x2 kernel generation %d (2 .. 5)", generation);
+#ifndef E2EMV_STAMPS
+    if (generation < 4)
+        return set_err(ctx, E2EMV_EINVAL, "f16x2 kernel generations 2 and 3 are A/B arms of the measurement build (tools/p2_stamps.py --build); this "
+                                          "library selects 5 (default), 105 or 4");
+#endif
     ctx->h2_legacy = generation == 2;
     ctx->attn_wide = generation >= 4;
     ctx->gemm_chain = generation >= 5 ? (always ? 2 : 1) : 0;

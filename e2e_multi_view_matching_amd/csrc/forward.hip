@@ -325,14 +325,20 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
                     GemmP2Args& q = st[2];
                     q.M = (int)Mtot; q.N = D; q.K = D; q.K1 = D; q.A = xp; q.lda = D; q.W = ctx->wp_final; q.out_scale = ctx->hs_final; q.bias = ctx->b_final;
                     q.out = P2_OUT_F32; q.C32 = att; q.ldc = D; q.EA = e_x; q.bias_amax = ctx->ba_final;  // (att = mdesc below)
-                    final_done = true;
                 }
                 // MLP1's K steps 8 .. 15 read the hidden columns MLP0's SECOND tile stores right in front of it; q | k | v and
                 // final_proj read x_new from their first K step on
                 const int dep[3] = {P2_CHAIN_INDEP, (2 * D - 256) / 32, 0};
                 prof_begin(ctx, PS_GEMM_CHAIN, s); rc = launch_gemm_p2_chain(ctx, st, dep, 3, s); prof_end(ctx, s);
-                if (rc) return rc;
-                continue;
+                if (rc == E2EMV_OK) {
+                    if (last) final_done = true;
+                    continue;
+                }
+                // the chain launcher validates before it launches: a shape it does not take (ESHAPE / EINVAL) leaves nothing enqueued -
+                // this layer and the rest run a launch per GEMM (the next layer then makes its own q | k | v: `!chain` above)
+                if (rc != E2EMV_ESHAPE && rc != E2EMV_EINVAL) return rc;
+                chain = false;
+                ctx->err.clear();
             }
             prof_begin(ctx, PS_GEMM_MLP0, s); rc = launch_gemm_p2(ctx, m0, s); prof_end(ctx, s);
             if (rc) return rc;
@@ -487,12 +493,10 @@ static int forward_joint(e2emv_ctx* ctx, const e2emv_forward_desc* fd, const flo
             float* chid = hid;              // [B][n_rows][D]
             if (use_mlp && p2 && ctx->wp_conf0) {
                 // plane kernels: [mdesc_i | mdesc_j(match)] -> planes with tile exponents -> conf_mlp.0 (+ BN, ReLU) on gemm_p2
+                // (one pass: the gather is resolved in the source address of the plane conversion - p2_tools.hip)
                 prof_begin(ctx, PS_CONF, s);
-                hipLaunchKernelGGL(conf_gather2_kernel, dim3((n_rows + 3) / 4, B), dim3(256), 0, s, Ni, n_rows, D, mdesc + (int64_t)i * n_rows * D,
-                                   mdesc + (int64_t)j * n_rows * D, tuple_stride, pm0[pidx], gathered);
-                prof_end(ctx, s);
-                prof_begin(ctx, PS_INGEST, s);
-                rc = launch_to_planes(ctx, gathered, (int64_t)B * n_rows, 2 * D, 2 * D, qkp, s, e_hid, nullptr);
+                rc = launch_conf_gather_planes(ctx, mdesc + (int64_t)i * n_rows * D, mdesc + (int64_t)j * n_rows * D, tuple_stride, pm0[pidx], Ni, n_rows, B, D, qkp,
+                                               e_hid, s);
                 prof_end(ctx, s);
                 if (rc) return rc;
                 GemmP2Args q;

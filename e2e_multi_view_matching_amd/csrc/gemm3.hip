@@ -25,6 +25,15 @@
 #include "common.h"
 
 namespace e2emv {
+__device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
+    a = (__bf16)v;
+    const float r1 = v - (float)a;
+    b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    c = (__bf16)r2;
+}
+
+#ifdef E2EMV_STAMPS  // round 6: the all-planes kernel is an A/B arm of the measurement build; the product keeps the plane splitter below
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -54,13 +63,6 @@ struct Gemm3Params {
     int n_rows;          // rows per image (Vt addressing)
 };
 
-__device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
-    a = (__bf16)v;
-    const float r1 = v - (float)a;
-    b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
-    c = (__bf16)r2;
-}
 
 // 512 threads = 8 waves as 2 (rows) x 4 (columns): each wave owns a 64 x 32 output block (two 32x32
 // MFMA tiles sharing one weight fragment).  Halving the per-wave tile halves accumulators AND staging
@@ -274,6 +276,7 @@ int launch_gemm3(e2emv_ctx* ctx, const Gemm3Args& a, hipStream_t s) {
     return E2EMV_OK;
 }
 
+#endif  // E2EMV_STAMPS
 // fp32 [rows][C] -> S3 [rows][3][ld] (test / ingest helper; producers normally emit S3 in their epilogue)
 __global__ void split3_rows_kernel(const float* src, int64_t rows, int C, int64_t lds_, uint16_t* dst, int64_t ld) {
     const int64_t r = blockIdx.x;

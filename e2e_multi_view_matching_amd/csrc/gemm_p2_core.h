@@ -144,13 +144,20 @@ __device__ __forceinline__ void gp_split8(const p2_f32x4& a0, const p2_f32x4& a1
 // placement: multiplies -> the MFMA that reads them: one MFMA and two ds_reads apart.
 // (acc[j][i]: weight row block j of the wave's 128 output columns x activation row block i of its 64 rows; wr / wc = the wave's
 // row / column position in the 4 x 2 wave grid, l31 / lh = lane & 31 / lane >> 5)
-template <bool first_step>
+// KDBG (measurement builds only): 1 = the fragment reads and multiplies without the MFMAs
+template <bool first_step, int KDBG = 0>
 __device__ __forceinline__ void gp_kstep(const char* smem, int buf, int wr, int wc, int l31, int lh, p2_f32x16 (&acc)[4][2]) {
     const int swz = (l31 >> 1) & 7;
     const char* xs = smem + buf * P2_BUFB + (wr * 64 + l31) * P2_ROWB;
     const char* ws = smem + buf * P2_BUFB + P2_TILEB + (wc * 128 + l31) * P2_ROWB;
     auto rd_x = [&](int ks, int t, int pl) { return *reinterpret_cast<const p2_f16x8*>(xs + t * 32 * P2_ROWB + (((4 * pl + 2 * ks + lh) ^ swz) << 4)); };
     auto rd_w = [&](int ks, int j, int pl) { return *reinterpret_cast<const p2_f16x8*>(ws + j * 32 * P2_ROWB + (((4 * pl + 2 * ks + lh) ^ swz) << 4)); };
+    auto gp_mfma = [](p2_f32x16& c, p2_f16x8 a, p2_f16x8 b) {
+        if constexpr (KDBG & 1) asm volatile("" :: "v"(a), "v"(b)); else e2emv::gp_mfma(c, a, b);
+    };
+    auto gp_mfma0 = [](p2_f32x16& c, p2_f16x8 a, p2_f16x8 b) {
+        if constexpr (KDBG & 1) asm volatile("" :: "v"(a), "v"(b)); else e2emv::gp_mfma0(c, a, b);
+    };
     p2_f16x8 xb[2][2][2];  // [k-half parity][row block][plane]
     p2_f16x8 wb[2][2];     // [group parity][plane]
     unsigned k2048 = 0x10001000u;  // two fp16 2^-11
@@ -344,6 +351,8 @@ __device__ __forceinline__ void gp_epilogue(const GemmP2Params& p, char* smem, c
                     const int dim = (wc * 2 + (j >> 1)) * 64 + (j & 1) * 32 + 16 * pass;  // (+ dl0: in vt_lane)
                     uint16_t* dst = vt_lane + off_i + dim * row2;
                     if (m0 >= p.M || tn * P2_BN + wc * 128 + j * 32 + dl >= p.N) dst = reinterpret_cast<uint16_t*>(dummy);
+                    if (DBG & 64) { asm volatile("" :: "v"(hi), "v"(lo), "v"(dst)); continue; }          // measurement: no stores
+                    if (DBG & 128) dst = p.Vt + ((dst - p.Vt) & ((1 << 19) - 1) & ~63ll);                 // measurement: 1 MB target
                     *reinterpret_cast<p2_u32x4*>(dst) = hi;
                     *reinterpret_cast<p2_u32x4*>(dst + 32) = lo;
                 }
@@ -396,7 +405,8 @@ __device__ __forceinline__ void gp_epilogue(const GemmP2Params& p, char* smem, c
             rv[b & 1][pass][0] = *reinterpret_cast<const p2_f32x4*>(sl + r * 128 + ((c0 ^ o_z) << 4));
             rv[b & 1][pass][1] = *reinterpret_cast<const p2_f32x4*>(sl + r * 128 + (((c0 + 1) ^ o_z) << 4));
             if constexpr (HAS_R) {
-                const int m = min(row0 + i * 32 + 16 * pass, p.M - 1);
+                int m = min(row0 + i * 32 + 16 * pass, p.M - 1);
+                if (DBG & 8192) m &= 255;  // measurement: the residual from an L2-resident slab
                 const uint16_t* rp = rcol + (int64_t)m * (2 * p.ldr);
                 rr[b & 1][pass][0] = *reinterpret_cast<const p2_u32x4*>(rp);
                 rr[b & 1][pass][1] = *reinterpret_cast<const p2_u32x4*>(rp + 32);

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
         rev_l = (DBG & 2048) && (tn & 1);
         lda_l = q.lda_b;
         ldw_l = q.ldw_b;
-        a_base = ((unsigned)tm * P2_BM + 32u * wave) * lda_l;
+        a_base = (((DBG & 4096) ? 0u : (unsigned)tm * P2_BM) + 32u * wave) * lda_l;  // (4096: every workgroup reads row block 0)
         w_base = ((unsigned)tn * P2_BN + 32u * wave) * ldw_l;
     };
     // (ld_r | c16 << 8) of a lane: its row among the 8 of a load and its swizzled 16-byte chunk - two VGPRs' worth of lane
@@ -206,13 +206,14 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
         if (since == 0 && ahead) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
         else if (since <= 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (DBG & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (measurement: the K loop without its per-step barrier - races, time only)
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (DBG & 16) t1 = __builtin_amdgcn_s_memtime();
         if (has_e && (cur_kt & 1) == 0) {  // a new K block
             // (everything that runs once per tile is marked unlikely: the K step's own path from the barrier to its first MFMA is
             // matrix-pipe idle time, and a cold block hipcc leaves inside it costs a taken branch + an instruction fetch)
             if (__builtin_expect(soft && cur_kt == 4, 0)) {
-                asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_dcache_inv\n\tbuffer_inv sc0\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // (vector L1 as at the hard hand-off)
                 ew = fetch_ew(f, false, true, ew);
             }
             const int e_step = e_of(ew, cur_kt >> 1);
@@ -246,10 +247,11 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
         }
         ++cur_kt;
         const bool ldv = ld_valid && !ld_blocked && !(since == 0 && ahead);
-        if (issue_first && ldv) issue(buf ^ 1, lkt, rc_t);
+        const bool ldi = ldv && !(DBG & 2);  // (2: no operand loads in the K loop)
+        if (issue_first && ldi) issue(buf ^ 1, lkt, rc_t);
         if (DBG & 16) t2 = __builtin_amdgcn_s_memtime();
-        gp_kstep<decltype(FIRST)::value>(smem_p2c, buf, wr, wc, l31, lh, acc);
-        if (!issue_first && ldv) {
+        gp_kstep<decltype(FIRST)::value, DBG & 1>(smem_p2c, buf, wr, wc, l31, lh, acc);
+        if (!issue_first && ldi) {
             unsigned rc = rc_t;
             asm("" : "+v"(rc) : "v"(acc[3][1]));  // scheduling-only: keeps the loads behind the MFMAs
             issue(buf ^ 1, lkt, rc);
@@ -304,11 +306,12 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
                 : "+v"(ev) : "s"(er_c[0]), "s"(er_c[1]), "s"(ar_c[0]), "s"(ar_c[1]));
         }
         if (!(DBG & 4)) {
+            constexpr int EDBG = DBG & (64 | 128 | 8192);  // no stores | stores into 1 MB | residual from a slab
             switch (cp.kind[s]) {
-                case P2_OUT_PLANES: gp_epilogue<P2_OUT_PLANES, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
-                case P2_OUT_PLANES | 4: gp_epilogue<P2_OUT_PLANES, true, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
-                case P2_OUT_QKV: gp_epilogue<P2_OUT_QKV, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
-                default: gp_epilogue<P2_OUT_F32, false, 0>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+                case P2_OUT_PLANES: gp_epilogue<P2_OUT_PLANES, false, EDBG>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+                case P2_OUT_PLANES | 4: gp_epilogue<P2_OUT_PLANES, true, EDBG>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+                case P2_OUT_QKV: gp_epilogue<P2_OUT_QKV, false, EDBG>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+                default: gp_epilogue<P2_OUT_F32, false, EDBG>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
             }
         } else {
             asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));
@@ -318,8 +321,11 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
         since = 0;
         if (ld_blocked) {
             // hard hand-off: every wave's stores of this tile have retired, then everybody's have; the consumer starts like a first tile
+            // (buffer_inv sc0: the consumer's loads must not be served from vector-L1 lines older than the producer waves' stores.  In
+            // this build - CU mode, no tgsplit: build.py refuses the flag - all waves of the workgroup share one write-through L1 and
+            // the invalidate is redundant; it is issued anyway, once per row block, so that the hand-off does not rest on that)
             if (DBG & 512) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\tbuffer_inv sc0" ::: "memory");
             ld_blocked = false;
             ++lf;
             lkt = 0;
@@ -395,9 +401,24 @@ int launch_gemm_p2_chain(e2emv_ctx* ctx, const GemmP2Args* a, const int* dep_kt,
         case 1028: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<1028>); break;
         case 2048: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<2048>); break;
         case 16: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<16>); break;
+        // round 6: 1 no MFMAs, 2 no operand loads in the K loop, 4096 every workgroup's activation rows = row block 0 (L2-resident),
+        // 64 epilogues without stores, 128 epilogue stores into 1 MB, 8192 the residual from an L2-resident slab
+        case 1: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<1>); break;
+        case 2: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<2>); break;
+        case 4096: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<4096>); break;
+        case 4100: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<4100>); break;
+        case 64: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<64>); break;
+        case 128: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<128>); break;
+        case 8192: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<8192>); break;
+        case 72: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<72>); break;      // per-tile stamps of the variants without stores / with L2-resident activations
+        case 4104: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<4104>); break;
+        case 4160: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<4160>); break;  // no stores AND L2-resident activations
+        case 32: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<32>); break;      // no per-step barrier
+        case 36: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<36>); break;
+        case 12416: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<12416>); break;  // 4096 + 8192 + 128: no HBM traffic but the weights
         default: break;
     }
-    if (dbg == 8 || dbg == 16) {
+    if ((dbg & 8) || dbg == 16) {
         if (!d_buf) E2EMV_HIP(ctx, hipMalloc((void**)&d_buf, nb));
         E2EMV_HIP(ctx, hipMemsetAsync(d_buf, 0, nb, s));
         for (int i = 0; i < n; ++i) cp.st[i].dbg = d_buf;
@@ -423,9 +444,9 @@ int launch_gemm_p2_chain(e2emv_ctx* ctx, const GemmP2Args* a, const int* dep_kt,
             }
         }
     }
-    if (dbg == 8) {
+    if (dbg & 8) {
         static int printed = 0;
-        if (printed++ < 3) {
+        if (printed++ < 1) {
             E2EMV_HIP(ctx, hipStreamSynchronize(s));
             std::vector<long long> h(2 * 8 * 12 * 4);
             E2EMV_HIP(ctx, hipMemcpy(h.data(), d_buf, nb, hipMemcpyDeviceToHost));

@@ -164,6 +164,9 @@ int launch_gemm_p2_chain(e2emv_ctx* ctx, const GemmP2Args* a, const int* dep_kt,
 int launch_to_planes(e2emv_ctx* ctx, const float* src, int64_t rows, int C, int64_t ld_src, uint16_t* dst, hipStream_t s, int* E = nullptr,
                      float* AM = nullptr);  // AM (optional, with E): the blocks' max |value|
 int launch_from_planes(e2emv_ctx* ctx, const uint16_t* src, int64_t rows, int C, float* dst, int64_t ld_dst, hipStream_t s, const int* E = nullptr);
+// [mdesc_i[n] | mdesc_j[matches[n]]] of B samples ([B][n_rows][2 D]) straight to scaled planes + tile exponents (the conf head's GEMM operand)
+int launch_conf_gather_planes(e2emv_ctx* ctx, const float* mdesc_i, const float* mdesc_j, int64_t tuple_stride, const int64_t* matches, int N, int n_rows,
+                              int B, int D, uint16_t* dst, int* E, hipStream_t s);
 // host: fp32 weights [rows][cols] -> P2 planes of 2^s W appended to `out` (offset returned), *out_scale = 2^-s
 size_t add_split_p2(std::vector<uint16_t>& out, const std::vector<float>& w, int rows, int cols, float* out_scale);
 // softmax(q k^T / sqrt(64)) v on plane operands: qk = q | k plain planes [n_img * n_rows][2D], vt = V^T plain planes;

@@ -72,6 +72,58 @@ __global__ __launch_bounds__(256) void to_planes_exp_kernel(const float* src, in
     }
 }
 
+// The conf head's input [mdesc_i[n] | mdesc_j[match n]] ([B][n_rows][2 D]) made as planes with tile exponents in ONE pass: the gather
+// of forward.hip's conf_gather2_kernel resolved in the source address of to_planes_exp_kernel's loads (round 6: one launch and a
+// 2 x 67 MB fp32 round trip less per forward at configs[1]; the arithmetic, and so the planes, are to_planes_exp_kernel's bit for bit).
+// Unmatched (-1) and padding rows take keypoint 0 of image j, as the gather kernel did (their confidence is 0 whatever the head says).
+__global__ __launch_bounds__(256) void conf_gather_planes_kernel(const float* mdesc_i, const float* mdesc_j, int64_t tuple_stride, const int64_t* matches, int N,
+                                                                 int n_rows, int D, uint16_t* dst, int* E, unsigned* stats) {
+    __shared__ float wmax[4];
+    const int cb = blockIdx.x, rb = blockIdx.y;  // 64-column block of the 2 D columns, 64-row block of the B * n_rows rows
+    const int t = threadIdx.x;
+    const int64_t m = (int64_t)rb * 64 + (t >> 2);
+    const int b = (int)(m / n_rows), row = (int)(m - (int64_t)b * n_rows);
+    const int n = cb * 64 + (t & 3) * 16;
+    const float* sp;
+    if (n < D) sp = mdesc_i + b * tuple_stride + (int64_t)row * D + n;
+    else {
+        int64_t j = row < N ? matches[(int64_t)b * N + row] : 0;
+        if (j < 0) j = 0;
+        sp = mdesc_j + b * tuple_stride + j * D + (n - D);
+    }
+    p2_f32x4 v[4];
+    float am = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = *reinterpret_cast<const p2_f32x4*>(sp + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(v[i][e]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+    if ((t & 63) == 0) wmax[t >> 6] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const int ex = p2_pick_exponent(am);
+    const float f = p2_exp2i(-ex);
+    if (t == 0) {
+        E[(int64_t)rb * gridDim.x + cb] = ex;
+        if (ex != 0 && stats) atomicAdd(stats, 1u);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        p2_u32x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const P2Pair a = p2_split_scaled(v[2 * h][2 * e] * f, v[2 * h][2 * e + 1] * f), c = p2_split_scaled(v[2 * h + 1][2 * e] * f, v[2 * h + 1][2 * e + 1] * f);
+            hi[e] = a.hi; lo[e] = a.lo; hi[2 + e] = c.hi; lo[2 + e] = c.lo;
+        }
+        uint16_t* dp = dst + p2_index(m, n + 8 * h, 2 * D);
+        *reinterpret_cast<p2_u32x4*>(dp) = hi;
+        *reinterpret_cast<p2_u32x4*>(dp + 32) = lo;
+    }
+}
+
 // planes -> fp32; plain != 0: plain planes (hi + lo) divided by `unscale`
 __global__ __launch_bounds__(256) void from_planes_kernel(const uint16_t* src, int64_t rows, int C, float* dst, int64_t ld_dst, int plain, float unscale,
                                                           const int* E) {
@@ -187,6 +239,18 @@ int launch_to_planes(e2emv_ctx* ctx, const float* src, int64_t rows, int C, int6
     }
     hipLaunchKernelGGL(to_planes_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, src, rows, C, ld_src, dst);
     E2EMV_CHECK_LAUNCH(ctx, "to_planes_kernel");
+    return E2EMV_OK;
+}
+
+int launch_conf_gather_planes(e2emv_ctx* ctx, const float* mdesc_i, const float* mdesc_j, int64_t tuple_stride, const int64_t* matches, int N, int n_rows,
+                              int B, int D, uint16_t* dst, int* E, hipStream_t s) {
+    const int64_t rows = (int64_t)B * n_rows;
+    if (rows % 64 || D % 64 || rows / 64 > 65535 || tuple_stride % 4 || (uintptr_t)mdesc_i % 16 || (uintptr_t)mdesc_j % 16 || !E)
+        return set_err(ctx, E2EMV_ESHAPE, "conf_gather_planes: needs 64 x 64 blocks (rows=%lld D=%d)", (long long)rows, D);
+    if (int rc = ensure_flags(ctx)) return rc;
+    hipLaunchKernelGGL(conf_gather_planes_kernel, dim3(2 * D / 64, (unsigned)(rows / 64)), dim3(256), 0, s, mdesc_i, mdesc_j, tuple_stride, matches, N, n_rows, D, dst,
+                       E, ctx->d_flags + 2);
+    E2EMV_CHECK_LAUNCH(ctx, "conf_gather_planes_kernel");
     return E2EMV_OK;
 }
 

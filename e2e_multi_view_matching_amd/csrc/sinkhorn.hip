@@ -1861,6 +1861,118 @@ static void launch_sweeps(const SkParams& p, int B, bool final, hipStream_t s) {
     }
 }
 
+// ---- the launcher's plan, shared by launch_sinkhorn and the e2emv_sinkhorn_plan query (bench.py reports it instead of re-deriving it)
+struct SkKernel { const void* fn = nullptr; int rows = 0, threads = 512, wg_per_cu = 0; size_t lds = 0; bool big = false; };
+struct SkSegment { int b0 = 0, n = 0; SkKernel k; int resident = 0; };
+struct SkPlan { int n_seg = 0; SkSegment seg[2]; };  // n_seg == 0: the log-domain launch chain
+
+// `count`: this is a real call (the demotion counters of the context advance); false for the query
+static int plan_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, int64_t ldS, int iters, bool count, SkPlan& plan) {
+    plan = SkPlan{};
+    bool resident = iters >= 1 && ldS <= 2048;
+    // which kernel: the context's pin (e2emv_set_sinkhorn_kernel; initialised ONCE from E2EMV_SINKHORN when the context is made)
+    const int pin = ctx->sinkhorn_kernel;
+    if (pin == E2EMV_SINKHORN_STREAM) resident = false;
+    // once a call of this context reported scores outside the exponential-domain kernel's range (e2emv_sync / e2emv_get_stats),
+    // the model at hand is served by the log-domain chain: slower, no range limit
+    // (demotion needs two observed range events; after 16 calls on the chain the resident kernel gets another try - a model whose
+    // scores really are out of its range is demoted again by the next event)
+    if (ctx->sinkhorn_stream) {
+        if (!count) resident = false;
+        else if (++ctx->sk_stream_calls > 16) { ctx->sinkhorn_stream = false; ctx->sk_stream_calls = 0; ctx->sk_range_strikes = 1; }
+        else resident = false;
+    }
+    if (!resident) return E2EMV_OK;
+    // A call is served by one or two resident launches (segments of the batch): the kernels with K in registers addressed by number
+    // (sinkhorn_resident128 at 513 .. 1024 columns, sinkhorn_resident2k at 1025 .. 2048: twice the rows per workgroup, twice the
+    // problems resident, a round 1.6 - 1.75 times as long - measured 0.83 - 0.94 against 0.51 - 0.53 ms per 100 iterations at
+    // 1024 x 1024, 1.21 against 0.80 at 2048 x 2048) take every FULL round of theirs, the remainder goes to whichever is cheaper:
+    // rounds of the compiler-allocated kernel, or one more round of the big one.  80 problems of 1024 x 1024 = 64 + 16.
+    // Pin rows64: never the big kernels; rows128: the big kernel for the whole batch whenever the shape allows it - with a pin a
+    // problem's result does not depend on its batch neighbours (tests compare a problem alone with the same problem in a batch).
+    SkKernel kbase, kbig;
+    const bool full = N == ldS && N == KT_of(ldS) * 256;
+    // granule pairs (16-byte exchange stores / loads): a thread must own an even number of columns and a consumer's column
+    // slice must be even
+    const int G0 = (M + skr_rows(ldS) - 1) / skr_rows(ldS);
+    const bool pairs = KT_of(ldS) >= 4 && ((N + G0 - 1) / G0) % 2 == 0 && dbg_knob("E2EMV_SKR_PAIR", 1) != 0;
+    const void* kfn = nullptr;
+    switch (KT_of(ldS)) {
+        case 1: kfn = full ? (const void*)sinkhorn_resident<1, true> : (const void*)sinkhorn_resident<1, false>; break;
+        case 2: kfn = full ? (const void*)sinkhorn_resident<2, true> : (const void*)sinkhorn_resident<2, false>; break;
+        case 4:
+            if (skr_rw(ldS) == 8) {
+                if (pairs) kfn = full ? (const void*)sinkhorn_resident<4, true, true, 8> : (const void*)sinkhorn_resident<4, false, true, 8>;
+                else kfn = full ? (const void*)sinkhorn_resident<4, true, false, 8> : (const void*)sinkhorn_resident<4, false, false, 8>;
+            } else if (pairs) kfn = full ? (const void*)sinkhorn_resident<4, true, true> : (const void*)sinkhorn_resident<4, false, true>;
+            else kfn = full ? (const void*)sinkhorn_resident<4, true> : (const void*)sinkhorn_resident<4, false>;
+            break;
+        default:
+            if (pairs) kfn = full ? (const void*)sinkhorn_resident<8, true, true> : (const void*)sinkhorn_resident<8, false, true>;
+            else kfn = full ? (const void*)sinkhorn_resident<8, true> : (const void*)sinkhorn_resident<8, false>;
+            break;
+    }
+    kbase.fn = kfn; kbase.rows = skr_rows(ldS); kbase.threads = 512;
+    kbase.lds = sizeof(float) * (size_t)(9 * KT_of(ldS) * 256 + 4 + 32);
+    if (KT_of(ldS) == 4) {
+        const int G128 = (M + 127) / 128, cs128 = (N + G128 - 1) / G128;
+        if (cs128 % 2 == 0 && G128 <= 16) {
+            kbig.fn = (full && M % 128 == 0) ? (const void*)sinkhorn_resident128<true> : (const void*)sinkhorn_resident128<false>;  // (full rows AND columns)
+            kbig.rows = 128;
+            kbig.lds = sizeof(float) * (size_t)(4 * SK128_RL * 1024 + 4 * 1024 + 1024 + 4 + 32 + 3 * 128);
+        }
+    } else if (KT_of(ldS) == 8) {
+        const int G2k = (M + 63) / 64, cs2k = (N + G2k - 1) / G2k;
+        if (cs2k % 2 == 0 && G2k <= 64) {
+            kbig.fn = (full && M % 64 == 0) ? (const void*)sinkhorn_resident2k<true> : (const void*)sinkhorn_resident2k<false>;
+            kbig.rows = 64;
+            kbig.lds = sizeof(float) * (size_t)(4 * SK2K_RL * 2048 + 2 * 2048 + 2048 + 4 + 32 + 3 * 64);
+        }
+    }
+    kbig.threads = 256; kbig.big = true;
+    static std::map<std::pair<int, const void*>, int> occupancy;  // (device, kernel) -> resident workgroups per CU
+    static std::mutex occupancy_mu;
+    for (SkKernel* k : {&kbase, &kbig}) {
+        if (!k->fn) continue;
+        std::lock_guard<std::mutex> lk(occupancy_mu);
+        auto it = occupancy.find({ctx->device, k->fn});
+        if (it == occupancy.end()) {
+            int nb = 0;
+            if (k->lds > 48 * 1024 && ensure_dynamic_lds(ctx, k->fn, k->lds) != E2EMV_OK) {
+                (void)hipGetLastError();  // a device with less LDS: the streaming chain serves the call
+                nb = 0;
+            } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k->fn, k->threads, k->lds) != hipSuccess) {
+                (void)hipGetLastError();
+                nb = 0;
+            }
+            it = occupancy.emplace(std::make_pair(ctx->device, k->fn), std::min(nb, 2)).first;
+        }
+        k->wg_per_cu = it->second;
+        const int G = (M + k->rows - 1) / k->rows;
+        if (k->wg_per_cu < 1 || G > k->wg_per_cu * ctx->num_cus) k->fn = nullptr;  // cannot hold a problem's workgroups at once
+    }
+    if (!kbase.fn) { if (kbig.fn) kbase = kbig; else return E2EMV_OK; }
+    auto res_of = [&](const SkKernel& k) { return std::max(1, (k.wg_per_cu * ctx->num_cus) / std::max((M + k.rows - 1) / k.rows, 1)); };
+    auto add = [&](int b0, int n, const SkKernel& k) {
+        SkSegment& sg = plan.seg[plan.n_seg++];
+        sg.b0 = b0; sg.n = n; sg.k = k; sg.resident = std::min(n, res_of(k));
+    };
+    if (!kbig.fn || kbase.big || pin == E2EMV_SINKHORN_ROWS64) {
+        add(0, B, kbase);
+    } else if (pin == E2EMV_SINKHORN_ROWS128) {
+        add(0, B, kbig);
+    } else {
+        const int res_big = res_of(kbig), res_base = res_of(kbase);
+        int n_big = (B / res_big) * res_big;   // every full round of the big kernel (it holds twice the problems at < 2 x the time)
+        const int rem = B - n_big;
+        if (rem > 0 && 8 * ((rem + res_base - 1) / res_base) > 13) n_big = B;  // the remainder too: one round of 1.6 against two or more of 1
+        if (n_big > 0) add(0, n_big, kbig);
+        if (n_big < B) add(n_big, B - n_big, kbase);
+    }
+    return E2EMV_OK;
+}
+
+
 int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t ldS, float alpha, int iters,
                     float match_thr, const SinkhornOut& out, char* ws, hipStream_t s) {
     if (B <= 0 || M <= 0 || N <= 0) return set_err(ctx, E2EMV_ESHAPE, "sinkhorn: empty problem");
@@ -1908,114 +2020,17 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
     };
 
     // ---- resident path: all iterations in one launch (S read once); the streaming chain below is the fallback for
-    // iters == 0, for E2EMV_SINKHORN=stream and for devices that cannot hold a problem's workgroups at once
-    bool resident = iters >= 1 && ldS <= 2048;
-    if (const char* e = getenv("E2EMV_SINKHORN")) {
-        if (strcmp(e, "stream") == 0) resident = false;
-    }
-    // once a call of this context reported scores outside the exponential-domain kernel's range (e2emv_sync / e2emv_get_stats),
-    // the model at hand is served by the log-domain chain: slower, no range limit
-    // (demotion needs two observed range events; after 16 calls on the chain the resident kernel gets another try - a model whose
-    // scores really are out of its range is demoted again by the next event)
-    if (ctx->sinkhorn_stream) {
-        if (++ctx->sk_stream_calls > 16) { ctx->sinkhorn_stream = false; ctx->sk_stream_calls = 0; ctx->sk_range_strikes = 1; }
-        else resident = false;
-    }
-    // A call is served by one or two resident launches (segments of the batch): the kernels with K in registers addressed by number
-    // (sinkhorn_resident128 at 513 .. 1024 columns, sinkhorn_resident2k at 1025 .. 2048: twice the rows per workgroup, twice the
-    // problems resident, a round 1.6 - 1.75 times as long - measured 0.83 - 0.94 against 0.51 - 0.53 ms per 100 iterations at
-    // 1024 x 1024, 1.21 against 0.80 at 2048 x 2048) take every FULL round of theirs, the remainder goes to whichever is cheaper:
-    // rounds of the compiler-allocated kernel, or one more round of the big one.  80 problems of 1024 x 1024 = 64 + 16.
-    // E2EMV_SINKHORN=rows64: never the big kernels; =rows128: the big kernel for the whole batch whenever the shape allows it
-    // (tests compare a problem alone with the same problem in a batch through the same kernel).
-    struct SkKernel { const void* fn = nullptr; int rows = 0, threads = 512, wg_per_cu = 0; size_t lds = 0; bool big = false; };
-    SkKernel kbase, kbig;
-    if (resident) {
-        const bool full = N == ldS && N == KT_of(ldS) * 256;
-        // granule pairs (16-byte exchange stores / loads): a thread must own an even number of columns and a consumer's column
-        // slice must be even
-        const int G0 = (M + skr_rows(ldS) - 1) / skr_rows(ldS);
-        const bool pairs = KT_of(ldS) >= 4 && ((N + G0 - 1) / G0) % 2 == 0 && dbg_knob("E2EMV_SKR_PAIR", 1) != 0;
-        const void* kfn = nullptr;
-        switch (KT_of(ldS)) {
-            case 1: kfn = full ? (const void*)sinkhorn_resident<1, true> : (const void*)sinkhorn_resident<1, false>; break;
-            case 2: kfn = full ? (const void*)sinkhorn_resident<2, true> : (const void*)sinkhorn_resident<2, false>; break;
-            case 4:
-                if (skr_rw(ldS) == 8) {
-                    if (pairs) kfn = full ? (const void*)sinkhorn_resident<4, true, true, 8> : (const void*)sinkhorn_resident<4, false, true, 8>;
-                    else kfn = full ? (const void*)sinkhorn_resident<4, true, false, 8> : (const void*)sinkhorn_resident<4, false, false, 8>;
-                } else if (pairs) kfn = full ? (const void*)sinkhorn_resident<4, true, true> : (const void*)sinkhorn_resident<4, false, true>;
-                else kfn = full ? (const void*)sinkhorn_resident<4, true> : (const void*)sinkhorn_resident<4, false>;
-                break;
-            default:
-                if (pairs) kfn = full ? (const void*)sinkhorn_resident<8, true, true> : (const void*)sinkhorn_resident<8, false, true>;
-                else kfn = full ? (const void*)sinkhorn_resident<8, true> : (const void*)sinkhorn_resident<8, false>;
-                break;
-        }
-        kbase.fn = kfn; kbase.rows = skr_rows(ldS); kbase.threads = 512;
-        kbase.lds = sizeof(float) * (size_t)(9 * KT_of(ldS) * 256 + 4 + 32);
-        if (KT_of(ldS) == 4) {
-            const int G128 = (M + 127) / 128, cs128 = (N + G128 - 1) / G128;
-            if (cs128 % 2 == 0 && G128 <= 16) {
-                kbig.fn = (full && M % 128 == 0) ? (const void*)sinkhorn_resident128<true> : (const void*)sinkhorn_resident128<false>;  // (full rows AND columns)
-                kbig.rows = 128;
-                kbig.lds = sizeof(float) * (size_t)(4 * SK128_RL * 1024 + 4 * 1024 + 1024 + 4 + 32 + 3 * 128);
-            }
-        } else if (KT_of(ldS) == 8) {
-            const int G2k = (M + 63) / 64, cs2k = (N + G2k - 1) / G2k;
-            if (cs2k % 2 == 0 && G2k <= 64) {
-                kbig.fn = (full && M % 64 == 0) ? (const void*)sinkhorn_resident2k<true> : (const void*)sinkhorn_resident2k<false>;
-                kbig.rows = 64;
-                kbig.lds = sizeof(float) * (size_t)(4 * SK2K_RL * 2048 + 2 * 2048 + 2048 + 4 + 32 + 3 * 64);
-            }
-        }
-        kbig.threads = 256; kbig.big = true;
-        static std::map<std::pair<int, const void*>, int> occupancy;  // (device, kernel) -> resident workgroups per CU
-        static std::mutex occupancy_mu;
-        for (SkKernel* k : {&kbase, &kbig}) {
-            if (!k->fn) continue;
-            std::lock_guard<std::mutex> lk(occupancy_mu);
-            auto it = occupancy.find({ctx->device, k->fn});
-            if (it == occupancy.end()) {
-                int nb = 0;
-                if (k->lds > 48 * 1024 && ensure_dynamic_lds(ctx, k->fn, k->lds) != E2EMV_OK) {
-                    (void)hipGetLastError();  // a device with less LDS: the streaming chain below serves the call
-                    nb = 0;
-                } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k->fn, k->threads, k->lds) != hipSuccess) {
-                    (void)hipGetLastError();
-                    nb = 0;
-                }
-                it = occupancy.emplace(std::make_pair(ctx->device, k->fn), std::min(nb, 2)).first;
-            }
-            k->wg_per_cu = it->second;
-            const int G = (M + k->rows - 1) / k->rows;
-            if (k->wg_per_cu < 1 || G > k->wg_per_cu * ctx->num_cus) k->fn = nullptr;  // cannot hold a problem's workgroups at once
-        }
-        if (!kbase.fn) { if (kbig.fn) kbase = kbig; else resident = false; }
-    }
+    // iters == 0, for the `stream` pin and for devices that cannot hold a problem's workgroups at once (plan_sinkhorn above)
+    SkPlan plan;
+    if (int rc_p = plan_sinkhorn(ctx, B, M, N, ldS, iters, true, plan)) return rc_p;
+    bool resident = plan.n_seg > 0;
     if (resident) {
         if (int rc_f = ensure_flags(ctx)) return rc_f;
-        int knob = 1;
-        if (const char* e = getenv("E2EMV_SINKHORN")) knob = strcmp(e, "rows64") == 0 ? 0 : (strcmp(e, "rows128") == 0 ? 2 : 1);
-        struct Segment { int b0, n; const SkKernel* k; };
-        Segment seg[2];
-        int n_seg = 0;
-        auto res_of = [&](const SkKernel& k) { return std::max(1, (k.wg_per_cu * ctx->num_cus) / std::max((M + k.rows - 1) / k.rows, 1)); };
-        if (!kbig.fn || !kbase.fn || kbase.big || knob == 0) {
-            seg[n_seg++] = {0, B, &kbase};
-        } else if (knob == 2) {
-            seg[n_seg++] = {0, B, &kbig};
-        } else {
-            const int res_big = res_of(kbig), res_base = res_of(kbase);
-            int n_big = (B / res_big) * res_big;   // every full round of the big kernel (it holds twice the problems at < 2 x the time)
-            const int rem = B - n_big;
-            if (rem > 0 && 8 * ((rem + res_base - 1) / res_base) > 13) n_big = B;  // the remainder too: one round of 1.6 against two or more of 1
-            if (n_big > 0) seg[n_seg++] = {0, n_big, &kbig};
-            if (n_big < B) seg[n_seg++] = {n_big, B - n_big, &kbase};
-        }
+        const SkSegment* seg = plan.seg;
+        const int n_seg = plan.n_seg;
         const char* dbg_path = dbg_env("E2EMV_SKR_DEBUG");
         for (int si = 0; si < n_seg; ++si) {
-            const SkKernel& k = *seg[si].k;
+            const SkKernel& k = seg[si].k;
             const int b0 = seg[si].b0, nb = seg[si].n;
             const ResidentPlan rp = resident_plan(nb, M, N, k.wg_per_cu * ctx->num_cus, k.rows);
             SkResParams rpar{};
@@ -2055,7 +2070,7 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
                 }
             }
         }
-        if (seg[0].k->big) ++ctx->stat_sinkhorn_rows128;
+        if (seg[0].k.big) ++ctx->stat_sinkhorn_rows128;
         // problems the exponential-domain kernel could not finish are re-solved in the log domain before anything reads u, v
         hipLaunchKernelGGL(sinkhorn_rescue, dim3(B), dim3(1024), sizeof(float) * (size_t)(M + N + 2), s, p, iters, ctx->d_flags);
         E2EMV_CHECK_LAUNCH(ctx, "sinkhorn_rescue");
@@ -2090,6 +2105,33 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
 }  // namespace e2emv
 
 using namespace e2emv;
+
+extern "C" int e2emv_set_sinkhorn_kernel(e2emv_ctx* ctx, int kernel) {
+    if (!ctx) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
+    if (kernel < E2EMV_SINKHORN_AUTO || kernel > E2EMV_SINKHORN_STREAM) return set_err(ctx, E2EMV_EINVAL, "set_sinkhorn_kernel: %d (E2EMV_SINKHORN_AUTO .. _STREAM)", kernel);
+    ctx->sinkhorn_kernel = kernel;
+    return E2EMV_OK;
+}
+
+extern "C" int e2emv_sinkhorn_plan(e2emv_ctx* ctx, int B, int M, int N, int iters, int* plan_out, int n) {
+    if (!ctx || !plan_out || n < 1) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
+    (void)hipSetDevice(ctx->device);
+    if (B <= 0 || M <= 0 || N <= 0 || iters < 0) return set_err(ctx, E2EMV_ESHAPE, "sinkhorn_plan: bad sizes");
+    SkPlan plan;
+    if (int rc = plan_sinkhorn(ctx, B, M, N, round_up(N, 4), iters, false, plan)) return rc;
+    for (int i = 0; i < n; ++i) plan_out[i] = 0;
+    plan_out[0] = plan.n_seg;
+    for (int si = 0; si < plan.n_seg && 1 + 4 * (si + 1) <= n; ++si) {
+        const SkSegment& sg = plan.seg[si];
+        plan_out[1 + 4 * si + 0] = sg.k.rows;                               // rows of a problem per workgroup
+        plan_out[1 + 4 * si + 1] = sg.n;                                    // problems of the batch this launch takes
+        plan_out[1 + 4 * si + 2] = sg.resident;                             // problems resident at a time
+        plan_out[1 + 4 * si + 3] = (sg.n + sg.resident - 1) / sg.resident;  // rounds
+    }
+    return E2EMV_OK;
+}
 
 extern "C" int e2emv_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* d_scores, float bin_score, int iters,
                               float* d_logZ, void* stream) {

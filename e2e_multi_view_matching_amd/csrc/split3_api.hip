@@ -84,6 +84,9 @@ extern "C" int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const f
         prof_end(ctx, s);
         return rc;
     }
+#ifndef E2EMV_STAMPS
+    return set_err(ctx, E2EMV_EINVAL, "gemm_bf16x3: the all-planes first-generation kernel (flags bit1, gemm3.hip) is part of the measurement build only");
+#else
     if ((rc = launch_split3(ctx, d_A, M, K, K, A3, K, s))) return rc;
     Gemm3Args g;
     g.M = M; g.N = Nout; g.K = K; g.K1 = K; g.A = A3; g.lda = K; g.W = W3; g.ldw = K; g.bias = d_bias;
@@ -92,6 +95,7 @@ extern "C" int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const f
     rc = launch_gemm3(ctx, g, s);
     prof_end(ctx, s);
     return rc;
+#endif
 }
 
 extern "C" int e2emv_attention_bf16x3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid, int D, int H, const float* d_qkv,

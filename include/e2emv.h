@@ -385,6 +385,25 @@ int e2emv_get_descriptors(e2emv_ctx* ctx, float* d_out, int64_t capacity_floats,
  * attention_p2w redid on its slow path (a performance counter: results are the same).  Host-synchronising. */
 int e2emv_get_stats(e2emv_ctx* ctx, uint64_t* stats, int n, int reset);
 
+/* ---- which Sinkhorn kernel serves a call (upstream log_optimal_transport: models/superglue.py:156-186; reference call sites
+ * /root/reference/helpers.py:246, eval_pairs.py:212) --------------------------------------------------------------------------
+ * E2EMV_SINKHORN_AUTO (default): by shape AND batch size - the kernels with the couplings in registers addressed by number take
+ * their full rounds, the remainder goes to the compiler-allocated kernel.  The kernels sum in different orders: a
+ * problem's log-assignment can differ by < 2e-5 between two batch compositions.  ROWS64 / ROWS128 pin one kernel kind for every
+ * call of the context: a problem's result then does not depend on its batch neighbours, bit for bit.  STREAM = the log-domain
+ * launch chain (no resident kernel; also taken for iters == 0).  The initial value comes from the environment variable
+ * E2EMV_SINKHORN = rows64 | rows128 | stream, read ONCE at e2emv_create. */
+#define E2EMV_SINKHORN_AUTO 0
+#define E2EMV_SINKHORN_ROWS64 1
+#define E2EMV_SINKHORN_ROWS128 2
+#define E2EMV_SINKHORN_STREAM 3
+int e2emv_set_sinkhorn_kernel(e2emv_ctx* ctx, int kernel);
+/* The launcher's plan for a batch of B problems of M x N scores and `iters` iterations on this context (what e2emv_sinkhorn /
+ * e2emv_matcher_forward would launch now; nothing is launched): plan[0] = number of resident launches (0 = the log-domain chain, 1
+ * or 2), then per launch 4 ints: rows of a problem per workgroup, problems of the batch it takes, problems resident at a time,
+ * rounds.  n = capacity of plan (>= 9 for everything).  bench.py reports its Sinkhorn bound from this instead of re-deriving it. */
+int e2emv_sinkhorn_plan(e2emv_ctx* ctx, int B, int M, int N, int iters, int* plan, int n);
+
 /* ---- training: the matcher with a tape, the backward of the match loss and (through the confidences) of the pose loss ------
  * Replaces, for stage-1 training (match loss only), what torch.autograd does under the reference's
  *   pred = run_matcher(...); train_loss.backward()        (/root/reference/helpers.py:243-260, train.py:406-425)
@@ -447,6 +466,30 @@ int e2emv_pose_errors_backward(e2emv_ctx* ctx, int B, const float* d_T, const fl
 int e2emv_profile(e2emv_ctx* ctx, int enable);
 int e2emv_profile_read(e2emv_ctx* ctx, float* ms, int64_t* launches, int n_slots, int reset);
 const char* e2emv_profile_name(int slot);
+
+/* ---- the one collective of the path: metric gather / reduction over the ranks of a node (RCCL over xGMI) --------------------------
+ * Replaces, for a host without torch.distributed, the reference's init_process_group(backend="nccl") (/root/reference/train.py:
+ * 270-277) and its only explicit collective, the all_reduce of the validation loss (train.py:102-106); the evaluation scripts'
+ * per-pair pose errors are gathered with the same communicator for the exact sort-based AUC.  One process per GPU; tuples are
+ * sharded, the data path has no collective.  librccl.so.1 is dlopen'ed by the first of these calls (E2EMV_ESTATE if absent).
+ *   rank 0: e2emv_comm_unique_id -> hand the 128 bytes to every rank (file, environment, the launcher's store) ->
+ *   every rank: e2emv_comm_init (collective: returns when all `world` ranks called it) -> e2emv_metric_* -> e2emv_comm_destroy.
+ * e2emv_comm_init_file does the hand-over through a file all ranks see (rank 0 writes path atomically, the others poll up to
+ * timeout_s seconds).  d_* buffers are device memory of the context's device; calls are ordered on `stream`. */
+#define E2EMV_COMM_ID_BYTES 128
+typedef struct e2emv_comm e2emv_comm;
+int e2emv_comm_unique_id(e2emv_ctx* ctx, void* id_out /* [E2EMV_COMM_ID_BYTES] */);
+int e2emv_comm_init(e2emv_ctx* ctx, const void* id, int rank, int world, e2emv_comm** out);
+int e2emv_comm_init_file(e2emv_ctx* ctx, const char* path, int rank, int world, double timeout_s, e2emv_comm** out);
+int e2emv_comm_destroy(e2emv_ctx* ctx, e2emv_comm* comm);
+int e2emv_comm_rank(const e2emv_comm* comm, int* rank, int* world);
+/* d_all [world][n] <- every rank's d_local [n], rank order, on every rank */
+int e2emv_metric_allgather(e2emv_ctx* ctx, e2emv_comm* comm, const float* d_local, int n, float* d_all, void* stream);
+/* d_buf [n] <- op over the ranks, in place */
+#define E2EMV_REDUCE_SUM 0
+#define E2EMV_REDUCE_MAX 1
+#define E2EMV_REDUCE_MIN 2
+int e2emv_metric_allreduce(e2emv_ctx* ctx, e2emv_comm* comm, float* d_buf, int n, int op, void* stream);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

@@ -119,7 +119,7 @@ def test_pose_from_matches_recovers_ground_truth_and_is_scale_invariant(full):
 def test_sinkhorn_idempotent_rerun_and_batch_independence(gpu):
     """Same input twice -> bit-identical output; a pair's result does not depend on its batch neighbours.  The library serves a
     batch of 32 on 128-row workgroups and a batch of 2 on 64-row ones (another summation order of the same algorithm): bit for bit
-    with the kernel pinned (E2EMV_SINKHORN=rows64 / rows128), within the two orders' distance with the library's own choice."""
+    with the kernel pinned (e2emv_set_sinkhorn_kernel: rows64 / rows128), within the two orders' distance with the library's own choice."""
     import os
     import e2e_multi_view_matching_amd as E
     g = torch.Generator().manual_seed(4)
@@ -130,13 +130,15 @@ def test_sinkhorn_idempotent_rerun_and_batch_independence(gpu):
     c = E.log_optimal_transport(s[5:7].contiguous(), 1.0, 100)
     assert float((c - a[5:7]).abs().max()) < 2e-5
     assert torch.equal(c[:, :-1, :-1].argmax(2), a[5:7, :-1, :-1].argmax(2))
+    from e2e_multi_view_matching_amd import _lib
+    ctx = _lib.context(gpu)
     try:
         for mode in ("rows64", "rows128"):
-            os.environ["E2EMV_SINKHORN"] = mode
+            ctx.set_sinkhorn_kernel(mode)
             a = E.log_optimal_transport(s, 1.0, 100)
             assert torch.equal(E.log_optimal_transport(s[5:7].contiguous(), 1.0, 100), a[5:7]), mode
     finally:
-        os.environ.pop("E2EMV_SINKHORN", None)
+        ctx.set_sinkhorn_kernel(None)
 
 
 def test_multi_frame_self_consistency(gpu):

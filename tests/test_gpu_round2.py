@@ -255,9 +255,10 @@ def test_config5_per_gpu_shape_t5_2048_fp16_batch8(gpu):
 
 
 def test_f16x2_out_of_range_activations(gpu, split_always):
-    """Activations beyond fp16's range (|x| > 65504 in a GEMM input).  Round 2's f16x2 kernels turn them into +-inf and
-    e2emv_sync reports it; the plane kernels (round 3, the default) carry a tile exponent per 64 x 64 block and solve the same
-    input like bf16x3 does - there is nothing to fall back to."""
+    """Activations beyond fp16's range (|x| > 65504 in a GEMM input).  The plane kernels (round 3, the default) carry a tile
+    exponent per 64 x 64 block and solve the same input like bf16x3 does - there is nothing to fall back to.  (Round 2's f16x2
+    kernels turned them into +-inf for e2emv_sync to report; that generation is selectable in the measurement build only since
+    round 6 - non-finite scores as an error: tests/test_gpu_sinkhorn_resident.py.)"""
     from e2e_multi_view_matching_amd import MultiViewMatcher, _lib
     from e2e_multi_view_matching_amd.synthetic import make_tuples
     ctx = _lib.context(gpu)
@@ -283,14 +284,3 @@ def test_f16x2_out_of_range_activations(gpu, split_always):
     assert float((z - zr).abs().max() / zr.abs().max()) < 1e-6
     assert torch.equal(out["matches0_0_1"], ref["matches0_0_1"])
     assert ctx.stats()["rescaled_blocks"] > 0                        # the exponents were at work
-    model.config["mfma_precision"] = "f16x2-r2"                      # round-2 kernels: loud, not silent
-    with torch.no_grad():
-        out = model(dg)
-    assert not bool(torch.isfinite(out["scores_0_1"]).all())
-    assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.EHIP and b"range" in ctx.lib.e2emv_last_error(ctx.h)  # non-finite scores
-    assert ctx.lib.e2emv_sync(ctx.h, None) == _lib.OK                # the report is consumed once
-    ctx.stats(reset=True)                                            # (the report moved the context's Sinkhorn to the log-domain chain: undo)
-    model.config["check_finite"] = True                              # the same report as an exception from forward()
-    with pytest.raises(_lib.E2EMVError), torch.no_grad():
-        model(dg)
-    ctx.stats(reset=True)                                            # (the report also moved the context's Sinkhorn to the log-domain chain)

@@ -1,5 +1,5 @@
 """The resident Sinkhorn kernel (-m gpu): all iterations in one launch in the exponential domain (one multiply-add per
-element per half-iteration), workgroups of a problem exchanging column sums through tagged granules.  Checked against the oracle, against the streaming launch chain (E2EMV_SINKHORN=stream), for
+element per half-iteration), workgroups of a problem exchanging column sums through tagged granules.  Checked against the oracle, against the streaming launch chain (the `stream` pin), for
 bit-identical re-runs, across rounds (more problems than fit the chip at once), on ragged shapes, and under uneven load
 (another stream saturating the memory system while the exchange runs)."""
 import os
@@ -16,18 +16,15 @@ def _scores(B, M, N, seed, scale=3.0):
 
 
 def _stream_mode(on):
-    if on:
-        os.environ["E2EMV_SINKHORN"] = "stream"
-    else:
-        os.environ.pop("E2EMV_SINKHORN", None)
+    from e2e_multi_view_matching_amd import _lib
+    _lib.context().set_sinkhorn_kernel("stream" if on else None)
 
 
 def _rows_mode(mode):
-    """None: the library's choice; "rows64" / "rows128": the 64-row kernel only / the 128-row kernel whenever the shape allows it."""
-    if mode:
-        os.environ["E2EMV_SINKHORN"] = mode
-    else:
-        os.environ.pop("E2EMV_SINKHORN", None)
+    """None: the library's choice; "rows64" / "rows128": the 64-row kernel only / the 128-row kernel whenever the shape allows it
+    (the context's pin, e2emv_set_sinkhorn_kernel)."""
+    from e2e_multi_view_matching_amd import _lib
+    _lib.context().set_sinkhorn_kernel(mode)
 
 
 @pytest.mark.parametrize("B,M,N,iters", [(2, 128, 128, 100), (1, 100, 77, 20), (2, 33, 250, 5), (3, 1024, 1024, 100),
@@ -185,7 +182,7 @@ def test_dynamic_range_of_the_exponential_domain(gpu):
     """The resident kernel iterates a = exp(u + rowmax), b = exp(v) instead of log-sum-exps.  Measured against an fp64
     oracle it is MORE accurate than the fp32 log-domain forms up to |logZ| ~ 700 (scores spread over hundreds of nats);
     when a scaling finally leaves fp32's range the rescue pass behind the kernel re-solves that problem in the log domain
-    inside the same call (counted in stats, nothing raised) - as the streaming chain (E2EMV_SINKHORN=stream) does."""
+    inside the same call (counted in stats, nothing raised) - as the streaming chain (the `stream` pin) does."""
     import e2e_multi_view_matching_amd as E
     from e2e_multi_view_matching_amd import _lib
     from oracle.sinkhorn import log_optimal_transport

@@ -154,6 +154,16 @@ def test_weight_fingerprint_sees_object_replacement_inside_submodules():
     changed("a replaced submodule")
     m.kenc.encoder[1].running_mean = m.kenc.encoder[1].running_mean.clone()
     changed("a re-assigned BatchNorm buffer")
+    # a None slot of a NESTED module filled later, and a submodule added to a nested module - neither changes the
+    # number of slots of any module that existed when the walk was cached
+    m.final_proj.bias = None
+    changed("a parameter slot set to None")
+    m.final_proj.bias = nn.Parameter(torch.zeros(m.config["descriptor_dim"]))
+    changed("a None slot of a nested module filled")
+    m.gnn.layers[0].extra = nn.Linear(2, 2)
+    changed("a submodule added to a nested module")
+    del m.gnn.layers[0].extra
+    changed("... and removed again")
     keys = [k for k, v in m.state_dict().items() if v.dtype.is_floating_point]
     assert [k for k, *_ in m._fingerprint()] == keys  # the same tensors, in state_dict order, that _send_weights uploads
 
@@ -191,3 +201,11 @@ def test_shard_range_partitions():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_generated_sinkhorn_rows_header_is_the_generators_output():
+    """csrc/sinkhorn128_rows.h (550 lines of asm statements on registers addressed by number) is generated: the committed file must
+    be exactly what tools/gen_sk128_asm.py writes (a hand edit of either would silently diverge)."""
+    import runpy
+    ns = runpy.run_path(os.path.join(ROOT, "tools", "gen_sk128_asm.py"), run_name="gen_sk128_asm_check")
+    assert open(ns["path"]).read() == ns["out"]

@@ -160,5 +160,9 @@ for nm, acc_rows in (("sk128_rc4v", False), ("sk128_rc4a", True)):
               CLCH, '"s"(a2[0]), "s"(a2[1]), "s"(a2[2]), "s"(a2[3]), "n"(B0), "n"(B1), "n"(B2), "n"(B3)', False)
 
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "e2e_multi_view_matching_amd", "csrc", "sinkhorn128_rows.h")
-open(path, "w").write(out)
-print(len(out.split("\n")), "lines ->", os.path.normpath(path))
+if __name__ == "__main__":
+    import sys
+    if "--check" in sys.argv:  # tests/test_host_and_abi.py: the committed header IS this generator's output
+        sys.exit(0 if open(path).read() == out else 1)
+    open(path, "w").write(out)
+    print(len(out.split("\n")), "lines ->", os.path.normpath(path))

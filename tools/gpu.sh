@@ -1,5 +1,5 @@
 #!/bin/bash
-# One parameterised GPU-box script (run through gpurun): tools/gpu.sh <stage> [...]; output under gpurun_out/r5/.
+# One parameterised GPU-box script (run through gpurun): tools/gpu.sh <stage> [...]; output under gpurun_out/r6/.
 #   planes   per-kernel parity of the plane kernels + matcher parity + micro-benchmarks + bench A/B (plane vs round-2 kernels)
 #   tests    the whole -m gpu suite
 #   bench    bench.py lines (c2 default, c4, c5)
@@ -7,7 +7,7 @@
 #   kt       rocprofv3 kernel trace of one config / mode
 #   prof     rocprofv3 kernel trace + the three PMC passes of config c2
 cd "$GRAFT_REPO_ROOT" || exit 1
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r5
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r6
 mkdir -p $OUT
 export TMPDIR=/tmp
 stage=${1:-tests}
@@ -96,7 +96,7 @@ stamps)
   timeout 900 python tools/p2_stamps.py 2>&1 | tee $OUT/p2_stamps.log
   ;;
 cstamps)
-  timeout 900 python tools/p2c_stamps.py 2>&1 | tee $OUT/p2c_stamps.log
+  timeout 1200 python tools/p2c_stamps.py "${@:2}" 2>&1 | tee $OUT/p2c_stamps.log
   ;;
 ab)
   timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_p2.json 2> $OUT/bench_p2.err
@@ -109,6 +109,7 @@ sk128)
   timeout 300 python - <<'PY' 2>&1 | tee $OUT/sk128_time.log
 import os, time, torch
 import e2e_multi_view_matching_amd as E
+from e2e_multi_view_matching_amd import _lib
 def t(s, it=100, reps=20):
     for _ in range(3): E.log_optimal_transport(s, 1.0, it)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -119,10 +120,9 @@ for B, M, N in ((32, 1024, 1024), (80, 1024, 1024), (48, 1024, 1024), (40, 1024,
     r = []
     for rep in range(2):
         for mode in ("rows64", "rows128", None):
-            if mode: os.environ["E2EMV_SINKHORN"] = mode
-            else: os.environ.pop("E2EMV_SINKHORN", None)
+            _lib.context().set_sinkhorn_kernel(mode)
             r.append(t(s))
-    os.environ.pop("E2EMV_SINKHORN", None)
+    _lib.context().set_sinkhorn_kernel(None)
     print(f"{B} x {M} x {N}: rows64 {r[0]:.3f} / {r[3]:.3f} ms   rows128 / 2k {r[1]:.3f} / {r[4]:.3f} ms   library's plan {r[2]:.3f} / {r[5]:.3f} ms")
 PY
   ;;

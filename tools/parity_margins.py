@@ -52,7 +52,7 @@ def main():
         scale = float(md32.abs().max())
         if md64 is not None:
             print(f"   descriptors: max |mdesc| {scale:.3f}; oracle fp32 vs fp64 max |d| {float((md32.double() - md64).abs().max()):.2e}")
-        for precision in ("f32", "bf16x3", "f16x2", "f16x2-r3"):
+        for precision in ("f32", "bf16x3", "f16x2", "f16x2-r4"):
             model.config["mfma_precision"] = precision
             with torch.no_grad():
                 out = model(dg)

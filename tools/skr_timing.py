@@ -51,7 +51,8 @@ def run(B, N, iters, flags, path):
 if __name__ == "__main__":
     if "--rows128" in sys.argv:  # the 128-row kernel (taken by itself for 32 problems) against the 64-row one
         for mode in ("rows64", "rows128"):
-            os.environ["E2EMV_SINKHORN"] = mode
+            from e2e_multi_view_matching_amd import _lib
+            _lib.context().set_sinkhorn_kernel(mode)
             for B, N in ((1, 1024), (32, 1024), (1, 2048), (8, 2048)):
                 print(mode, end=": ")
                 run(B, N, 100, 0, "/tmp/skr.txt")
