@@ -109,6 +109,7 @@ SIGNATURES = {
     "e2emv_attention_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                        c_void_p]),
     "e2emv_set_f16x2_kernels": (c_int, [c_void_p, c_int]),
+    "e2emv_set_attention_key_split": (c_int, [c_void_p, c_int]),
     "e2emv_gemm_p2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                               c_void_p]),
     "e2emv_qkv_p2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -231,6 +232,11 @@ class Context:
         self.call("e2emv_set_f16x2_kernels", int(generation))
         self.f16x2_kernels = int(generation)
 
+    def set_attention_key_split(self, on=True):
+        """attention_p2w: split the items of a half-empty last round of workgroups along the keys (default on)."""
+        self.call("e2emv_set_attention_key_split", 1 if on else 0)
+        self.attention_key_split = bool(on)
+
     def select_f16x2_kernels(self, generation=None):
         """The generation every model on this device runs from now on (forward() re-selects `default_f16x2_kernels` on each
         call, so `set_f16x2_kernels` alone lasts one call).  None = back to what E2EMV_F16X2_KERNELS chose at creation."""
@@ -277,6 +283,7 @@ class Context:
         self.default_precision = other.default_precision
         self.default_f16x2_kernels = other.default_f16x2_kernels
         self.call("e2emv_set_sinkhorn_kernel", getattr(other, "sinkhorn_kernel_pin", 0))
+        self.call("e2emv_set_attention_key_split", 1 if getattr(other, "attention_key_split", True) else 0)
         want = getattr(other, "split_min_rows", -1)
         if getattr(self, "split_min_rows", -1) != want:
             self.set_split_min_rows(want)

@@ -16,6 +16,9 @@ struct AttnP2Params {
     int B, T, n_rows, D, H, cross;
     int nv[E2EMV_MAX_TUPLE];
     int nq, groups, gper;
+    int n_full, n_split;  // attention_p2w key split (launcher): items < n_full are whole, the rest are walked by n_split workgroups each
+    float* part;          // ... their (O, m, l) records and
+    int* part_e;          // ... the V exponent each wave's O sits at
     unsigned* stats;      // attention_p2w: [0] += (wave, stream, tile) softmaxes redone on the slow path (beyond a stream's first tile)
     long long* dbg;       // measurement build: timestamps of two workgroups (attention_p2w)
 };

@@ -34,6 +34,7 @@ typedef __attribute__((ext_vector_type(16))) float aw_f32x16;
 constexpr int AW_QT = 256;              // queries per workgroup
 constexpr int AW_TILEB = 64 * 256;      // one operand tile: 64 rows x 256 B
 constexpr int AW_REGB = 2 * AW_TILEB;   // region: V(j) | K(j+1)
+constexpr int AW_PART_F = 68;           // floats of a key-split part's record per query: O[64], m, l (+ 2: 16-byte rows)
 // Softmax numerators carry the factor 2^AW_PLOG against the stream's running maximum.  7 (attention_p2: 10) leaves the fast
 // path 8.9 bits of growth of a row's maximum before its sum check sends the tile through the slow path - measured with 10:
 // a third of the tiles of a 1024-key problem had SOME query of the workgroup beyond 5.9 bits, and a slow path costs every
@@ -132,11 +133,23 @@ __device__ __forceinline__ void aw_load_q(const char* qp, p2_f16x8 (&q)[2][4]) {
 // ABL (measurement only, wrong results): 1 no softmax arithmetic in the slots, 2 no MFMAs, 4 no fragment reads, 8 no LDS-direct
 // loads, 16 no barrier
 // MULTI: more than one source image per query image (cross layers of tuples with T > 2); without it the tile walk is a counter
-template <bool HAS_E, int ABL = 0, bool MULTI = true>
+// PART: the instantiation that walks the key-split PARTS of a launch's leftover items (its own launch behind the whole items': the
+// whole-item kernel stays the code it was - carrying the part logic as run-time flags cost it 6 % at configs[1])
+template <bool HAS_E, int ABL = 0, bool MULTI = true, bool PART = false>
 __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem_aw[];
 
-    const int lin = blockIdx.x;
+    // PART: items from p.n_full on are walked in PARTS (key split, round 6): when the items do not fill the last round of
+    // workgroups (T = 5: 640 items on 256 CUs - 3 rounds for 2.5), each of the r leftover items is walked by n_split workgroups, part
+    // ks taking tiles [ks T / n_split, (ks + 1) T / n_split) of the item's T key tiles and leaving (m, l, O) of its keys in p.part for
+    // attention_p2w_combine.  A part keeps its item's place in the XCD interleave (its keys are the L2 working set of that XCD).
+    int lin = blockIdx.x, ks = 0;
+    constexpr bool part = PART;
+    if constexpr (PART) {  // (grid = leftover items x n_split)
+        const int h = blockIdx.x, tpx = (8 * p.gper * p.nq - p.n_full) >> 3;  // leftover items per XCD
+        ks = (h >> 3) / tpx;
+        lin = p.n_full + 8 * ((h >> 3) % tpx) + (h & 7);
+    }
     const int xcd = lin & 7, idx = lin >> 3;
     const int g = xcd * p.gper + idx / p.nq;
     if (g >= p.groups) return;
@@ -180,6 +193,12 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
     auto src_t = [&](int si) __attribute__((always_inline)) { return !p.cross ? t : (si < t ? si : si + 1); };
     int n_tiles = 0;
     for (int si = 0; si < n_src; ++si) n_tiles += (p.nv[src_t(si)] + 63) / 64;
+    int t0 = 0;  // first tile of this workgroup's share (a whole item: all of them)
+    if constexpr (PART) {
+        t0 = ks * n_tiles / p.n_split;
+        n_tiles = (ks + 1) * n_tiles / p.n_split - t0;
+        if (n_tiles <= 0) return;  // (fewer tiles than parts: the combine pass skips the part the same way)
+    }
     struct Cur { int si, kt, nv; unsigned kb, vb; int eb; };  // kb / vb: byte offsets of the source's first K / V^T tile, eb: its first 64-row block
     auto cur_src = [&](Cur& c) __attribute__((always_inline)) {
         const int im = b * p.T + src_t(c.si);
@@ -189,12 +208,19 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
         c.vb = (unsigned)((im * p.H + head) * 64) * (unsigned)p.n_rows * 4u;
         c.eb = (im * p.n_rows) >> 6;
     };
-    auto cur_init = [&]() __attribute__((always_inline)) { Cur c; c.si = 0; cur_src(c); return c; };
     auto cur_next = [&](Cur& c) __attribute__((always_inline)) {
         ++c.kt;
         if constexpr (MULTI) {
             if (c.kt * 64 >= c.nv && c.si + 1 < n_src) { ++c.si; cur_src(c); }
         }
+    };
+    auto cur_init = [&]() __attribute__((always_inline)) {
+        Cur c;
+        c.si = 0;
+        cur_src(c);
+        if constexpr (PART)
+            for (int i = 0; i < t0; ++i) cur_next(c);  // (a part starts at its first tile)
+        return c;
     };
 
     // ---- loader: one piece = 4 rows x 256 B; lane -> (row lane >> 4, LDS position lane & 15), source chunk = position ^ (row & 15)
@@ -220,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
     int* const els = reinterpret_cast<int*>(smem_aw + 3 * AW_REGB);
     int ek_mine = 0, ev_mine = 0;
     if (HAS_E && tid < n_tiles) {  // (n_tiles <= 7 sources x 32 tiles)
-        int si = 0, kt = tid;
+        int si = 0, kt = PART ? tid + t0 : tid;
         if constexpr (MULTI) {
             for (; si + 1 < n_src; ++si) {
                 const int nt = (p.nv[src_t(si)] + 63) / 64;
@@ -623,6 +649,25 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
     // ---- epilogue: scaled planes of the two streams' output rows
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the pieces the last iterations issued past the last tile: nothing lands in LDS behind this workgroup)
     asm volatile("s_nop 15" : "+a"(O[0][0]), "+a"(O[0][1]), "+a"(O[1][0]), "+a"(O[1][1]));  // (the last MFMAs' results -> VALU)
+    if constexpr (PART) {
+        // a part's result: per query O (64 floats, at the exponent e_o of its last V tile), the running maximum and the sum of its keys
+        // - record (leftover item, part, query) of AW_PART_F floats; the wave's e_o beside them
+        const int64_t rec = ((int64_t)(lin - p.n_full) * p.n_split + ks) * AW_QT;
+        if (lane == 0) p.part_e[rec / 64 + wave] = e_o;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float l_tot = l_run[a] + __shfl_xor(l_run[a], 32);
+            float* o = p.part + (rec + wave * 64 + a * 32 + l31) * AW_PART_F;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<p2_f32x4*>(o + 32 * d + 8 * gq + 4 * lh) = p2_f32x4{O[a][d][4 * gq], O[a][d][4 * gq + 1], O[a][d][4 * gq + 2], O[a][d][4 * gq + 3]};
+            if (lh == 0) { o[64] = m_run[a]; o[65] = l_tot; }
+        }
+        if (p.stats && n_slow && lane == 0) atomicAdd(p.stats, n_slow);
+        return;
+    }
     if (p.EO && lane == 0 && q_ok[0]) p.EO[(((int64_t)img * p.n_rows + q_row[0]) >> 6) * 4 + head] = e_o;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -653,6 +698,64 @@ __global__ __launch_bounds__(256, 1) void attention_p2w_kernel(AttnP2Params p) {
     if constexpr ((ABL & 32) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp();  // 13: stores done
+    }
+}
+
+// The parts of the key-split items -> output rows.  Part k of a query holds O_k = sum_j 2^(s_j - m_k + c) v_j over ITS keys (at the
+// exponent e_k of its last V tile), l_k = sum_j 2^(s_j - m_k + c) and m_k; with m = max m_k: out = sum_k 2^(m_k - m) 2^(e_k - e) O_k /
+// (16 sum_k 2^(m_k - m) l_k) at e = max e_k - the arithmetic of the kernel's own epilogue behind the rescaling of its slow path.
+// One workgroup = one leftover item's 256 queries; thread = (query, 16 dims).
+__global__ __launch_bounds__(1024) void attention_p2w_combine(AttnP2Params p) {
+    const int item = blockIdx.x, lin = p.n_full + item;
+    const int xcd = lin & 7, idx = lin >> 3;
+    const int g = xcd * p.gper + idx / p.nq;
+    if (g >= p.groups) return;
+    const int qt = idx % p.nq, img = g / p.H, head = g % p.H, t = img % p.T;
+    if (qt * AW_QT >= p.nv[t]) return;
+    const int n_src = p.cross ? p.T - 1 : 1;
+    int n_tiles = 0;
+    for (int si = 0; si < n_src; ++si) n_tiles += (p.nv[!p.cross ? t : (si < t ? si : si + 1)] + 63) / 64;
+    const int q = threadIdx.x >> 2, dq = (threadIdx.x & 3) * 16;
+    const int row = qt * AW_QT + q;
+    float m = -3.0e38f;
+    int e = -1000;
+    for (int k = 0; k < p.n_split; ++k) {
+        if ((k + 1) * n_tiles / p.n_split - k * n_tiles / p.n_split <= 0) continue;
+        const int64_t rec = ((int64_t)item * p.n_split + k) * AW_QT;
+        m = fmaxf(m, p.part[(rec + q) * AW_PART_F + 64]);
+        e = max(e, p.part_e[rec / 64 + (q >> 6)]);
+    }
+    float acc[16], l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k = 0; k < p.n_split; ++k) {
+        if ((k + 1) * n_tiles / p.n_split - k * n_tiles / p.n_split <= 0) continue;
+        const int64_t rec = ((int64_t)item * p.n_split + k) * AW_QT;
+        const float* o = p.part + (rec + q) * AW_PART_F;
+        const int ek = p.part_e[rec / 64 + (q >> 6)];
+        const float a = __builtin_amdgcn_exp2f(o[64] - m);
+        const float ae = a * (ek - e < -126 ? 0.f : p2_exp2i(ek - e));
+        l += a * o[65];
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            const p2_f32x4 v = *reinterpret_cast<const p2_f32x4*>(o + dq + i);
+            acc[i] += ae * v[0]; acc[i + 1] += ae * v[1]; acc[i + 2] += ae * v[2]; acc[i + 3] += ae * v[3];
+        }
+    }
+    if (row >= p.n_rows) return;
+    if (p.EO && (threadIdx.x & 255) == 0) p.EO[(((int64_t)img * p.n_rows + row) >> 6) * 4 + head] = e;
+    const float inv = 1.f / (l * P2_VS);
+    uint16_t* op = p.out + p2_index((int64_t)img * p.n_rows + row, head * 64 + dq, p.D);  // (dq, dq + 8: inside one 32-column block)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        p2_u32x4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const P2Pair pr = p2_split_scaled(acc[8 * h + 2 * i] * inv, acc[8 * h + 2 * i + 1] * inv);
+            hi[i] = pr.hi; lo[i] = pr.lo;
+        }
+        *reinterpret_cast<p2_u32x4*>(op + 8 * h) = hi;
+        *reinterpret_cast<p2_u32x4*>(op + 8 * h + 32) = lo;
     }
 }
 
@@ -695,8 +798,52 @@ int launch_attention_p2w(e2emv_ctx* ctx, AttnP2Params& p, int n_valid, hipStream
 #endif
     if (int rc = ensure_dynamic_lds(ctx, fn, lds)) return rc;
     void* args[] = {&p};
-    E2EMV_HIP(ctx, hipLaunchKernel(fn, dim3(8 * p.gper * p.nq), dim3(256), args, lds, s));
-    E2EMV_CHECK_LAUNCH(ctx, "attention_p2w_kernel");
+    // ---- the last round of workgroups.  n_items = R CUs + r: with 0 < r <= CUs / 2 the r leftover items would hold the chip for a whole
+    // round at < half its width (T = 5, 1024 keypoints: 640 items, 3 rounds for 2.5 of work) - they are split along the keys into
+    // n_split = floor(CUs / r) parts each (<= 8, <= the fewest key tiles of an item) + one small combine launch.  Fewer items than CUs
+    // (R = 0: a pair or two per call) split the same way.  e2emv_attention_p2 flags bit 12 (tests): never.
+    const int n_items = 8 * p.gper * p.nq, cus = std::max(8, ctx->num_cus / 8 * 8);
+    const int r = n_items % cus;
+    int min_tiles = 1 << 30;
+    for (int t = 0; t < p.T; ++t) {  // key tiles of the item with the fewest: a part must own at least one
+        int nt = 0;
+        for (int si = 0; si < p.T; ++si)
+            if (p.cross ? si != t : si == t) nt += (p.nv[si] + 63) / 64;
+        min_tiles = std::min(min_tiles, nt);
+    }
+    p.n_full = n_items;
+    p.n_split = 1;
+    p.part = nullptr;
+    p.part_e = nullptr;
+    if (ctx->attn_key_split && r > 0 && 2 * r <= cus && r % 8 == 0) {
+        const int k = std::min(std::min(cus / r, 8), min_tiles);
+        if (k >= 2) {
+            const size_t n_rec = (size_t)r * k * AW_QT;
+            const size_t need = n_rec * AW_PART_F * sizeof(float) + (n_rec / 64) * sizeof(int);
+            if (need > ctx->attn_part_bytes) {
+                if (ctx->d_attn_part) { E2EMV_HIP(ctx, hipStreamSynchronize(s)); (void)hipFree(ctx->d_attn_part); ctx->d_attn_part = nullptr; ctx->attn_part_bytes = 0; }
+                E2EMV_HIP(ctx, hipMalloc((void**)&ctx->d_attn_part, need));
+                ctx->attn_part_bytes = need;
+            }
+            p.n_full = n_items - r;
+            p.n_split = k;
+            p.part = ctx->d_attn_part;
+            p.part_e = reinterpret_cast<int*>(ctx->d_attn_part + n_rec * AW_PART_F);
+        }
+    }
+    if (p.n_full > 0) {
+        E2EMV_HIP(ctx, hipLaunchKernel(fn, dim3(p.n_full), dim3(256), args, lds, s));
+        E2EMV_CHECK_LAUNCH(ctx, "attention_p2w_kernel");
+    }
+    if (p.n_split > 1) {
+        const void* fp = p.EQK ? (multi ? reinterpret_cast<const void*>(attention_p2w_kernel<true, 0, true, true>) : reinterpret_cast<const void*>(attention_p2w_kernel<true, 0, false, true>))
+                               : (multi ? reinterpret_cast<const void*>(attention_p2w_kernel<false, 0, true, true>) : reinterpret_cast<const void*>(attention_p2w_kernel<false, 0, false, true>));
+        if (int rc = ensure_dynamic_lds(ctx, fp, lds)) return rc;
+        E2EMV_HIP(ctx, hipLaunchKernel(fp, dim3((n_items - p.n_full) * p.n_split), dim3(256), args, lds, s));
+        E2EMV_CHECK_LAUNCH(ctx, "attention_p2w_kernel (parts)");
+        hipLaunchKernelGGL(attention_p2w_combine, dim3(n_items - p.n_full), dim3(1024), 0, s, p);
+        E2EMV_CHECK_LAUNCH(ctx, "attention_p2w_combine");
+    }
 #ifdef E2EMV_STAMPS
     if (p.dbg) {
         E2EMV_HIP(ctx, hipStreamSynchronize(s));

@@ -103,6 +103,7 @@ struct e2emv_ctx {
     bool h2_legacy = false;  // f16x2 mode on the round-2 kernels (fp32 activations split inside gemm_h2 / attention_h2f): the A/B arm of the plane path
     int gemm_chain = 1;      // f16x2 kernel generation 5 (default): MLP0 -> MLP1 -> next q|k|v chained in one launch (gemm_p2c.hip); 0 = generation 4 (a launch per GEMM), 2 = chained whenever the shapes allow (e2emv_set_f16x2_kernels(105))
     bool attn_wide = true;   // f16x2 kernel generations 4, 5: attention_p2w above 256 keys; false = generation 3 (attention_p2 everywhere)
+    bool attn_key_split = true;  // attention_p2w: a half-empty last round of workgroups is split along the keys (attention_p2w.hip; e2emv_attention_p2 flags bit 12 clears it for one call)
     int attn_abl = 0;        // measurement build: ablation of attention_p2w's main loop
     int attn_p2_nw = 0;      // attention on planes: 0 = by key count, 4 | 8 = attention_p2 with that many waves, 1 = attention_p2w (micro-benchmarks)
     bool b3_planes = false;  // bf16x3 mode: q|k|v handed to the attention as planes from the GEMM epilogue (E2EMV_B3_PLANES=1)

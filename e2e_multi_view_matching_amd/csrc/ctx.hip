@@ -671,6 +671,13 @@ int e2emv_set_f16x2_kernels(e2emv_ctx* ctx, int generation) {
     return E2EMV_OK;
 }
 
+int e2emv_set_attention_key_split(e2emv_ctx* ctx, int on) {
+    if (!ctx) return E2EMV_EINVAL;
+    E2EMV_LOCK(ctx);
+    ctx->attn_key_split = on != 0;
+    return E2EMV_OK;
+}
+
 int e2emv_set_split_min_rows(e2emv_ctx* ctx, int64_t min_rows) {
     if (!ctx) return E2EMV_EINVAL;
     E2EMV_LOCK(ctx);

@@ -347,6 +347,12 @@ int e2emv_attention_bf16x3(e2emv_ctx* ctx, int B, int T, int n_rows, int n_valid
  * round-2 kernels that keep fp32 activations and split them inside the consuming GEMM / attention (kept as A/B arms and
  * for other widths).  Also E2EMV_F16X2_KERNELS=r2 | r3 | r4 at e2emv_create. */
 int e2emv_set_f16x2_kernels(e2emv_ctx* ctx, int generation);
+/* attention_p2w (f16x2, above 256 keys): when the (image, head, 256-query) items of a launch leave the last round of workgroups at most
+ * half full - tuple_size 5 at 1024 keypoints: 640 items on 256 CUs, three rounds for 2.5 of work; a pair or two per call: fewer items
+ * than CUs - the leftover items are split along the keys over the idle CUs and merged by a small second launch (on = 1, default; the
+ * reference's shapes: eval_multi_view.py:154-162).  Results differ from the unsplit kernel by the order of the softmax sums only
+ * (~1e-7 relative).  on = 0: never (A/B runs, tests). */
+int e2emv_set_attention_key_split(e2emv_ctx* ctx, int on);
 /* building blocks on fp32 buffers (conversion to / from planes done by helper kernels; for tests and micro-benchmarks):
  * C = act([A | A2] W^T + bias) (+ R); A [M,K1], A2 [M,K-K1] or NULL, W [N,K], R [M,N] or NULL.  flags: bit0 relu, bit1 the
  * kernel writes planes (converted back to fp32 afterwards) instead of fp32, bit2 = with the tile exponents of the range

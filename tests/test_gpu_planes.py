@@ -228,3 +228,32 @@ def test_attention_p2_tile_exponents_carry_fp32_range(gpu, qs, ks, vs, waves):
     err = float((out[:, :n_valid].double() - ref[:, :n_valid]).abs().max()) / vs
     err32 = float((out32[:, :n_valid].double() - ref[:, :n_valid]).abs().max()) / vs
     assert err < 3 * err32 + 3e-6, (err, err32)
+
+
+@pytest.mark.parametrize("B,T,n_rows,n_valid,cross", [(8, 5, 1024, 1024, 1),   # configs[3]'s cross layers: 640 items, the last 128 in two parts each
+                                                       (8, 5, 1024, 1024, 0),   # ... and its self layers
+                                                       (3, 2, 1024, 1000, 0),   # fewer items than CUs (96 -> 2 parts each), ragged last tile
+                                                       (1, 3, 640, 577, 1),     # 36 items -> 7 parts of 19 tiles: uneven parts over two sources
+                                                       (2, 2, 384, 300, 1)])    # 5 tiles in 5 parts of one tile each
+def test_attention_p2w_key_split_equals_the_unsplit_kernel(gpu, B, T, n_rows, n_valid, cross):
+    """Round 6: the items of a half-empty last round of workgroups are split along the keys (parts leave (m, l, O), a second launch
+    merges them).  Same operands through the same kernel with the split off: equal up to the order of the softmax sums - and both
+    against the fp64 reference at the one size where that is cheap."""
+    import e2e_multi_view_matching_amd as E
+    from e2e_multi_view_matching_amd import _lib
+    ctx = _lib.context(gpu)
+    g = torch.Generator().manual_seed(n_valid + T)
+    qkv = (torch.randn(B * T, n_rows, 3 * 256, generator=g) * 1.5).to(gpu)
+    try:
+        ctx.set_attention_key_split(False)
+        whole = E.attention_p2(qkv, B, T, n_valid, 4, cross, waves=1).cpu()
+        ctx.set_attention_key_split(True)
+        split = E.attention_p2(qkv, B, T, n_valid, 4, cross, waves=1).cpu()
+    finally:
+        ctx.set_attention_key_split(True)
+    assert bool(torch.isfinite(split[:, :n_valid]).all())
+    d = float((split[:, :n_valid] - whole[:, :n_valid]).abs().max())
+    assert d < 8e-6, d  # (outputs of magnitude ~4: the order of fp32 sums; the kernel itself sits 2e-5 from fp64)
+    if B * T <= 6:
+        ref = _attention_ref(qkv.cpu(), B, T, n_valid, 4, cross)
+        assert float((split[:, :n_valid].double() - ref[:, :n_valid]).abs().max()) < 2e-5

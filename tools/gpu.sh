@@ -42,8 +42,8 @@ import json; d=json.loads(open('$OUT/bench_g5_2.json').read().strip().splitlines
   args="--steps 2 --warmup 1 --cpu-pairs 0 --no-alt --no-latency --no-profile"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_chain -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_chain.log 2>&1)
   db=$(find /tmp/kt_chain -name '*.db' | head -1)
-  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r5_kernel_stats_c2_f16x2_chain.md 2>&1
-  head -24 $OUT/r5_kernel_stats_c2_f16x2_chain.md
+  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r6_kernel_stats_c2_f16x2_chain.md 2>&1
+  head -24 $OUT/r6_kernel_stats_c2_f16x2_chain.md
   ;;
 planes)
   timeout 900 python -m pytest tests/test_gpu_planes.py -x -q 2>&1 | tail -15 | tee $OUT/planes_tests.log
@@ -141,19 +141,22 @@ final)
   # at::native count of a trace with three times the steps
   bash tools/gpu.sh prof c2 f16x2
   cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
+  # (round 6: counter passes of configs[3] and the configs[4] share on the current kernels too - each prof call extends the traffic file)
+  bash tools/gpu.sh prof c4 f16x2 > /dev/null
+  cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
+  bash tools/gpu.sh prof c5 f16x2 > /dev/null
+  cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
   bash tools/gpu.sh bench
-  bash tools/gpu.sh kt c4 f16x2 > /dev/null
-  bash tools/gpu.sh kt c5 f16x2 > /dev/null
   args="--steps 6 --warmup 1 --cpu-pairs 0 --no-alt --no-latency --no-profile"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_c2_steps6 -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_c2_steps6.log 2>&1)
   db=$(find /tmp/kt_c2_steps6 -name '*.db' | head -1)
-  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r5_kernel_stats_c2_f16x2_steps6.md 2>&1
+  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r6_kernel_stats_c2_f16x2_steps6.md 2>&1
   # the Sinkhorn kernels against each other (product library), then their per-phase timestamps (measurement build)
   bash tools/gpu.sh sk128 > /dev/null 2>&1
   timeout 400 python tools/skr_timing.py --rows128 2>&1 | grep -v amdgpu.ids > $OUT/skr_rows128.log
-  { echo "# ms per call of 100 iterations incl. the final sweep, one box, alternating (tools/gpu.sh sk128; rows64 = E2EMV_SINKHORN=rows64: the 64-row"; echo "# (32-row at 2048 columns) workgroups only, rows128 / 2k = the kernels with the couplings in registers addressed by number for the whole batch,"; echo "# library's plan = their full rounds + the remainder on whichever is cheaper: what a call gets by default)"; grep " x " $OUT/sk128_time.log; echo; echo "# tests/test_gpu_sinkhorn_resident.py on the same box:"; tail -1 $OUT/sk128_tests.log; echo; echo "# per-phase timestamps (tools/skr_timing.py --rows128, measurement build tools/libe2emv_stamps.bin; workgroup 0's thread 0, iterations 2 - 13):"; cat $OUT/skr_rows128.log; } > $OUT/r5_sinkhorn_rows128.log
-  echo "at::native launches: steps 2 / steps 6"; grep "at::native" $OUT/r5_kernel_stats_c2_f16x2.md $OUT/r5_kernel_stats_c2_f16x2_steps6.md
-  grep "gemm_p2_chain\|attention_p2w" $OUT/r5_kernel_stats_c2_f16x2.md $OUT/r5_kernel_stats_c2_f16x2_steps6.md
+  { echo "# ms per call of 100 iterations incl. the final sweep, one box, alternating (tools/gpu.sh sk128; rows64 = E2EMV_SINKHORN=rows64: the 64-row"; echo "# (32-row at 2048 columns) workgroups only, rows128 / 2k = the kernels with the couplings in registers addressed by number for the whole batch,"; echo "# library's plan = their full rounds + the remainder on whichever is cheaper: what a call gets by default)"; grep " x " $OUT/sk128_time.log; echo; echo "# tests/test_gpu_sinkhorn_resident.py on the same box:"; tail -1 $OUT/sk128_tests.log; echo; echo "# per-phase timestamps (tools/skr_timing.py --rows128, measurement build tools/libe2emv_stamps.bin; workgroup 0's thread 0, iterations 2 - 13):"; cat $OUT/skr_rows128.log; } > $OUT/r6_sinkhorn_rows128.log
+  echo "at::native launches: steps 2 / steps 6"; grep "at::native" $OUT/r6_kernel_stats_c2_f16x2.md $OUT/r6_kernel_stats_c2_f16x2_steps6.md
+  grep "gemm_p2_chain\|attention_p2w" $OUT/r6_kernel_stats_c2_f16x2.md $OUT/r6_kernel_stats_c2_f16x2_steps6.md
   ;;
 one)
   timeout 300 python bench.py --steps 10 --warmup 3 --cpu-pairs 0 --no-alt --no-latency > $OUT/bench_one.json 2> $OUT/bench_one.err
@@ -166,16 +169,16 @@ kt)
   args="--config $cfg --precision $mode --steps 2 --warmup 1 --cpu-pairs 0 --no-alt --no-latency --no-profile"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_${cfg}_${mode} -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_${cfg}_${mode}.log 2>&1)
   db=$(find /tmp/kt_${cfg}_${mode} -name '*.db' | head -1)
-  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r5_kernel_stats_${cfg}_${mode}.md 2>&1
-  head -40 $OUT/r5_kernel_stats_${cfg}_${mode}.md
+  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r6_kernel_stats_${cfg}_${mode}.md 2>&1
+  head -40 $OUT/r6_kernel_stats_${cfg}_${mode}.md
   ;;
 prof)
   cfg=${2:-c2}; mode=${3:-f16x2}
   args="--config $cfg --precision $mode --steps 2 --warmup 1 --cpu-pairs 0 --no-alt --no-latency --no-profile"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_${cfg}_${mode} -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/kt_${cfg}_${mode}.log 2>&1)
   db=$(find /tmp/kt_${cfg}_${mode} -name '*.db' | head -1)
-  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r5_kernel_stats_${cfg}_${mode}.md 2>&1
-  head -30 $OUT/r5_kernel_stats_${cfg}_${mode}.md
+  [ -n "$db" ] && python profiles/summarize_rocpd.py "$db" > $OUT/r6_kernel_stats_${cfg}_${mode}.md 2>&1
+  head -30 $OUT/r6_kernel_stats_${cfg}_${mode}.md
   i=0
   for ctr in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
     (cd /tmp && timeout 400 rocprofv3 --pmc $ctr -d /tmp/pmc_${cfg}_${mode}_$i -- python $GRAFT_REPO_ROOT/bench.py $args > $OUT/pmc_${cfg}_${mode}_$i.log 2>&1)
@@ -184,8 +187,8 @@ prof)
   d0=$(find /tmp/pmc_${cfg}_${mode}_0 -name '*.db' | head -1); d1=$(find /tmp/pmc_${cfg}_${mode}_1 -name '*.db' | head -1); d2=$(find /tmp/pmc_${cfg}_${mode}_2 -name '*.db' | head -1)
   cp profiles/pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null
   pairs=32; kpts=1024; [ "$cfg" = c4 ] && pairs=80; [ "$cfg" = c5 ] && { pairs=80; kpts=2048; }
-  python profiles/summarize_pmc.py "$d0" "$d1" "$d2" $OUT/r5_pmc_${cfg}_${mode}.md $OUT/pmc_traffic.json $cfg $mode $pairs $kpts > /dev/null 2> $OUT/pmc_${cfg}_${mode}_summ.err
-  head -12 $OUT/r5_pmc_${cfg}_${mode}.md
+  python profiles/summarize_pmc.py "$d0" "$d1" "$d2" $OUT/r6_pmc_${cfg}_${mode}.md $OUT/pmc_traffic.json $cfg $mode $pairs $kpts > /dev/null 2> $OUT/pmc_${cfg}_${mode}_summ.err
+  head -12 $OUT/r6_pmc_${cfg}_${mode}.md
   ;;
 *) echo "unknown stage $stage"; exit 2;;
 esac
