@@ -309,27 +309,6 @@ int launch_attention3f(e2emv_ctx* ctx, int B, int T, int n_rows, const int* n_va
 int launch_attention3(e2emv_ctx* ctx, int B, int T, int n_rows, const int* n_valid_img, int D, int H, const uint16_t* qk,
                       const uint16_t* vt, int cross, uint16_t* out3, float* out32, hipStream_t s);
 
-// ---- bf16x3 on PLANE activations (gemm_p3.hip, round 6): "P3" = [rows][C / 16 blocks of {16 p1 | 16 p2 | 16 p3} bf16], x = p1 + p2 + p3
-struct GemmP3Args {
-    int M = 0, N = 0, K = 0, K1 = 0;
-    const uint16_t* A = nullptr;   // P3 planes [M][lda columns]
-    int64_t lda = 0;
-    const uint16_t* A2 = nullptr;  // second K segment (k >= K1)
-    int64_t lda2 = 0;
-    const uint16_t* W = nullptr;   // P3 planes [N][K columns] (add_split_p3)
-    const float* bias = nullptr;
-    const uint16_t* R = nullptr;   // residual, P3 planes [M][ldr columns] (may alias C3)
-    int64_t ldr = 0;
-    bool relu = false;
-    float* C32 = nullptr;          // fp32 output [M][ldc] ...
-    uint16_t* C3 = nullptr;        // ... or P3 planes [M][ldc columns]
-    int64_t ldc = 0;
-};
-int launch_gemm_p3(e2emv_ctx* ctx, const GemmP3Args& a, hipStream_t s);
-int launch_to_planes3(e2emv_ctx* ctx, const float* src, int64_t rows, int C, int64_t ld_src, uint16_t* dst, hipStream_t s);
-int launch_from_planes3(e2emv_ctx* ctx, const uint16_t* src, int64_t rows, int C, float* dst, int64_t ld_dst, hipStream_t s);
-size_t add_split_p3(std::vector<uint16_t>& out, const std::vector<float>& w, int rows, int cols);
-
 // Sinkhorn on an internal score buffer S [n_groups * group_batch][M][ldS] (ldS % 4 == 0).  Batch
 // element bb belongs to output group bb / group_batch (= the image pair of a tuple): each group
 // has its own dense logZ [group_batch][M+1][N+1] (optional) and match outputs.

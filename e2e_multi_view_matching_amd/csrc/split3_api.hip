@@ -52,7 +52,7 @@ extern "C" int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const f
                                  const float* d_bias, float* d_C, int flags, void* stream) {
     if (!ctx || !d_A || !d_W || !d_C) return E2EMV_EINVAL;
     E2EMV_ENTER(ctx, stream);
-    if (M <= 0 || Nout <= 0 || K <= 0 || K % ((flags & 8) ? 16 : 32) || Nout % 4) return set_err(ctx, E2EMV_ESHAPE, "gemm_bf16x3: M=%d N=%d K=%d", M, Nout, K);
+    if (M <= 0 || Nout <= 0 || K <= 0 || K % 32 || Nout % 4) return set_err(ctx, E2EMV_ESHAPE, "gemm_bf16x3: M=%d N=%d K=%d", M, Nout, K);
     hipStream_t s = (hipStream_t)stream;
     auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
     const size_t szA = al((size_t)M * 3 * K * 2), szW = al((size_t)Nout * 3 * K * 2);
@@ -60,34 +60,6 @@ extern "C" int e2emv_gemm_bf16x3(e2emv_ctx* ctx, int M, int Nout, int K, const f
     if (rc) return rc;
     uint16_t* A3 = (uint16_t*)ctx->d_ws;
     uint16_t* W3 = (uint16_t*)(ctx->d_ws + szA);
-    if (flags & 8) {  // gemm_p3.hip: bf16x3 on pre-split P3 planes (activation converted by a helper launch, weights on the host); bit4: planes out
-        // bit5: d_C holds a residual R [M][N] on entry (added to the product; R and the plane output share one buffer as x does in MLP1)
-        if ((flags & (16 | 32)) && Nout % 16) return set_err(ctx, E2EMV_ESHAPE, "gemm_bf16x3 (planes out / residual): N = %d must be a multiple of 16", Nout);
-        const size_t szA3 = al((size_t)M * K * 6), szW3 = al((size_t)Nout * K * 6), szC3 = al((size_t)M * Nout * 6);
-        if ((rc = ws_reserve(ctx, szA3 + szW3 + szC3))) return rc;
-        uint16_t* Ap = (uint16_t*)ctx->d_ws;
-        uint16_t* Wp = (uint16_t*)(ctx->d_ws + szA3);
-        uint16_t* Cp = (uint16_t*)(ctx->d_ws + szA3 + szW3);
-        if ((flags & 32) && (rc = launch_to_planes3(ctx, d_C, M, Nout, Nout, Cp, s))) return rc;
-        std::vector<float> hw((size_t)Nout * K);
-        E2EMV_HIP(ctx, hipStreamSynchronize(s));
-        E2EMV_HIP(ctx, hipMemcpy(hw.data(), d_W, hw.size() * sizeof(float), hipMemcpyDeviceToHost));
-        std::vector<uint16_t> planes;
-        const size_t off = add_split_p3(planes, hw, Nout, K);
-        E2EMV_HIP(ctx, hipMemcpy(Wp, planes.data() + off, (size_t)Nout * K * 6, hipMemcpyHostToDevice));
-        if ((rc = launch_to_planes3(ctx, d_A, M, K, K, Ap, s))) return rc;
-        GemmP3Args g;
-        g.M = M; g.N = Nout; g.K = K; g.K1 = K; g.A = Ap; g.lda = K; g.W = Wp; g.bias = d_bias; g.relu = (flags & 1) != 0;
-        if (flags & 32) { g.R = Cp; g.ldr = Nout; }
-        if (flags & 16) { g.C3 = Cp; g.ldc = Nout; } else { g.C32 = d_C; g.ldc = Nout; }
-        const int reps = std::max(1, flags >> 8);
-        prof_begin(ctx, PS_GEMM, s);
-        for (int r = 0; r < reps && !rc; ++r) rc = launch_gemm_p3(ctx, g, s);
-        prof_end(ctx, s);
-        if (rc) return rc;
-        if (flags & 16) rc = launch_from_planes3(ctx, Cp, M, Nout, d_C, Nout, s);
-        return rc;
-    }
     if (flags & 4) {  // f16x2 GEMM (gemm_h2.hip); the weight planes are made on the host as e2emv_commit_weights makes them
         std::vector<float> hw((size_t)Nout * K);
         E2EMV_HIP(ctx, hipStreamSynchronize(s));

@@ -72,7 +72,7 @@ def attention(qkv, B, T, n_valid, H, cross):
     return out
 
 
-def gemm_bf16x3(A, W, bias=None, relu=False, all_planes=False, f16x2=False, p3=False, planes_out=False, residual=None, reps=1):
+def gemm_bf16x3(A, W, bias=None, relu=False, all_planes=False, f16x2=False):
     """bf16x3 split-operand GEMM building block on fp32 tensors: act(A W^T + bias).  Default: gemm_x3.hip (activations
     split on the way into LDS); ``all_planes=True``: the first-generation kernel that reads pre-split planes (gemm3.hip); ``f16x2=True``: the
     fp16 x 2 form of gemm_x3.hip (two activation planes, three products)."""
@@ -80,14 +80,11 @@ def gemm_bf16x3(A, W, bias=None, relu=False, all_planes=False, f16x2=False, p3=F
     A_, W_ = A.contiguous().float(), W.contiguous().float()
     M, K = A_.shape
     N = W_.shape[0]
-    # p3=True: gemm_p3.hip - bf16x3 on pre-split "P3" planes (round 6); planes_out: the kernel writes planes (read back as fp32);
-    # residual [M][N]: added in the epilogue from ITS planes; reps: timed repetitions of the kernel alone (profile slot "gemm")
-    C = residual.contiguous().float().clone() if residual is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
+    C = torch.empty((M, N), dtype=torch.float32, device=A.device)
     b = bias.contiguous().float() if bias is not None else None
-    flags = (1 if relu else 0) | (2 if all_planes else 0) | (4 if f16x2 else 0) | (8 if p3 else 0) | (16 if planes_out else 0) | (32 if residual is not None else 0)
-    flags |= (int(reps) << 8) if reps > 1 else 0
     with torch.cuda.device(A.device):
-        ctx.call("e2emv_gemm_bf16x3", M, N, K, _lib.ptr(A_), _lib.ptr(W_), _lib.ptr(b), _lib.ptr(C), flags, _lib.stream_ptr(A.device))
+        ctx.call("e2emv_gemm_bf16x3", M, N, K, _lib.ptr(A_), _lib.ptr(W_), _lib.ptr(b), _lib.ptr(C), (1 if relu else 0) | (2 if all_planes else 0) | (4 if f16x2 else 0),
+                 _lib.stream_ptr(A.device))
     return C
 
 

@@ -109,37 +109,6 @@ def test_extract_matches_vs_oracle(gpu):
 
 
 # ---------------------------------------------------------------- bf16x3 split-operand building blocks
-@pytest.mark.parametrize("M,N,K", [(300, 208, 64), (1024, 512, 512), (65, 36, 256), (256, 256, 48), (2048, 768, 256), (700, 256, 512)])
-@pytest.mark.parametrize("variant", ["f32out", "planes", "planes+relu+residual"])
-def test_gemm_p3_bf16x3_on_planes(gpu, M, N, K, variant):
-    """gemm_p3.hip (round 6): the bf16x3 arithmetic on pre-split P3 planes - against fp64 at the bar of the in-loop-split kernel
-    (gemm_x3.hip), with the plane output (three bf16 planes = 24 bits: one more rounding of the result) and the residual read back
-    from ITS planes."""
-    import e2e_multi_view_matching_amd as E
-    if variant != "f32out" and N % 16:
-        pytest.skip("plane output: N % 16")
-    g = torch.Generator().manual_seed(M + N + K)
-    A = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g) * 2)   # rows spanning ~4 decades
-    W = torch.randn(N, K, generator=g) / K ** 0.5
-    b = torch.randn(N, generator=g)
-    Rs = torch.randn(M, N, generator=g) * torch.exp(torch.randn(M, 1, generator=g) * 2) if "residual" in variant else None
-    ref = A.double() @ W.double().T + b.double()
-    scale = (A.double().abs() @ W.double().abs().T) + b.double().abs()
-    if "relu" in variant:
-        ref = ref.clamp_min(0)
-    if Rs is not None:
-        ref = ref + Rs.double()
-        scale = scale + Rs.double().abs()
-    out = E.gemm_bf16x3(A.to(gpu), W.to(gpu), bias=b.to(gpu), relu="relu" in variant, p3=True, planes_out=variant != "f32out",
-                        residual=Rs.to(gpu) if Rs is not None else None).cpu()
-    out3 = E.gemm_bf16x3(A.to(gpu), W.to(gpu), bias=b.to(gpu)).cpu() if variant == "f32out" and K % 32 == 0 else None
-    e = float(((out.double() - ref).abs() / scale).max())
-    assert e < 4e-7, e
-    if out3 is not None:  # the same products as gemm_x3, summed in another order
-        e3 = float(((out3.double() - (A.double() @ W.double().T + b.double())).abs() / scale).max())
-        assert e < 2 * e3 + 1e-7, (e, e3)
-
-
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 64), (1024, 512, 512), (65, 36, 256)])
 def test_gemm_bf16x3_has_fp32_class_accuracy(gpu, M, N, K):
     import e2e_multi_view_matching_amd as E
