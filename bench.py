@@ -615,6 +615,12 @@ def run(args):
             k = w_["kernels"][kname]
             if w_.get("csrc_stamp") and w_["csrc_stamp"] == _stamp():
                 traffic = int(k["read_bytes"] + k["write_bytes"])
+                # attention_p2w runs as up to three instantiations per layer (self / cross items, and the key-split parts of the
+                # leftover items - a launch of their own): bytes of ALL of them per LAYER launch, not the average over instantiations
+                var = {n: e for n, e in w_["kernels"].items() if n.startswith(kname + "<")}
+                whole = sum(e["launches"] for n, e in var.items() if not n.rstrip(">").rstrip().endswith("true"))
+                if fam == "attention" and len(var) > 1 and whole > 0:
+                    traffic = int(sum((e["read_bytes"] + e["write_bytes"]) * e["launches"] for e in var.values()) / whole)
                 traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command (tools/gpu.sh prof) on these very sources "
                                f"(csrc stamp {w_['csrc_stamp'][:12]}), not measured in this run")
             else:
