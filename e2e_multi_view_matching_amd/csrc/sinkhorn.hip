@@ -1861,6 +1861,12 @@ static void launch_sweeps(const SkParams& p, int B, bool final, hipStream_t s) {
     }
 }
 
+// every polled word of a resident launch starts from 0 (epochs count from 1), and so does the launch's give-up flag
+__global__ __launch_bounds__(256) void skr_zero_kernel(uint4* buf, size_t n16, unsigned* flag) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) buf[i] = uint4{0u, 0u, 0u, 0u};
+    if (blockIdx.x == 0 && threadIdx.x == 0) flag[0] = 0u;
+}
+
 // ---- the launcher's plan, shared by launch_sinkhorn and the e2emv_sinkhorn_plan query (bench.py reports it instead of re-deriving it)
 struct SkKernel { const void* fn = nullptr; int rows = 0, threads = 512, wg_per_cu = 0; size_t lds = 0; bool big = false; };
 struct SkSegment { int b0 = 0, n = 0; SkKernel k; int resident = 0; };
@@ -2049,8 +2055,10 @@ int launch_sinkhorn(e2emv_ctx* ctx, int B, int M, int N, const float* S, int64_t
             rpar.flags = dbg_knob("E2EMV_SKR_FLAGS", rpar.flags);
             rpar.u = p.u + (int64_t)b0 * (M + 1); rpar.v = p.v + (int64_t)b0 * p.ldV; rpar.ldV = p.ldV;
             // every polled word starts from 0 in every launch (epochs count from 1)
-            E2EMV_HIP(ctx, hipMemsetAsync(w, 0, rp.bytesA + rp.bytesB + rp.bytesU, s));
-            E2EMV_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, 4, s));
+            // (ONE launch for the granule buffers and the give-up flag: two hipMemsetAsync were two fill kernels of ~14 us each per segment)
+            hipLaunchKernelGGL(skr_zero_kernel, dim3((unsigned)std::min<size_t>(1024, ((rp.bytesA + rp.bytesB + rp.bytesU) / 16 + 255) / 256)), dim3(256), 0, s,
+                               reinterpret_cast<uint4*>(w), (rp.bytesA + rp.bytesB + rp.bytesU) / 16, ctx->d_flags);
+            E2EMV_CHECK_LAUNCH(ctx, "skr_zero_kernel");
             hipLaunchKernelGGL_ptr(k.fn, dim3((unsigned)(rp.n_res * rp.G)), dim3(k.threads), k.lds, s, rpar);
             E2EMV_CHECK_LAUNCH(ctx, "sinkhorn_resident");
             if (d_dbg) {  // development aid: per-phase timestamps of resident problem 0, appended as text
