@@ -674,6 +674,13 @@ def run(args):
                           f"peak = dense 16-bit MFMA 2500 TFLOP/s / {products} MFMA products per algorithmic flop (split operands)")) +
                         "; traffic = HBM bytes per launch (read + write) from the PMC passes under profiles/",
                 "avg_launch_ms": round(ms / max(n, 1), 4), "launches_per_step": n // args.steps})
+        if mode_ in ("f16x2", "bf16x3"):
+            # what the matrix pipe SUSTAINS on this chip for a stream of nothing but 32x32x16 16-bit MFMAs on random operands (tools/wp_gemm.hip,
+            # profiles/r6_wp_gemm.log: 1.66 PFLOP/s = 0.67 of the 2.5 PFLOP/s the `peak` above is derived from - the clock settles at ~1.6 GHz under a
+            # saturated pipe).  Supplementary: `frac` stays priced against the guide's nominal peak.
+            sustained = 1665.0 / products
+            main["sustained_matrix_rate"] = {"tflops": round(sustained, 1), "frac": round(achieved / sustained, 4),
+                                             "source": "measured: tools/wp_gemm.hip 'MFMAs only' steady state, profiles/r6_wp_gemm.log (not a spec number)"}
         fam2 = "attention" if fam == "gemm" else "gemm"
         a2, _, _ = family(fam2)
         second = {"kernel": fam2, "achieved": round(a2, 2), "unit": "TFLOP/s", "frac": round(a2 / peak, 4)}
