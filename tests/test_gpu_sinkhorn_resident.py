@@ -248,3 +248,25 @@ def test_dynamic_range_of_the_exponential_domain(gpu):
         _stream_mode(False)
     ref = log_optimal_transport(s.double(), 1.0, 100).float()
     assert bool(torch.isfinite(out).all()) and float((out - ref).abs().max()) < 5e-3  # fp32 log domain at |logZ| ~ 1200
+
+
+def test_the_launchers_plan_is_queryable_and_follows_the_pin(gpu):
+    """e2emv_sinkhorn_plan (round 6): what launch_sinkhorn would run for a batch on this context - bench.py reports its Sinkhorn bound
+    from it instead of re-deriving the heuristic - and the per-context kernel pin that replaces the per-call getenv."""
+    from e2e_multi_view_matching_amd import _lib
+    ctx = _lib.context(gpu)
+    try:
+        ctx.set_sinkhorn_kernel(None)
+        assert ctx.sinkhorn_plan(32, 1024, 1024, 100) == [{"rows_per_workgroup": 128, "problems": 32, "resident_problems": 32, "rounds": 1}]
+        p80 = ctx.sinkhorn_plan(80, 1024, 1024, 100)   # configs[3]: 64 on 128-row workgroups (2 rounds) + 16 on 64-row ones
+        assert [(s["rows_per_workgroup"], s["problems"], s["rounds"]) for s in p80] == [(128, 64, 2), (64, 16, 1)]
+        assert ctx.sinkhorn_plan(80, 2048, 2048, 100) == [{"rows_per_workgroup": 64, "problems": 80, "resident_problems": 8, "rounds": 10}]
+        assert ctx.sinkhorn_plan(4, 256, 256, 0) == []                      # iters = 0: the log-domain chain
+        ctx.set_sinkhorn_kernel("rows64")
+        assert [s["rows_per_workgroup"] for s in ctx.sinkhorn_plan(32, 1024, 1024, 100)] == [64]
+        ctx.set_sinkhorn_kernel("rows128")
+        assert [(s["rows_per_workgroup"], s["rounds"]) for s in ctx.sinkhorn_plan(80, 1024, 1024, 100)] == [(128, 3)]
+        ctx.set_sinkhorn_kernel("stream")
+        assert ctx.sinkhorn_plan(32, 1024, 1024, 100) == []
+    finally:
+        ctx.set_sinkhorn_kernel(None)
