@@ -709,6 +709,16 @@ def run(args):
                             "us_per_launch": round(us, 1), "hbm_gbs": round(4 * U / us / 1e3, 1), "frac_hbm": round(4 * U / us / 1e3 / PEAK_HBM_GBS, 4),
                             "tflops_eq": round(fp / us / 1e6, 1), "frac_mfma": round(fp / us / 1e6 / peak, 4)})
             main["per_kernel"] = per
+            # The line's roofline is the NAMED kernel's own: its algorithmic flops per launch / its own average launch time (HIP events),
+            # not the family average (the family holds the small launches too); the family's numbers move to `family`.
+            own = next((e for e in per if e["kernel"].startswith(kname)), None)
+            if own is not None and main["bound"] == "mfma":
+                main["family"] = {"achieved": main["achieved"], "frac": main["frac"], "avg_launch_ms": main["avg_launch_ms"],
+                                  "launches_per_step": main["launches_per_step"], "unit": "TFLOP/s"}
+                main["achieved"], main["frac"] = own["tflops_eq"], own["frac_mfma"]
+                main["avg_launch_ms"], main["launches_per_step"] = round(own["us_per_launch"] / 1e3, 4), own["launches_per_step"]
+                if "sustained_matrix_rate" in main:
+                    main["sustained_matrix_rate"]["frac"] = round(own["tflops_eq"] / main["sustained_matrix_rate"]["tflops"], 4)
             main["per_kernel_note"] = ("HIP events around each kernel instantiation's launches in the timed steps (the interval of a launch ends where "
                                        "the next family's begins: dispatch gaps included); bytes = compulsory activation traffic of the launch, flops = "
                                        "algorithmic; a chained launch is priced at its OWN compulsory 6 U (read [x | message] 2, write x_new 1, "
