@@ -820,6 +820,7 @@ def run(args):
                                                         "max_abs_err_deg_diff": float(np.max(np.abs(eh - eo))),
                                                         "note": "the reference's own fp32 arccos on each side: ill-conditioned below a degree"}}
     if dist is not None:
+        _dist_mod.close_library_comms()  # (the library's RCCL communicator, if the metric gather used it: before the process group goes)
         dist.destroy_process_group()
         # RCCL writes its version banner through C stdio: flush it now so that the JSON line below is the LAST line
         import ctypes

@@ -119,6 +119,24 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def close_library_comms():
+    """Destroys the library communicators this process made (before torch.distributed.destroy_process_group / interpreter exit: an RCCL
+    communicator left alive at exit is torn down in an unspecified order)."""
+    for key, comm in list(_lib_comm.items()):
+        try:
+            if comm is not None:
+                torch.cuda.synchronize()
+                comm.close()
+        except Exception:  # noqa: BLE001
+            pass
+        _lib_comm.pop(key, None)
+
+
+import atexit  # noqa: E402
+
+atexit.register(close_library_comms)
+
+
 def gather_pair_errors(local_errors, device=None, group=None):
     """All-gather variable-length per-pair pose errors (degrees); every rank gets the full array
     in rank order.  inf marks a pair whose pose could not be computed (``eval_pairs.py:259``)."""
