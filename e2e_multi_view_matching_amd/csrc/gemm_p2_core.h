@@ -223,8 +223,16 @@ __device__ __forceinline__ void gp_acc_fence(p2_f32x16 (&acc)[4][2]) {
     asm volatile("s_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
 }
 
-template <int OUT, bool HAS_R, int DBG>
+// RLDS (round 6; the chained kernel's MLP1, whose successor tile is hard-dependent: nothing runs ahead, both tile buffers are idle): the
+// residual blocks arrive in LDS instead of in registers - a ring of four 4 KB block slots in the wave's own 16 KB of the tile buffers,
+// filled by LDS-direct loads: blocks 0 - 3 go out at the head of the epilogue, IN FRONT of every store, block b + 4 when block b's slot has
+// been read.  In the register form a block's residual load sits in the in-order memory queue behind the stores of the block before it and
+// the wave cannot go on until it returns: eight store + load round trips per tile (MLP1's epilogue: 24.5 us against 10 for the others);
+// here a load is waited for four blocks after it was issued, with a counted vmcnt that leaves everything younger in flight.
+// (M a multiple of 256 and whole column tiles: the chained kernel's own conditions.)
+template <int OUT, bool HAS_R, int DBG, bool RLDS = false>
 __device__ __forceinline__ void gp_epilogue(const GemmP2Params& p, char* smem, const p2_f32x16 (&acc)[4][2], int wave, int tm, int tn, int e_run, int ev) {
+    static_assert(!RLDS || (HAS_R && OUT == P2_OUT_PLANES), "the LDS residual ring belongs to the plane epilogue with a residual");
     // (the lane index is recomputed per tile: everything the epilogue derives from it - slab positions, store offsets, masks -
     // is then recomputed per tile, a few dozen integer instructions, instead of being hoisted out of the tile loop and held in
     // registers across the K loop, where there are none to spare)
@@ -362,7 +370,8 @@ __device__ __forceinline__ void gp_epilogue(const GemmP2Params& p, char* smem, c
     }
     // bias: without a residual the epilogue issues NO load behind its first store (all four column blocks up front, 32
     // registers); with one, the bias of block b + 1 travels with its residual loads (the registers go to the residual)
-    constexpr int NB = HAS_R ? 2 : 4;
+    constexpr bool RREG = HAS_R && !RLDS;  // the residual through registers, a block ahead (gemm_p2; every chained tile but MLP1)
+    constexpr int NB = RREG ? 2 : 4;
     p2_f32x4 bias8[NB][2];
     auto load_bias = [&](int slot, int j) {
         const int n = tn * P2_BN + wc * 128 + j * 32 + o_c;
@@ -370,12 +379,38 @@ __device__ __forceinline__ void gp_epilogue(const GemmP2Params& p, char* smem, c
         if (p.bias && n < p.N) bias8[slot][0] = *reinterpret_cast<const p2_f32x4*>(p.bias + n);
         if (p.bias && n + 4 < p.N) bias8[slot][1] = *reinterpret_cast<const p2_f32x4*>(p.bias + n + 4);
     };
-    if (!HAS_R) {
+    if (!RREG) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) load_bias(j, j);
     }
+    // ---- RLDS: the ring.  Slot s = this wave's 16 KB of the tile buffers + 4 KB s; a block = 32 rows x 128 B (one 32-column plane block per
+    // row), moved by 4 LDS-direct loads of 8 rows; chunk c of row r sits at position c ^ (((r >> 1) & 1) << 2) (the hi / lo halves of odd row
+    // pairs swapped: conflict-free 16-byte reads in the row-contiguous view)
+    char* const rl_base = smem + wave * 16384;
+    __amdgpu_buffer_rsrc_t rsR;
+    unsigned rl_vo = 0;
+    if constexpr (RLDS) {
+        rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.Rp), 0, (int)((unsigned)p.M * (unsigned)p.ldr * 4u), 0x00020000);
+        const unsigned r8 = (unsigned)lane >> 3, pos = (unsigned)lane & 7u;
+        rl_vo = r8 * (unsigned)p.ldr * 4u + ((pos ^ (((r8 >> 1) & 1u) << 2)) * 16u);
+    }
+    auto rl_issue = [&](int bb) {
+        if constexpr (RLDS) {
+            const int i = bb >> 2, j = bb & 3;
+            const unsigned m0 = (unsigned)(tm * P2_BM + wr * 64 + i * 32);
+            const unsigned so = m0 * (unsigned)p.ldr * 4u + (unsigned)(tn * 8 + wc * 4 + j) * 128u;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p2_glds16(rsR, rl_base + (bb & 3) * 4096 + q * 1024, rl_vo, so + (unsigned)q * 8u * (unsigned)p.ldr * 4u);
+            asm volatile("" ::: "memory");
+        }
+    };
+    if constexpr (RLDS) {  // (behind the bias loads, in front of everything else this epilogue puts into the memory queue)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) rl_issue(bb);
+    }
     p2_f32x4 rv[2][2][2];              // [parity][pass][half]: the block in the row-contiguous view
-    p2_u32x4 rr[HAS_R ? 2 : 1][2][2];  // [parity][pass][plane]: its residual
+    p2_u32x4 rr[RREG ? 2 : 1][2][2];   // [parity][pass][plane]: its residual
     // this lane's first row / column of the tile in the row-contiguous view; block (i, j), pass: row0 + 32 i + 16 pass,
     // columns col0 + 32 j .. + 7.  Addresses = one per-tile base + wave-uniform steps (per-store index arithmetic in 64 bits
     // was a tenth of the epilogue's instructions)
@@ -392,9 +427,9 @@ __device__ __forceinline__ void gp_epilogue(const GemmP2Params& p, char* smem, c
         constexpr int b = decltype(BB)::value;
         constexpr int i = b >> 2, j = b & 3;
         slab_write(i, j);
-        if (HAS_R) load_bias(b & 1, j);
+        if (RREG) load_bias(b & 1, j);
         const uint16_t* rcol = nullptr;
-        if constexpr (HAS_R) {
+        if constexpr (RREG) {
             const int nc = min(col0 + j * 32, p.N - 8);
             rcol = p.Rp + ((nc >> 5) * 64 + (nc & 31));
         }
@@ -404,7 +439,7 @@ __device__ __forceinline__ void gp_epilogue(const GemmP2Params& p, char* smem, c
             const int c0 = 2 * (lane & 3);
             rv[b & 1][pass][0] = *reinterpret_cast<const p2_f32x4*>(sl + r * 128 + ((c0 ^ o_z) << 4));
             rv[b & 1][pass][1] = *reinterpret_cast<const p2_f32x4*>(sl + r * 128 + (((c0 + 1) ^ o_z) << 4));
-            if constexpr (HAS_R) {
+            if constexpr (RREG) {
                 int m = min(row0 + i * 32 + 16 * pass, p.M - 1);
                 if (DBG & 8192) m &= 255;  // measurement: the residual from an L2-resident slab
                 const uint16_t* rp = rcol + (int64_t)m * (2 * p.ldr);
@@ -423,22 +458,38 @@ __device__ __forceinline__ void gp_epilogue(const GemmP2Params& p, char* smem, c
         // residual sum commute with it) - the bias once per use of its registers, the accumulator scale as a uniform
         float osf = os, rsf = 1.f;
         if constexpr (HAS_R) rsf = rsc[j >> 1];
+        // RLDS: this block's residual from its ring slot.  Issue order of the wave's memory queue: [bias] L0 L1 L2 L3 | L4 S0 | L5 S1 | L6 S2 | L7 S3 |
+        // S4 | S5 | S6 | S7 (L = 4 loads, S = 4 stores): the wait for L_b leaves everything younger in flight
+        p2_u32x4 rq[2][2];
+        if constexpr (RLDS) {
+            constexpr int CNT[8] = {12, 16, 20, 24, 28, 24, 20, 16};
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CNT[b]) : "memory");
+            const unsigned sw = (((unsigned)o_r >> 1) & 1u) << 2;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const char* rp_ = rl_base + (b & 3) * 4096 + (o_r + 16 * pass) * 128;
+                rq[pass][0] = *reinterpret_cast<const p2_u32x4*>(rp_ + ((((unsigned)lane & 3u) ^ sw) << 4));
+                rq[pass][1] = *reinterpret_cast<const p2_u32x4*>(rp_ + (((4u + ((unsigned)lane & 3u)) ^ sw) << 4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]) :: "memory");  // in registers before the slot is refilled
+            if constexpr (b < 4) rl_issue(b + 4);
+        }
         if constexpr (OUT == P2_OUT_PLANES) {
             osf = os * fa;
             rsf *= fa;
-            if (HAS_R || i == 0) { bias8[HAS_R ? (b & 1) : j][0] *= fa; bias8[HAS_R ? (b & 1) : j][1] *= fa; }
+            if (RREG || i == 0) { bias8[RREG ? (b & 1) : j][0] *= fa; bias8[RREG ? (b & 1) : j][1] *= fa; }
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             const bool ok = col_ok && i * 32 + 16 * pass < rows_left;
-            p2_f32x4 v0 = rv[b & 1][pass][0] * osf + bias8[HAS_R ? (b & 1) : j][0];
-            p2_f32x4 v1 = rv[b & 1][pass][1] * osf + bias8[HAS_R ? (b & 1) : j][1];
+            p2_f32x4 v0 = rv[b & 1][pass][0] * osf + bias8[RREG ? (b & 1) : j][0];
+            p2_f32x4 v1 = rv[b & 1][pass][1] * osf + bias8[RREG ? (b & 1) : j][1];
             if constexpr (OUT != P2_OUT_QKV) {
                 gp_relu2x8(v0, v1, p.relu);
                 if constexpr (OUT == P2_OUT_F32 || HAS_R) { v0 *= unfold; v1 *= unfold; }  // (no plane scale to fold the 1/2 into)
             }
             if constexpr (HAS_R) {
-                const p2_u32x4 rh = rr[b & 1][pass][0], rl = rr[b & 1][pass][1];
+                const p2_u32x4 rh = RLDS ? rq[pass][0] : rr[RREG ? (b & 1) : 0][pass][0], rl = RLDS ? rq[pass][1] : rr[RREG ? (b & 1) : 0][pass][1];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const p2_f32x2 a = gp_join_scaled(rh[e], rl[e]), c = gp_join_scaled(rh[2 + e], rl[2 + e]);

@@ -309,7 +309,17 @@ __global__ __launch_bounds__(512, 1) void gemm_p2_chain_kernel(GemmP2ChainParams
             constexpr int EDBG = DBG & (64 | 128 | 8192);  // no stores | stores into 1 MB | residual from a slab
             switch (cp.kind[s]) {
                 case P2_OUT_PLANES: gp_epilogue<P2_OUT_PLANES, false, EDBG>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
-                case P2_OUT_PLANES | 4: gp_epilogue<P2_OUT_PLANES, true, EDBG>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
+                case P2_OUT_PLANES | 4:
+                    // MLP1: the tile behind it is hard-dependent - nothing has run ahead into the tile buffers; once every wave is through
+                    // the last K step they carry this epilogue's residual ring (gemm_p2_core.h, RLDS).  (E2EMV_P2C_DBG 32768, measurement
+                    // build: the residual through registers as before)
+                    if (ld_blocked && !(DBG & 32768)) {
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        gp_epilogue<P2_OUT_PLANES, true, EDBG, true>(q, smem_p2c, acc, wave, tm, tn, e_run, ev);
+                    } else {
+                        gp_epilogue<P2_OUT_PLANES, true, EDBG>(q, smem_p2c, acc, wave, tm, tn, e_run, ev);
+                    }
+                    break;
                 case P2_OUT_QKV: gp_epilogue<P2_OUT_QKV, false, EDBG>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
                 default: gp_epilogue<P2_OUT_F32, false, EDBG>(q, smem_p2c, acc, wave, tm, tn, e_run, ev); break;
             }
@@ -415,6 +425,8 @@ int launch_gemm_p2_chain(e2emv_ctx* ctx, const GemmP2Args* a, const int* dep_kt,
         case 4160: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<4160>); break;  // no stores AND L2-resident activations
         case 32: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<32>); break;      // no per-step barrier
         case 36: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<36>); break;
+        case 32768: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<32768>); break;  // MLP1's residual through registers (the round-5 form)
+        case 32776: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<32776>); break;  // ... with per-tile stamps
         case 12416: fn = reinterpret_cast<const void*>(gemm_p2_chain_kernel<12416>); break;  // 4096 + 8192 + 128: no HBM traffic but the weights
         default: break;
     }
